@@ -1,0 +1,470 @@
+"""CPU ORACLE for the IsoCon alignment + nearest-neighbour-graph hot path.
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+leg; the product package (isocon_amd/) never imports it.  PARITY STATUS: "parity unpinned" -- see the header
+of isocon_oracle.c (edlib / parasail are absent third-party dependencies and the reference's own tests pin
+no value of this path).
+
+Two layers:
+  * thin ctypes bindings over oracle/_build/libisocon_oracle.so (built by oracle/Makefile);
+  * a restatement of the reference's four hot-path modules with the reference's signatures and return
+    shapes, each function citing the reference lines it follows (paths relative to /root/reference):
+        EAM = modules/edlib_alignment_module.py      SWM = modules/SW_alignment_module.py
+        NNG = modules/nearest_neighbor_graph.py      GBA = modules/get_best_alignments.py
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from multiprocessing import Pool
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libisocon_oracle.so")
+_lib = None
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle (gcc) if needed and return the path of the shared object."""
+    src = os.path.join(_HERE, "isocon_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.orc_ed_dp.restype = ctypes.c_int32
+        L.orc_ed_dp.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]
+        L.orc_ed_bounded.restype = ctypes.c_int32
+        L.orc_ed_bounded.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]
+        L.orc_ed_pairs.restype = None
+        L.orc_ed_pairs.argtypes = [_u8p, _i64p, _i32p, _i32p, _i32p, ctypes.c_int64, _i32p]
+        for f in (L.orc_nn_1set, L.orc_nn_2set):
+            f.restype = ctypes.c_int64
+            f.argtypes = [_u8p, _i64p, ctypes.c_int32, _u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                          _i64p, _i32p, _i32p, ctypes.c_int64, _i64p]
+        L.orc_sg_trace.restype = ctypes.c_int32
+        L.orc_sg_trace.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32,
+                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                   _u32p, ctypes.c_int64, _i64p, _i32p]
+        L.orc_sg_score.restype = ctypes.c_int32
+        L.orc_sg_score.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32,
+                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        _lib = L
+    return _lib
+
+
+def _b(s) -> bytes:
+    return s if isinstance(s, bytes) else s.encode("ascii")
+
+
+def pack(seqs):
+    """list[str] -> (uint8 buffer, int64 offsets[n+1])."""
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    buf = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8) if len(seqs) else np.zeros(0, np.uint8)
+    if buf.size == 0:
+        buf = np.zeros(1, np.uint8)
+    return np.ascontiguousarray(buf), off
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+# ---------------------------------------------------------------------------------------------------
+# primitive bindings
+# ---------------------------------------------------------------------------------------------------
+
+def ed_dp(a: str, b: str) -> int:
+    a, b = _b(a), _b(b)
+    return lib().orc_ed_dp(a, len(a), b, len(b))
+
+
+def ed_bounded(a: str, b: str, k: int = -1) -> int:
+    """edlib.align(a, b, mode="NW", task="distance", k=k)["editDistance"] (NNG:104-107)."""
+    a, b = _b(a), _b(b)
+    return lib().orc_ed_bounded(a, len(a), b, len(b), int(k))
+
+
+def ed_pairs(seqs, a_idx, b_idx, k=None) -> np.ndarray:
+    buf, off = pack(seqs)
+    a_idx = np.ascontiguousarray(a_idx, dtype=np.int32)
+    b_idx = np.ascontiguousarray(b_idx, dtype=np.int32)
+    out = np.empty(len(a_idx), dtype=np.int32)
+    kk = None if k is None else np.ascontiguousarray(k, dtype=np.int32)
+    lib().orc_ed_pairs(_p(buf, _u8p), _p(off, _i64p), _p(a_idx, _i32p), _p(b_idx, _i32p),
+                       _p(kk, _i32p) if kk is not None else None, len(a_idx), _p(out, _i32p))
+    return out
+
+
+def _nn(fn, seqs, flags, start, count, depth):
+    buf, off = pack(seqs)
+    flags = np.ascontiguousarray(flags, dtype=np.uint8)
+    row_ptr = np.zeros(count + 1, dtype=np.int64)
+    cap = max(16 * count, 1024)
+    calls = ctypes.c_int64(0)
+    depth = int(min(depth, 2 ** 62))
+    while True:
+        cols = np.empty(cap, dtype=np.int32)
+        eds = np.empty(cap, dtype=np.int32)
+        r = fn(_p(buf, _u8p), _p(off, _i64p), len(seqs), _p(flags, _u8p), start, count, depth,
+               _p(row_ptr, _i64p), _p(cols, _i32p), _p(eds, _i32p), cap, ctypes.byref(calls))
+        if r >= 0:
+            return row_ptr, cols[:r], eds[:r], calls.value
+        cap = -r
+
+
+def nn_1set(seqs, converged, start, count, depth=2 ** 32):
+    """C restatement of NNG:110-198 on a length-sorted list; returns (row_ptr, cols, eds, n_edlib_calls)."""
+    return _nn(lib().orc_nn_1set, seqs, converged, start, count, depth)
+
+
+def nn_2set(seqs, is_target, start, count, depth=2 ** 32):
+    """C restatement of NNG:341-424; rows of target entries are empty."""
+    return _nn(lib().orc_nn_2set, seqs, is_target, start, count, depth)
+
+
+_OPS = "=XID"
+
+
+def sg_trace(s1: str, s2: str, match=2, mismatch=-3, open_=2, ext=0, policy=0):
+    """parasail.sg_trace_scan_16(s1, s2, open, ext, matrix_create("ACGT", match, mismatch)) restated.
+    Returns dict(cigar, score, end_query, end_ref, matches, mismatches, indels)."""
+    a, b = _b(s1), _b(s2)
+    cap = len(a) + len(b) + 4
+    ops = np.empty(cap, dtype=np.uint32)
+    n_ops = ctypes.c_int64(0)
+    res = np.zeros(6, dtype=np.int32)
+    rc = lib().orc_sg_trace(a, len(a), b, len(b), match, mismatch, open_, ext, policy,
+                            _p(ops, _u32p), cap, ctypes.byref(n_ops), _p(res, _i32p))
+    if rc != 0:
+        raise MemoryError("orc_sg_trace")
+    cig = "".join("%d%s" % (int(o) >> 4, _OPS[int(o) & 15]) for o in ops[:n_ops.value])
+    return dict(cigar=cig, score=int(res[0]), end_query=int(res[1]), end_ref=int(res[2]),
+                matches=int(res[3]), mismatches=int(res[4]), indels=int(res[5]))
+
+
+def sg_score(s1, s2, match=2, mismatch=-3, open_=2, ext=0) -> int:
+    a, b = _b(s1), _b(s2)
+    return lib().orc_sg_score(a, len(a), b, len(b), match, mismatch, open_, ext)
+
+
+# ---------------------------------------------------------------------------------------------------
+# EAM -- modules/edlib_alignment_module.py
+# ---------------------------------------------------------------------------------------------------
+
+def edlib_alignment(x, y, i, j, x_acc="", y_acc=""):
+    """EAM:107-128."""
+    ed = ed_bounded(x, y, -1)
+    assert ed >= 0
+    if x_acc == y_acc == "":
+        return (x, y, ed)
+    return (x_acc, y_acc, (x, y, ed))
+
+
+def _eam_task(task):
+    args, kwargs = task
+    return edlib_alignment(*args, **kwargs)
+
+
+def _pool_map(fn, tasks, nr_cores):
+    # EAM:28-41 / SWM:124-153 / NNG:28-74: Pool(processes=nr_cores).map_async(...).get()
+    with Pool(processes=nr_cores) as pool:
+        return pool.map_async(fn, tasks).get(999999999)
+
+
+def edlib_align_sequences(matches, nr_cores=1):
+    """EAM:10-49.  {s1: iterable(s2)} -> {s1: {s2: ed}}, sequence-keyed; keys without members are absent."""
+    tasks = [((s1, s2, i, j), {}) for j, s1 in enumerate(matches) for i, s2 in enumerate(matches[s1])]
+    results = map(_eam_task, tasks) if nr_cores == 1 else _pool_map(_eam_task, tasks, nr_cores)
+    out = {}
+    for s1, s2, ed in results:
+        out.setdefault(s1, {})[s2] = ed
+    return out
+
+
+def edlib_align_sequences_keeping_accession(matches, nr_cores=1):
+    """EAM:51-99.  {acc1: {acc2: (s1, s2)}} -> {acc1: {acc2: (s1, s2, ed)}}."""
+    tasks = [((matches[a1][a2][0], matches[a1][a2][1], i, j), {"x_acc": a1, "y_acc": a2})
+             for j, a1 in enumerate(matches) for i, a2 in enumerate(matches[a1])]
+    results = map(_eam_task, tasks) if nr_cores == 1 else _pool_map(_eam_task, tasks, nr_cores)
+    out = {}
+    for a1, a2, triple in results:
+        out.setdefault(a1, {})[a2] = triple
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# SWM -- modules/SW_alignment_module.py
+# ---------------------------------------------------------------------------------------------------
+
+def cigar_to_seq(cigar, query, ref):
+    """SWM:15-56.  '='/'X' copy both, 'I' consumes the query ('-' in ref), 'D' consumes the ref."""
+    q_parts, r_parts = [], []
+    qi = ri = 0
+    num = 0
+    for ch in cigar:
+        if ch.isdigit():
+            num = num * 10 + ord(ch) - 48
+            continue
+        if ch in "=X":
+            q_parts.append(query[qi:qi + num]); r_parts.append(ref[ri:ri + num]); qi += num; ri += num
+        elif ch == "I":
+            q_parts.append(query[qi:qi + num]); r_parts.append("-" * num); qi += num
+        elif ch == "D":
+            q_parts.append("-" * num); r_parts.append(ref[ri:ri + num]); ri += num
+        else:
+            raise SystemExit("error: bad cigar op %r in %s" % (ch, cigar))  # SWM:51-54 calls sys.exit()
+        num = 0
+    return "".join(q_parts), "".join(r_parts)
+
+
+def parasail_alignment(s1, s2, i, j, x_acc="", y_acc="", match_score=2, mismatch_penalty=-3,
+                       opening_penalty=2, gap_ext=0, tie_policy=0):
+    """SWM:64-86 (tie_policy is the oracle's extra knob, see isocon_oracle.c)."""
+    r = sg_trace(s1, s2, match_score, mismatch_penalty, opening_penalty, gap_ext, tie_policy)
+    s1_aln, s2_aln = cigar_to_seq(r["cigar"], s1, s2)
+    mismatches = sum(1 for a, b in zip(s1_aln, s2_aln) if a != b and a != "-" and b != "-")
+    matches = sum(1 for a, b in zip(s1_aln, s2_aln) if a == b and a != "-")
+    indels = len(s1_aln) - mismatches - matches
+    assert (matches, mismatches, indels) == (r["matches"], r["mismatches"], r["indels"])
+    stats = (s1_aln, s2_aln, (matches, mismatches, indels))
+    if x_acc == y_acc == "":
+        return (s1, s2, stats)
+    return (x_acc, y_acc, stats)
+
+
+def _swm_task(task):
+    args, kwargs = task
+    return parasail_alignment(*args, **kwargs)
+
+
+def mismatch_penalty_for(ed, len1, len2):
+    """SWM:102-109 error-rate buckets."""
+    error_rate = float(ed) / min(len1, len2)
+    if error_rate <= 0.01:
+        return -1
+    if 0.01 < error_rate <= 0.09:
+        return -2
+    return -4
+
+
+def sw_align_sequences(matches, nr_cores=1, mismatch_penalty=-1):
+    """SWM:89-164.  {s1: {s2: ed}} -> {s1: {s2: (s1_aln, s2_aln, (matches, mismatches, indels))}}."""
+    tasks = [((s1, s2, i, j), {"mismatch_penalty": mismatch_penalty_for(matches[s1][s2], len(s1), len(s2))})
+             for j, s1 in enumerate(matches) for i, s2 in enumerate(matches[s1])]
+    results = map(_swm_task, tasks) if nr_cores == 1 else _pool_map(_swm_task, tasks, nr_cores)
+    out = {}
+    for s1, s2, stats in results:
+        if stats:
+            out.setdefault(s1, {})[s2] = stats
+    return out
+
+
+def sw_align_sequences_keeping_accession(matches, nr_cores=1):
+    """SWM:167-249.  {acc1: {acc2: (s1, s2, ed)}} -> {acc1: {acc2: (s1_aln, s2_aln, counts)}}."""
+    tasks = []
+    for j, a1 in enumerate(matches):
+        for i, a2 in enumerate(matches[a1]):
+            s1, s2, ed = matches[a1][a2]
+            tasks.append(((s1, s2, i, j), {"x_acc": a1, "y_acc": a2,
+                                           "mismatch_penalty": mismatch_penalty_for(ed, len(s1), len(s2))}))
+    results = map(_swm_task, tasks) if nr_cores == 1 else _pool_map(_swm_task, tasks, nr_cores)
+    out = {}
+    for a1, a2, stats in results:
+        if stats:
+            out.setdefault(a1, {})[a2] = stats
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# NNG -- modules/nearest_neighbor_graph.py
+# ---------------------------------------------------------------------------------------------------
+
+LAST_CALLS = {"edlib_ed": 0}  # instrumentation: number of edlib_ed() calls of the last NN call
+
+
+def get_nearest_neighbors(batch_of_queries, global_index_in_matrix, start_index, seq_to_acc_list_sorted,
+                          has_converged, neighbor_search_depth):
+    """NNG:110-198 via the C loop."""
+    seqs = [s for s, _ in seq_to_acc_list_sorted]
+    conv = [1 if s in has_converged else 0 for s in seqs]
+    row_ptr, cols, eds, calls = nn_1set(seqs, conv, start_index, len(batch_of_queries), neighbor_search_depth)
+    LAST_CALLS["edlib_ed"] = calls
+    out = {}
+    for r in range(len(batch_of_queries)):
+        acc1 = seq_to_acc_list_sorted[start_index + r][1]
+        out[acc1] = {seq_to_acc_list_sorted[int(cols[e])][1]: int(eds[e]) for e in range(row_ptr[r], row_ptr[r + 1])}
+    return out
+
+
+def _nn1_task(task):
+    args, kwargs = task
+    res = get_nearest_neighbors(*args, **kwargs)
+    return res, LAST_CALLS["edlib_ed"]
+
+
+def get_exact_nearest_neighbor_graph(seq_to_acc_list_sorted, has_converged, params):
+    """NNG:19-82: serial call, or Pool fan-out with the reference's chunking and halo rules."""
+    n = len(seq_to_acc_list_sorted)
+    depth = params.neighbor_search_depth
+    if params.nr_cores == 1:
+        return get_nearest_neighbors(seq_to_acc_list_sorted, 0, 0, seq_to_acc_list_sorted, has_converged, depth)
+    chunk_size = max(int(n / (10 * params.nr_cores)), 20)
+    tasks = []
+    for i in range(0, n, chunk_size):
+        ref_start = max(0, i - depth - 1)
+        refs = seq_to_acc_list_sorted[ref_start:i + chunk_size + depth + 1]
+        chunk = seq_to_acc_list_sorted[i:i + chunk_size]
+        conv_chunk = set(seq for seq, _ in chunk if seq in has_converged)
+        tasks.append(((chunk, i, i - ref_start, refs, conv_chunk, depth), {}))
+    results = _pool_map(_nn1_task, tasks, params.nr_cores)
+    merged, calls = {}, 0
+    for sub, c in results:
+        for acc in sub:
+            assert acc not in merged
+        merged.update(sub)
+        calls += c
+    LAST_CALLS["edlib_ed"] = calls
+    return merged
+
+
+def compute_nearest_neighbor_graph(S, has_converged, params):
+    """NNG:237-296 -> (nearest_neighbor_graph, isolated)."""
+    seq_to_acc = {seq: acc for (acc, seq) in S.items()}
+    seq_to_acc_list_sorted = sorted(seq_to_acc.items(), key=lambda x: len(x[0]))
+    graph = get_exact_nearest_neighbor_graph(seq_to_acc_list_sorted, has_converged, params)
+    seen = set(S[acc1] for acc1 in graph)
+    isolated = set(seq_to_acc).difference(seen)
+    return graph, isolated
+
+
+def get_nearest_neighbors_2set(batch, start_index, seq_to_acc_list_sorted, target_accessions, neighbor_search_depth):
+    """NNG:341-424 via the C loop."""
+    seqs = [s for s, _ in seq_to_acc_list_sorted]
+    is_t = [1 if acc in target_accessions else 0 for _, acc in seq_to_acc_list_sorted]
+    row_ptr, cols, eds, calls = nn_2set(seqs, is_t, start_index, len(batch), neighbor_search_depth)
+    LAST_CALLS["edlib_ed"] = calls
+    out = {}
+    for r in range(len(batch)):
+        if is_t[start_index + r]:
+            continue
+        acc1 = seq_to_acc_list_sorted[start_index + r][1]
+        out[acc1] = {seq_to_acc_list_sorted[int(cols[e])][1]: int(eds[e]) for e in range(row_ptr[r], row_ptr[r + 1])}
+    return out
+
+
+def _nn2_task(task):
+    args, kwargs = task
+    res = get_nearest_neighbors_2set(*args, **kwargs)
+    return res, LAST_CALLS["edlib_ed"]
+
+
+def get_exact_nearest_neighbor_graph_2set(seq_to_acc_list_sorted_all, target_accessions, params):
+    """NNG:300-334."""
+    n = len(seq_to_acc_list_sorted_all)
+    depth = params.neighbor_search_depth
+    if params.nr_cores == 1:
+        return get_nearest_neighbors_2set(seq_to_acc_list_sorted_all, 0, seq_to_acc_list_sorted_all,
+                                          target_accessions, depth)
+    chunk_size = max(int(n / (10 * params.nr_cores)), 20)
+    tasks = [((seq_to_acc_list_sorted_all[i:i + chunk_size], i, seq_to_acc_list_sorted_all, target_accessions, depth), {})
+             for i in range(0, n, chunk_size)]
+    results = _pool_map(_nn2_task, tasks, params.nr_cores)
+    merged, calls = {}, 0
+    for sub, c in results:
+        for acc in sub:
+            assert acc not in merged
+        merged.update(sub)
+        calls += c
+    LAST_CALLS["edlib_ed"] = calls
+    return merged
+
+
+def compute_2set_nearest_neighbor_graph(X, C, params):
+    """NNG:201-234."""
+    queries = [(seq, acc) for (acc, seq) in X.items()]
+    targets = [(seq, acc) for (acc, seq) in C.items()]
+    merged = sorted(queries + targets, key=lambda x: len(x[0]))
+    return get_exact_nearest_neighbor_graph_2set(merged, set(C.keys()), params)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GBA -- modules/get_best_alignments.py
+# ---------------------------------------------------------------------------------------------------
+
+def find_best_matches(approximate_matches, params, edge_creating_min_treshold=-1, edge_creating_max_treshold=2 ** 30):
+    """GBA:5-119."""
+    exact = edlib_align_sequences(approximate_matches, nr_cores=params.nr_cores)
+    best = {}
+    for s1 in exact:
+        for s2, ed in exact[s1].items():
+            if ed < edge_creating_max_treshold:
+                best.setdefault(s1, {})[s2] = ed
+                best.setdefault(s2, {})[s1] = ed
+    for s1 in list(best.keys()):
+        lo = min(best[s1].values())
+        for s2 in list(best[s1].keys()):
+            if best[s1][s2] > lo and best[s1][s2] > edge_creating_min_treshold:
+                del best[s1][s2]
+    if not sum(len(v) for v in best.values()):
+        raise ZeroDivisionError("float division by zero")  # GBA:60
+    alns = sw_align_sequences(best, nr_cores=params.nr_cores)
+    out = {}
+    for s1 in alns:
+        for s2 in alns[s1]:
+            a1, a2, (m, mm, ind) = alns[s1][s2]
+            ed = mm + ind
+            if ed < edge_creating_max_treshold:
+                out.setdefault(s1, {})[s2] = (ed, a1, a2)
+                out.setdefault(s2, {})[s1] = (ed, a2, a1)
+    for s1 in list(out.keys()):
+        lo = min(v[0] for v in out[s1].values())
+        for s2 in list(out[s1].keys()):
+            if out[s1][s2][0] > lo and out[s1][s2][0] > edge_creating_min_treshold:
+                del out[s1][s2]
+    return out
+
+
+def find_best_matches_2set(highest_paf_scores, X, C, params):
+    """GBA:121-203."""
+    approx = {}
+    for read_acc, hits in highest_paf_scores.items():
+        approx[read_acc] = {}
+        for _score, t_acc in hits:
+            approx[read_acc][t_acc] = (X[read_acc], C[t_acc])
+    exact = edlib_align_sequences_keeping_accession(approx, nr_cores=params.nr_cores)
+    best = {a1: dict(exact[a1]) for a1 in exact}
+    for a1 in list(best.keys()):
+        lo = min(v[2] for v in best[a1].values())
+        for a2 in list(best[a1].keys()):
+            if best[a1][a2][2] > lo:
+                del best[a1][a2]
+    alns = sw_align_sequences_keeping_accession(best, nr_cores=params.nr_cores)
+    out = {}
+    for x_acc in alns:
+        for c_acc in alns[x_acc]:
+            xa, ca, (m, mm, ind) = alns[x_acc][c_acc]
+            ed = mm + ind
+            if x_acc in out:
+                cur = next(iter(out[x_acc].values()))[0]
+                if ed < cur:
+                    out[x_acc] = {c_acc: (ed, xa, ca)}
+                elif ed == cur:
+                    out[x_acc][c_acc] = (ed, xa, ca)
+            else:
+                out[x_acc] = {c_acc: (ed, xa, ca)}
+    return out

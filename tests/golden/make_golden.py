@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the BUILD container only).
+
+What is pinned and how:
+  * orchestration (dict shapes, key order, -1 handling, chunking, penalty buckets, filtering): the REFERENCE's own
+    Python modules are imported from /root/reference and executed; their outputs are stored as expected values.
+  * arithmetic: the reference delegates it to `edlib` / `parasail`, which are absent here (and from the reference
+    tree), so the three stand-ins in tests/golden/shims/ forward those calls to the CPU oracle
+    (oracle/isocon_oracle.c).  Edit distances are additionally pinned by the textbook DP (orc_ed_dp).
+    => distances: pinned by definition; CIGAR tie-breaks: "parity unpinned" (policy 0 = believed parasail).
+Nothing of the reference's source text is written to the fixtures: only inputs (synthetic sequences, and the
+sequences of the reference's public test FASTA test/data/simulated_pacbio_reads_n_200.fa) and outputs.
+
+Usage:  python tests/golden/make_golden.py        (writes tests/golden/*.json)
+"""
+import contextlib
+import io
+import json
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, "shims"))
+sys.path.insert(0, REF)
+
+import networkx  # noqa: E402
+
+if not hasattr(networkx.Graph, "node"):  # the reference targets networkx <= 2.3 (requirements.txt:3)
+    networkx.Graph.node = property(lambda g: g.nodes)
+
+from oracle import oracle as O  # noqa: E402
+from isocon_amd import synth  # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from modules import nearest_neighbor_graph as R_NNG  # noqa: E402
+    from modules import edlib_alignment_module as R_EAM  # noqa: E402
+    from modules import SW_alignment_module as R_SWM  # noqa: E402
+    from modules import get_best_alignments as R_GBA  # noqa: E402
+
+
+class Params(object):
+    def __init__(self, nr_cores=1, neighbor_search_depth=2 ** 32):
+        self.nr_cores = nr_cores
+        self.neighbor_search_depth = neighbor_search_depth
+        self.verbose = False
+        self.develop_logfile = None
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def dd_to_list(d):
+    """dict-of-dict -> [[k1, [[k2, v], ...]], ...] preserving insertion order."""
+    return [[k1, [[k2, v] for k2, v in inner.items()]] for k1, inner in d.items()]
+
+
+def read_fasta(path):
+    acc, seqs, out = None, [], {}
+    for line in open(path):
+        line = line.strip()
+        if line.startswith(">"):
+            if acc is not None:
+                out[acc] = "".join(seqs)
+            acc, seqs = line[1:].replace(" ", "_"), []
+        elif line:
+            seqs.append(line)
+    if acc is not None:
+        out[acc] = "".join(seqs)
+    return out
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, separators=(",", ":"))
+    print("wrote %s (%.1f kB)" % (name, os.path.getsize(path) / 1e3))
+
+
+def g1_edit_distances(rng):
+    cases = []
+
+    def add(q, t, ks):
+        d = O.ed_dp(q, t)
+        for k in ks(d):
+            if k < -1:
+                continue
+            cases.append([q, t, k, d if (k < 0 or d <= k) else -1])
+
+    rs = lambda n: "".join(rng.choice("ACGT") for _ in range(n))  # noqa: E731
+    std = lambda d: sorted(set([-1, 0, 1, d - 1, d, d + 1, 31, 62, 63, 64, 65, 127, 128, 2 * d + 3]))  # noqa: E731
+    add("A", "A", std); add("A", "C", std); add("A", "AC", std); add("ACGT", "ACGT", std)
+    add("AAAA", "CCCCCC", std); add("ACGTACGT", "TGCATGCA", std)
+    for n in (1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200):
+        a = rs(n)
+        add(a, a, std)
+        b = list(a); b[n // 2] = "A" if b[n // 2] != "A" else "C"
+        add(a, "".join(b), std)
+        add(a, a[: n // 2] + a[n // 2 + 1:], std)           # one deletion
+        add(a, a + rs(5), std)                               # length diff 5
+        add(a, rs(max(1, n - 3)), std)                       # unrelated
+    prof = dict(rate=0.04, ins=0.4, dele=0.3, sub=0.3)
+    import numpy as np
+    nrng = np.random.Generator(np.random.PCG64(11))
+    few = lambda d: sorted(set([-1, d - 1, d, 63, 64]))  # noqa: E731
+    for n in (150, 400, 900, 1500):
+        a = rs(n)
+        for _ in range(3):
+            b = synth.mutate(nrng, np.frombuffer(a.encode(), dtype=np.uint8), prof).tobytes().decode()
+            add(a, b, few)
+        # exon-style difference: 90-base block missing
+        add(a, a[: n // 3] + a[n // 3 + 90:], few)
+    return cases
+
+
+def nn_case(S, has_converged, nr_cores, depth):
+    p = Params(nr_cores, depth)
+    graph, isolated = quiet(R_NNG.compute_nearest_neighbor_graph, dict(S), set(has_converged), p)
+    return dict(S=list(S.items()), has_converged=sorted(has_converged), nr_cores=nr_cores,
+                depth=depth, graph=dd_to_list(graph), isolated=sorted(isolated))
+
+
+def nn2_case(X, C, nr_cores, depth):
+    p = Params(nr_cores, depth)
+    graph = quiet(R_NNG.compute_2set_nearest_neighbor_graph, dict(X), dict(C), p)
+    return dict(X=list(X.items()), C=list(C.items()), nr_cores=nr_cores, depth=depth, graph=dd_to_list(graph))
+
+
+def main():
+    rng = random.Random(12345)
+    O.build()
+
+    # ---- G1: (q, t, k) -> ed
+    dump("g1_edit_distance.json", dict(cases=g1_edit_distances(rng)))
+
+    # ---- G2: NN graphs through the reference's own NNG module
+    accs, seqs, isoforms = synth.make_reads(70, 110, 3, seed=101)
+    S = dict(zip(accs, seqs))
+    # duplicate a few sequences (the dedup dict keeps the first position but the LAST accession, NNG:243)
+    S["dup_a"] = seqs[3]; S["dup_b"] = seqs[10]; S["dup_c"] = seqs[3]
+    conv = {seqs[3], seqs[10], seqs[20]}
+    g2 = []
+    for nr_cores in (1, 3):
+        for hc in (set(), conv):
+            for depth in (2 ** 32, 3, 1):
+                g2.append(nn_case(S, hc, nr_cores, depth))
+    # one longer synthetic set with same-length unrelated isoforms and exon-sized differences
+    accs2, seqs2, _ = synth.make_reads(120, 400, 4, seed=202, profile=dict(rate=0.03, ins=0.5, dele=0.3, sub=0.2))
+    g2.append(nn_case(dict(zip(accs2, seqs2)), set(), 1, 2 ** 32))
+    g2.append(nn_case(dict(zip(accs2, seqs2)), set(seqs2[:15]), 3, 2 ** 32))
+    dump("g2_nn_graph_1set.json", dict(cases=g2))
+
+    # the reference's public test reads (config C1): NN graph, serial
+    fa = read_fasta(os.path.join(REF, "test", "data", "simulated_pacbio_reads_n_200.fa"))
+    g2b = nn_case(fa, set(), 1, 2 ** 32)
+    g2b["n_edlib_calls_serial"] = None
+    O.compute_nearest_neighbor_graph(fa, set(), Params(1))
+    g2b["n_edlib_calls_serial"] = O.LAST_CALLS["edlib_ed"]
+    dump("g2_nn_graph_n200.json", g2b)
+
+    # ---- G2c: 2-set graphs (reads vs candidates)
+    g2c = []
+    C = {"cand_%d" % i: iso for i, iso in enumerate(isoforms)}
+    C["cand_copy_of_read"] = seqs[5]          # ed == 0 is admitted in the 2-set variant (NNG:388)
+    X = dict(zip(accs, seqs))
+    for nr_cores in (1, 3):
+        for depth in (2 ** 32, 1, 2):
+            g2c.append(nn2_case(X, C, nr_cores, depth))
+    g2c.append(nn2_case(X, {"far": "ACGT" * 80}, 1, 2 ** 32))   # reads with no admissible candidate -> {}
+    dump("g2_nn_graph_2set.json", dict(cases=g2c))
+
+    # ---- G3: edlib_align_sequences*, dict- and set-valued inputs
+    centre_a, centre_b = seqs[0], seqs[1]
+    matches_dict = {centre_a: {s: 0 for s in seqs[2:9]}, centre_b: {s: 0 for s in seqs[9:14]}, seqs[14]: {}}
+    matches_set = {centre_a: set(seqs[2:9]), centre_b: set(seqs[9:14])}
+    g3 = dict(
+        dict_input=[[k, list(v)] for k, v in matches_dict.items()],
+        dict_expected={str(c): dd_to_list(quiet(R_EAM.edlib_align_sequences, matches_dict, nr_cores=c)) for c in (1, 2)},
+        set_input=[[k, sorted(v)] for k, v in matches_set.items()],
+        set_expected=dd_to_list(quiet(R_EAM.edlib_align_sequences, matches_set, nr_cores=1)),
+    )
+    acc_matches = {"c0": {accs[i]: (isoforms[0], seqs[i]) for i in range(6)},
+                   "c1": {accs[i]: (isoforms[1], seqs[i]) for i in range(6, 10)}}
+    g3["acc_input"] = [[a1, [[a2, list(v)] for a2, v in inner.items()]] for a1, inner in acc_matches.items()]
+    g3["acc_expected"] = {str(c): dd_to_list(quiet(R_EAM.edlib_align_sequences_keeping_accession, acc_matches, nr_cores=c))
+                          for c in (1, 2)}
+    dump("g3_edlib_align.json", g3)
+
+    # ---- G4/G5: sw_align_sequences* (policy 0), tie-free and tie-heavy, bucket edges
+    def sub(s, pos):
+        return s[:pos] + ("A" if s[pos] != "A" else "C") + s[pos + 1:]
+
+    base = "".join(rng.choice("ACGT") for _ in range(300))
+    tie_free = {base: {}}
+    for pos in (10, 150, 290):
+        t = sub(base, pos)
+        tie_free[base][t] = O.ed_dp(base, t)
+    t2 = sub(sub(base, 50), 200)
+    tie_free[base][t2] = O.ed_dp(base, t2)
+    homo = base[:100] + "AAAAAAA" + base[100:]
+    tie_heavy = {base: {}, homo: {homo[:150] + homo[190:]: 0,   # exon-sized gap + homopolymer
+                                  base[:100] + "AAA" + base[100:]: 0}}
+    for t in (base[:100] + "AAAAA" + base[100:],            # homopolymer length difference
+              base[7:], base[:-9], "GG" + base + "TT",       # end gaps on either side
+              base[:140] + base[141:200] + "C" + base[200:],  # indel pair
+              "".join(rng.choice("ACGT") for _ in range(280))):  # unrelated
+        tie_heavy[base][t] = 0
+    for s1 in tie_heavy:
+        for s2 in tie_heavy[s1]:
+            tie_heavy[s1][s2] = O.ed_dp(s1, s2)
+    # penalty buckets (SWM:103-109): ed/min(len) == 0.01 exactly, just above, 0.09 exactly, just above
+    b100 = base[:100]
+    b200 = base[:200]
+    buckets = {b200: {b200[:199] + "T": 2, b200[:198] + "TT": 3}, b100: {b100[:99] + "G": 9, b100[:98] + "GG": 10, b100[:97] + "GGG": 1}}
+    g4 = {}
+    for name, mt in (("tie_free", tie_free), ("tie_heavy", tie_heavy), ("buckets", buckets)):
+        exp = {str(c): dd_to_list(quiet(R_SWM.sw_align_sequences, mt, nr_cores=c)) for c in (1, 2)}
+        g4[name] = dict(input=dd_to_list(mt), expected=exp)
+    acc_in = {"c0": {accs[i]: (isoforms[0], seqs[i], O.ed_dp(isoforms[0], seqs[i])) for i in range(5)},
+              "c2": {accs[i]: (isoforms[2], seqs[i], O.ed_dp(isoforms[2], seqs[i])) for i in range(5, 8)}}
+    g4["keeping_accession"] = dict(
+        input=[[a1, [[a2, list(v)] for a2, v in inner.items()]] for a1, inner in acc_in.items()],
+        expected={str(c): dd_to_list(quiet(R_SWM.sw_align_sequences_keeping_accession, acc_in, nr_cores=c)) for c in (1, 2)})
+    # parasail_alignment with the other callers' scoring (end_invariant_functions.py:22, hypothesis_test_module.py:99)
+    pa = []
+    for (mm, op, ext) in ((-3, 3, 0), (-3, 3, 1), (-3, 2, 0)):
+        for s2 in list(tie_heavy[base])[:3]:
+            r = quiet(R_SWM.parasail_alignment, base, s2, 0, 0, mismatch_penalty=mm, opening_penalty=op, gap_ext=ext)
+            pa.append(dict(s1=base, s2=s2, mismatch_penalty=mm, opening_penalty=op, gap_ext=ext, expected=[r[0], r[1], list(r[2][:2]) + [list(r[2][2])]]))
+    g4["parasail_alignment"] = pa
+    g4["tie_policy"] = 0
+    dump("g4_sw_align.json", g4)
+
+    # ---- GBA: find_best_matches / find_best_matches_2set
+    approx = {seqs[0]: [seqs[1], seqs[2], seqs[3]], seqs[4]: [seqs[0], seqs[5]], seqs[6]: [seqs[7]]}
+    gba = dict(approx=[[k, v] for k, v in approx.items()],
+               expected=[[k1, [[k2, list(v)] for k2, v in inner.items()]]
+                         for k1, inner in quiet(R_GBA.find_best_matches, approx, Params(1)).items()])
+    paf = {accs[i]: [(0, "cand_0"), (0, "cand_1"), (0, "cand_2")] for i in range(6)}
+    Cg = {"cand_%d" % i: iso for i, iso in enumerate(isoforms)}
+    gba["paf"] = [[k, [list(x) for x in v]] for k, v in paf.items()]
+    gba["X"] = [[a, X[a]] for a in paf]
+    gba["C"] = list(Cg.items())
+    gba["expected_2set"] = [[k1, [[k2, list(v)] for k2, v in inner.items()]]
+                            for k1, inner in quiet(R_GBA.find_best_matches_2set, paf, X, Cg, Params(1)).items()]
+    dump("gba_best_matches.json", gba)
+
+
+if __name__ == "__main__":
+    main()
