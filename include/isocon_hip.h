@@ -1,0 +1,131 @@
+/*
+ * isocon_hip.h -- C ABI of libisocon_hip.so: the MI355X (gfx950) implementation of IsoCon's all-pairs alignment +
+ * nearest-neighbour-graph hot path.
+ *
+ * The reference (ksahlin/IsoCon v0.3.3) is pure Python and has NO FFI for this path: its arithmetic is reached
+ * through the Python bindings of two third-party libraries (edlib, parasail).  Each entry point below therefore
+ * cites the reference *call site(s)* it replaces (paths relative to the reference root); the Python modules in
+ * isocon_amd/ bind them with ctypes and re-create the reference's function signatures on top
+ * (see INTEGRATION.md).
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer; every function returns an
+ * isocon_status (0 = OK, negative = error) and never throws; all calls block until results are in host memory.
+ * Sequences are upper-case ACGT (the reference builds its parasail matrix on "ACGT",
+ * modules/SW_alignment_module.py:65); anything else is rejected with ISOCON_E_ALPHABET.
+ */
+#ifndef ISOCON_HIP_H
+#define ISOCON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ISOCON_OK = 0,
+    ISOCON_E_ARG = -1,        /* bad argument */
+    ISOCON_E_ALPHABET = -2,   /* non-ACGT symbol */
+    ISOCON_E_HIP = -3,        /* HIP runtime error (isocon_last_error() has the text) */
+    ISOCON_E_CAPACITY = -4,   /* caller buffer too small; required size written back */
+    ISOCON_E_NODEVICE = -5,   /* no usable GPU */
+    ISOCON_E_UNSUPPORTED = -6
+} isocon_status;
+
+typedef struct isocon_store isocon_store; /* opaque: packed sequence set resident in HBM */
+
+/* Select the HIP device for subsequent calls of this process (one process per GPU). */
+int isocon_init(int device_ordinal);
+const char *isocon_strerror(int status);
+const char *isocon_last_error(void);
+int isocon_device_count(void);
+
+/*
+ * Pack n sequences (ASCII, concatenated; sequence i = ascii[offsets[i] .. offsets[i+1])) into 2 bit-planes per
+ * base, chunk-major ([64-base chunk][sequence][lo,hi] -> coalesced 16-B loads across consecutive sequences) and
+ * upload them.  Replaces the per-task pickling of Python strings of the reference's Pool fan-out
+ * (modules/nearest_neighbor_graph.py:33-35,65; modules/edlib_alignment_module.py:32; modules/SW_alignment_module.py:144).
+ * For the nearest-neighbour entry points the sequences MUST be given in the reference's length-sorted order
+ * (modules/nearest_neighbor_graph.py:246 / :208).
+ */
+int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t n, isocon_store **out);
+void isocon_store_destroy(isocon_store *s);
+uint32_t isocon_store_size(const isocon_store *s);
+uint64_t isocon_store_device_bytes(const isocon_store *s);
+
+/*
+ * Batched global (NW) edit distance over an explicit pair list.
+ *   k[p] >= 0 : out[p] = distance if <= k[p], else -1      == edlib.align(x, y, mode="NW", task="distance", k=k)
+ *               (modules/nearest_neighbor_graph.py:104-107)
+ *   k[p] <  0 or k == NULL : unbounded distance            == edlib.align(x, y, "NW")
+ *               (modules/edlib_alignment_module.py:111)
+ * kernel_ms (optional) receives the summed HIP-event time of the kernels.
+ */
+int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const int32_t *k, uint64_t n_pairs,
+                    int32_t *out_ed, float *kernel_ms);
+
+/* statistics block filled by the nearest-neighbour entry points (all counters are for the one call) */
+typedef struct {
+    uint64_t pairs_evaluated;     /* (shared,lane) pairs the banded kernels actually ran */
+    uint64_t cells_columns;       /* text columns processed, summed over evaluated lanes */
+    uint64_t tiles;               /* 64-lane tiles executed */
+    uint64_t hits;                /* candidate edges recorded on the device */
+    uint64_t fallback_queries;    /* queries that needed a band wider than 64 rows */
+    uint64_t full_pairs;          /* pairs sent to the un-banded kernel */
+    float kernel_ms;              /* HIP-event time of all kernels of the call */
+    float scan_kernel_ms;         /* ... of the dominant (64-row band scan) kernel */
+    uint32_t scan_launches;
+    uint32_t reserved;
+} isocon_nn_stats;
+
+/*
+ * Exact nearest-neighbour graph over a length-sorted store.
+ *   1-set (is_target == NULL): for every i with is_converged[i] == 0 the arg-min set of POSITIVE edit distances
+ *     over all other sequences, restricted to d <= len(i) and to sorted-order offsets <= depth
+ *     == get_nearest_neighbors (modules/nearest_neighbor_graph.py:110-198) for every query, i.e. the whole of
+ *     get_exact_nearest_neighbor_graph (:19-82) independent of nr_cores.
+ *   2-set (is_target != NULL): queries are the entries with is_target[i] == 0, neighbours only entries with
+ *     is_target[i] == 1, distance 0 admitted == get_nearest_neighbors_2set (:341-424).
+ *     depth must be >= the number of targets (the reference's default 2**32 never binds).
+ * Output CSR: out_best[i] = minimal distance (-1 if row empty), out_row_ptr[n+1], out_cols = neighbour indices in
+ * the reference's insertion order (ascending offset, lower index first).  If the edges do not fit cols_cap the
+ * call returns ISOCON_E_CAPACITY and *n_cols_needed holds the required capacity.
+ */
+int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t *is_target, uint64_t depth,
+                    int32_t *out_best, uint64_t *out_row_ptr, uint32_t *out_cols, uint64_t cols_cap,
+                    uint64_t *n_cols_needed, isocon_nn_stats *stats);
+
+/*
+ * Sharded variant for one-process-per-GPU runs (the reference has no distributed path; its Pool chunking is
+ * modules/nearest_neighbor_graph.py:33-35).  best_inout[n] is IN/OUT (0x3fffffff = no neighbour known yet).
+ *   phase 0: 64-row band over every admissible pair whose LOWER index (1-set) / whose query (2-set) lies in
+ *            [q_begin, q_end).  Pass best_inout all 0x3fffffff.
+ *   phase 1: wide bands / un-banded kernel for the owned queries in [q_begin, q_end) that are still unresolved
+ *            in best_inout (which must be the element-wise MIN over all ranks' phase-0 results).
+ * Each call returns up to hits_cap candidate edges (endpoint, neighbour, distance) as int32 triples.  The caller
+ * min-reduces best over ranks after each phase, all-gathers the triples and calls isocon_nn_finalize.
+ */
+int isocon_nn_partial(isocon_store *s, const uint8_t *is_converged, const uint8_t *is_target, uint64_t depth,
+                      uint32_t q_begin, uint32_t q_end, int32_t phase, int32_t *best_inout, int32_t *out_hits,
+                      uint64_t hits_cap, uint64_t *n_hits, isocon_nn_stats *stats);
+int isocon_nn_finalize(uint32_t n, const int32_t *best, const int32_t *hits, uint64_t n_hits,
+                       int32_t *out_best, uint64_t *out_row_ptr, uint32_t *out_cols, uint64_t cols_cap,
+                       uint64_t *n_cols_needed);
+
+/*
+ * Batched semi-global affine alignment with traceback == parasail.sg_trace_scan_16/32(s1=a, s2=b, open, ext,
+ * matrix_create("ACGT", match, mismatch)) + the CIGAR decode and column counting of parasail_alignment
+ * (modules/SW_alignment_module.py:64-86).  mismatch is per pair (the reference picks it from the error-rate
+ * bucket, :102-109).  tie_policy 0 = parasail's behaviour as restated in oracle/isocon_oracle.c.
+ * Outputs: CIGAR ops as (len << 4 | code), code 0 '=', 1 'X', 2 'I' (consumes a), 3 'D' (consumes b);
+ * out_ops_ptr[n_pairs+1]; out_res[6*p..] = score, end_query, end_ref, matches, mismatches, indels.
+ */
+int isocon_sg_trace_batch(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t match,
+                          const int8_t *mismatch_per_pair, int32_t open, int32_t ext, int32_t tie_policy,
+                          uint32_t *out_ops, uint64_t *out_ops_ptr, uint64_t ops_cap, uint64_t *n_ops_needed,
+                          int32_t *out_res, float *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

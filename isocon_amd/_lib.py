@@ -1,0 +1,120 @@
+"""ctypes binding of libisocon_hip.so (C ABI: include/isocon_hip.h).
+
+The library is built in-tree by build() (hipcc --offload-arch=gfx950) and loaded from isocon_amd/lib/.  There is
+no CPU fallback: if the shared object is missing or no GPU is usable the product functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libisocon_hip.so")
+SRC_DIR = os.path.join(_HERE, "csrc")
+_SOURCES = ["isocon_hip.hip", "band_core.hpp", "common.hpp", "ed_band.hpp", "ed_full.hpp", "nn.hpp", "nn_host.inc",
+            "sg.hpp", "sg_host.inc"]
+
+ISOCON_OK = 0
+ISOCON_E_CAPACITY = -4
+NN_INF = 0x3FFFFFFF
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+i8p = ctypes.POINTER(ctypes.c_int8)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+i32p = ctypes.POINTER(ctypes.c_int32)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+f32p = ctypes.POINTER(ctypes.c_float)
+
+
+class NNStats(ctypes.Structure):
+    _fields_ = [("pairs_evaluated", ctypes.c_uint64), ("cells_columns", ctypes.c_uint64), ("tiles", ctypes.c_uint64),
+                ("hits", ctypes.c_uint64), ("fallback_queries", ctypes.c_uint64), ("full_pairs", ctypes.c_uint64),
+                ("kernel_ms", ctypes.c_float), ("scan_kernel_ms", ctypes.c_float), ("scan_launches", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# name -> (restype, argtypes): every symbol include/isocon_hip.h declares
+SYMBOLS = {
+    "isocon_init": (ctypes.c_int, [ctypes.c_int]),
+    "isocon_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "isocon_last_error": (ctypes.c_char_p, []),
+    "isocon_device_count": (ctypes.c_int, []),
+    "isocon_store_create": (ctypes.c_int, [u8p, u64p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
+    "isocon_store_destroy": (None, [ctypes.c_void_p]),
+    "isocon_store_size": (ctypes.c_uint32, [ctypes.c_void_p]),
+    "isocon_store_device_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
+    "isocon_ed_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, i32p, ctypes.c_uint64, i32p, f32p]),
+    "isocon_nn_graph": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, i32p, u64p, u32p, ctypes.c_uint64,
+                                       u64p, ctypes.POINTER(NNStats)]),
+    "isocon_nn_partial": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_int32, i32p, i32p, ctypes.c_uint64, u64p, ctypes.POINTER(NNStats)]),
+    "isocon_nn_finalize": (ctypes.c_int, [ctypes.c_uint32, i32p, i32p, ctypes.c_uint64, i32p, u64p, u32p,
+                                          ctypes.c_uint64, u64p]),
+    "isocon_sg_trace_batch": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, ctypes.c_int32, i8p,
+                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, u32p, u64p, ctypes.c_uint64,
+                                             u64p, i32p, f32p]),
+}
+
+_lib = None
+_initialised = False
+
+
+def needs_build() -> bool:
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    return any(os.path.getmtime(os.path.join(SRC_DIR, f)) > t for f in _SOURCES if os.path.exists(os.path.join(SRC_DIR, f)))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compile the HIP library for gfx950 (works without a GPU)."""
+    if not force and not needs_build():
+        return SO_PATH
+    os.makedirs(os.path.dirname(SO_PATH), exist_ok=True)
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-o", SO_PATH, os.path.join(SRC_DIR, "isocon_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=SRC_DIR)
+    return SO_PATH
+
+
+def load():
+    """Load the shared object and bind every symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError("libisocon_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                               "there is no CPU fallback" % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class IsoconError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != ISOCON_OK:
+        L = load()
+        raise IsoconError("%s failed: %s (%s)" % (what, L.isocon_strerror(rc).decode(), L.isocon_last_error().decode()))
+
+
+def lib():
+    """Library handle with the GPU selected (LOCAL_RANK / ISOCON_GPU_DEVICE / 0).  Raises without a GPU."""
+    global _initialised
+    L = load()
+    if not _initialised:
+        dev = int(os.environ.get("ISOCON_GPU_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        check(L.isocon_init(dev), "isocon_init(%d)" % dev)
+        _initialised = True
+    return L

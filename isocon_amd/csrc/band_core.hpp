@@ -1,0 +1,176 @@
+// band_core.hpp -- lane-level math of the banded bit-vector edit-distance kernel (gfx950).
+//
+// Replaces the arithmetic the reference delegates to edlib.align(q, t, mode="NW", task="distance", k=K)
+// (/root/reference/modules/nearest_neighbor_graph.py:104-107, modules/edlib_alignment_module.py:111).
+//
+// Algorithm (not edlib's block scheme): a 64*W-row window of Myers/Hyyro vertical-delta bit-vectors slides
+// down one row per text column (diagonal band).  One wavefront handles ONE shared sequence (the "pattern",
+// rows) against 64 lane sequences (the "texts", columns); the band origin a0 is wave-uniform so the pattern
+// window is a wave-uniform value (SGPRs, slid by the scalar unit) and only the text base differs per lane.
+//
+//   window at column j (1-based) covers rows a0+j .. a0+j+64W-1; row r <-> pattern base r-1.
+//   rows <= 0 are "virtual": D[i][j] = j - i there, which makes row 0 come out as D[0][j] = j without a
+//   special case (init: VP = rows >= 1, VN = rows <= 0; Eq masked to 0 on virtual rows).
+//   rows > m hold garbage that can never flow upwards.
+//   column step (vectors stored after column j are aligned to the window of column j+1):
+//       D0 = (((Eq & VP) + VP) ^ VP) | Eq | VN ;  HP = VN | ~(D0 | VP) ;  HN = D0 & VP
+//       VP' = HN | ~((D0 >> 1) | HP) ;            VN' = (D0 >> 1) & HP
+//   score: D at the window's top row follows a diagonal: top += 1 - D0[bit 0]; the value on the final diagonal
+//   (row j + m - n) is top + popcount(VP & low(b*)) - popcount(VN & low(b*)), b* = (m - n) - a0; it is
+//   non-decreasing in j and equals D[m][n] at j = n, so "value > k" is a safe early exit.
+//
+// The same header is compiled by g++ for the wave emulator in tests/emul (CPU unit tests of this math).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ISO_HD __host__ __device__ __forceinline__
+#else
+#define ISO_HD inline
+#endif
+
+namespace isocon {
+
+ISO_HD int popc64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+
+// Geometry of one lane inside a tile whose band origin is a0 (<= 0) and whose window has 64*W rows.
+struct LaneGeom {
+    int32_t k_eff;   // largest threshold this lane can certify with the tile's window (-1: none)
+    int32_t bstar;   // bit index of the final diagonal inside the window
+};
+
+// Ukkonen: a path of cost <= k from diagonal 0 to diagonal d = m - n stays on diagonals
+// [min(0,d) - x, max(0,d) + x], x = (k - |d|) / 2.
+ISO_HD int32_t lane_emin(int32_t d, int32_t k)
+{
+    const int32_t ad = d < 0 ? -d : d;
+    const int32_t x = (k - ad) / 2;
+    return (d < 0 ? d : 0) - x;
+}
+
+template <int W>
+ISO_HD LaneGeom lane_geom(int32_t d, int32_t k, int32_t a0)
+{
+    LaneGeom g;
+    const int32_t ad = d < 0 ? -d : d;
+    const int32_t top = a0 + 64 * W - 1;         // highest diagonal covered
+    const int32_t dpos = d > 0 ? d : 0, dneg = d < 0 ? d : 0;
+    g.bstar = d - a0;
+    if (k < ad || top < dpos || a0 > dneg) { g.k_eff = -1; return g; }
+    int32_t x = (k - ad) / 2;
+    int32_t xmax = top - dpos;
+    if (dneg - a0 < xmax) xmax = dneg - a0;
+    if (x <= xmax) { g.k_eff = k; return g; }
+    g.k_eff = ad + 2 * xmax + 1;                 // largest k with (k-|d|)/2 == xmax
+    return g;
+}
+
+// Per-lane DP state.
+template <int W>
+struct BandLane {
+    uint64_t VP[W], VN[W];
+    uint64_t LM[W];     // low(b*) mask
+    uint32_t ztop;      // number of D0 bit-0 hits so far (top = nv + columns - ztop)
+};
+
+template <int W>
+ISO_HD void band_init(BandLane<W> &L, int32_t nv /* = -a0 */, int32_t bstar)
+{
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const int32_t lo = nv - 64 * i;          // number of virtual bits in this word
+        const uint64_t vp = lo <= 0 ? ~(uint64_t)0 : (lo >= 64 ? 0 : (~(uint64_t)0 << lo));
+        L.VP[i] = vp;
+        L.VN[i] = ~vp;
+        const int32_t b = bstar - 64 * i;
+        L.LM[i] = b <= 0 ? 0 : (b >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << b) - 1));
+    }
+    L.ztop = 0;
+}
+
+// One text column.  NL/NH = ~pattern bit-planes of the current window (wave-uniform), VM = valid-row mask
+// (only read when MASKED), slo/shi = text base bit-planes splat to 32 bits (0 or 0xffffffff).
+template <int W, bool MASKED>
+ISO_HD void band_step(BandLane<W> &L, const uint64_t (&NL)[W], const uint64_t (&NH)[W], const uint64_t (&VM)[W],
+                      uint32_t slo, uint32_t shi)
+{
+    const uint64_t sl = ((uint64_t)slo << 32) | slo;
+    const uint64_t sh = ((uint64_t)shi << 32) | shi;
+    uint64_t D0[W], HP[W], HN[W];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        uint64_t eq = (NL[i] ^ sl) & (NH[i] ^ sh);
+        if (MASKED) eq &= VM[i];
+        const uint64_t vp = L.VP[i], vn = L.VN[i];
+        const uint64_t x = eq & vp;
+        uint64_t s = x + vp;
+        uint64_t c = s < x;
+        if (W > 1) { const uint64_t s2 = s + carry; c |= (s2 < s); s = s2; carry = c; }
+        D0[i] = (s ^ vp) | eq | vn;
+        HP[i] = vn | ~(D0[i] | vp);
+        HN[i] = D0[i] & vp;
+    }
+    L.ztop += (uint32_t)D0[0] & 1u;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint64_t d0s = (D0[i] >> 1) | ((i + 1 < W) ? (D0[(i + 1 < W) ? i + 1 : i] << 63) : 0);
+        L.VP[i] = HN[i] | ~(d0s | HP[i]);
+        L.VN[i] = d0s & HP[i];
+    }
+}
+
+// D on the final diagonal after `cols` columns.
+template <int W>
+ISO_HD int32_t band_diag_value(const BandLane<W> &L, int32_t nv, int32_t cols)
+{
+    int32_t v = nv + cols - (int32_t)L.ztop;
+#pragma unroll
+    for (int i = 0; i < W; ++i) v += popc64(L.VP[i] & L.LM[i]) - popc64(L.VN[i] & L.LM[i]);
+    return v;
+}
+
+// Slide the wave-uniform window one row down.  F* hold the next 64 stream bits (already complemented for NL/NH).
+template <int W>
+ISO_HD void window_slide(uint64_t (&NL)[W], uint64_t (&NH)[W], uint64_t (&VM)[W], uint64_t &FL, uint64_t &FH)
+{
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint64_t inl = (i + 1 < W) ? NL[(i + 1 < W) ? i + 1 : i] : FL;
+        const uint64_t inh = (i + 1 < W) ? NH[(i + 1 < W) ? i + 1 : i] : FH;
+        const uint64_t inv = (i + 1 < W) ? VM[(i + 1 < W) ? i + 1 : i] : ~(uint64_t)0;
+        NL[i] = (NL[i] >> 1) | (inl << 63);
+        NH[i] = (NH[i] >> 1) | (inh << 63);
+        VM[i] = (VM[i] >> 1) | (inv << 63);
+    }
+    FL >>= 1;
+    FH >>= 1;
+}
+
+// 64 bits of a sequence's bit-plane stream starting at bit `off` (may be negative: virtual rows read as 0).
+// chunk(ci) must return plane word ci of the shared sequence, 0 beyond the end.
+template <class ChunkFn>
+ISO_HD uint64_t stream64(ChunkFn chunk, int32_t off)
+{
+    if (off <= -64) return 0;
+    if (off < 0) return chunk(0) << (-off);
+    const int32_t ci = off >> 6, s = off & 63;
+    const uint64_t a = chunk(ci);
+    if (s == 0) return a;
+    return (a >> s) | (chunk(ci + 1) << (64 - s));
+}
+
+ISO_HD uint64_t valid_word(int32_t nv, int i)
+{
+    const int32_t lo = nv - 64 * i;
+    return lo <= 0 ? ~(uint64_t)0 : (lo >= 64 ? 0 : (~(uint64_t)0 << lo));
+}
+
+}  // namespace isocon

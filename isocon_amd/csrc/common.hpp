@@ -1,0 +1,60 @@
+// common.hpp -- device store layout, error plumbing and wave helpers shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/isocon_hip.h"
+
+namespace isocon {
+
+// Packed sequence set in HBM.
+//   planes[((chunk * n) + id) * 2 + p] : 64 bases of sequence `id`, bit-plane p (0 = low code bit, 1 = high);
+//   A=0 C=1 G=2 T=3; bases past the end are 0; there are nchunks = ceil(maxlen/64)+1 chunks (last all-zero).
+//   Consecutive ids are adjacent in memory, so a wave whose lanes hold consecutive sequences loads
+//   64 x 16 B = 1 KiB contiguous per chunk.
+struct DevStore {
+    const uint64_t *planes;
+    const int32_t *lens;
+    uint32_t n;
+    uint32_t nchunks;
+};
+
+extern thread_local std::string g_last_error;
+
+#define ISO_HIP_CHECK(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                  \
+            return ISOCON_E_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int32_t uniform_i32(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int32_t load_relaxed_agent(const int32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace isocon

@@ -1,0 +1,356 @@
+// isocon_hip.hip -- C ABI of libisocon_hip.so (see include/isocon_hip.h).  Host orchestration + kernel launches.
+// gfx950 only.  One process drives one GPU (isocon_init selects it).
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "ed_band.hpp"
+#include "ed_full.hpp"
+#include "nn.hpp"
+#include "sg.hpp"
+
+namespace isocon {
+thread_local std::string g_last_error;
+}
+
+using namespace isocon;
+
+struct isocon_store {
+    DevStore dev;
+    std::vector<int32_t> lens;   // host copy
+    uint64_t device_bytes = 0;
+    uint64_t *d_planes = nullptr;
+    int32_t *d_lens = nullptr;
+    int32_t maxlen = 0;
+};
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+    int alloc(size_t bytes)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        ISO_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+        return ISOCON_OK;
+    }
+};
+
+struct EventTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float total = 0.f;
+    bool ok = false;
+    EventTimer() { ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess; }
+    ~EventTimer() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    void start() { if (ok) (void)hipEventRecord(e0, 0); }
+    float stop()
+    {
+        float ms = 0.f;
+        if (ok) { (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); }
+        total += ms;
+        return ms;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *isocon_strerror(int status)
+{
+    switch (status) {
+    case ISOCON_OK: return "ok";
+    case ISOCON_E_ARG: return "bad argument";
+    case ISOCON_E_ALPHABET: return "sequence contains a symbol outside ACGT";
+    case ISOCON_E_HIP: return "HIP runtime error";
+    case ISOCON_E_CAPACITY: return "output buffer too small";
+    case ISOCON_E_NODEVICE: return "no usable GPU";
+    case ISOCON_E_UNSUPPORTED: return "unsupported request";
+    default: return "unknown status";
+    }
+}
+
+const char *isocon_last_error(void) { return g_last_error.c_str(); }
+
+int isocon_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int isocon_init(int device_ordinal)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_last_error = "hipGetDeviceCount: no device"; return ISOCON_E_NODEVICE; }
+    if (device_ordinal < 0 || device_ordinal >= n) return ISOCON_E_ARG;
+    ISO_HIP_CHECK(hipSetDevice(device_ordinal));
+    return ISOCON_OK;
+}
+
+int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t n, isocon_store **out)
+{
+    if (!out || (!ascii && n) || !offsets) return ISOCON_E_ARG;
+    *out = nullptr;
+    int32_t maxlen = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0x3fffffff) return ISOCON_E_ARG;
+        maxlen = std::max<int32_t>(maxlen, (int32_t)(offsets[i + 1] - offsets[i]));
+    }
+    const uint32_t nchunks = (uint32_t)((maxlen + 63) / 64 + 1);
+    std::vector<uint64_t> planes((size_t)nchunks * std::max<uint32_t>(n, 1) * 2, 0);
+    std::vector<int32_t> lens(std::max<uint32_t>(n, 1), 0);
+    static int8_t code[256];
+    static bool code_init = false;
+    if (!code_init) {
+        memset(code, -1, sizeof(code));
+        code['A'] = 0; code['C'] = 1; code['G'] = 2; code['T'] = 3;
+        code_init = true;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t *s = ascii + offsets[i];
+        const int32_t len = (int32_t)(offsets[i + 1] - offsets[i]);
+        lens[i] = len;
+        for (int32_t c0 = 0; c0 < len; c0 += 64) {
+            uint64_t lo = 0, hi = 0;
+            const int32_t e = std::min(len, c0 + 64);
+            for (int32_t p = c0; p < e; ++p) {
+                const int8_t cd = code[s[p]];
+                if (cd < 0) {
+                    g_last_error = "sequence " + std::to_string(i) + " position " + std::to_string(p) + ": symbol outside ACGT";
+                    return ISOCON_E_ALPHABET;
+                }
+                lo |= (uint64_t)(cd & 1) << (p - c0);
+                hi |= (uint64_t)(cd >> 1) << (p - c0);
+            }
+            const size_t at = ((size_t)(c0 >> 6) * n + i) * 2;
+            planes[at] = lo;
+            planes[at + 1] = hi;
+        }
+    }
+    isocon_store *st = new isocon_store();
+    st->lens = lens;
+    st->maxlen = maxlen;
+    const size_t pbytes = planes.size() * sizeof(uint64_t), lbytes = lens.size() * sizeof(int32_t);
+    if (hipMalloc((void **)&st->d_planes, pbytes) != hipSuccess || hipMalloc((void **)&st->d_lens, lbytes) != hipSuccess) {
+        g_last_error = "hipMalloc(store) failed";
+        isocon_store_destroy(st);
+        return ISOCON_E_HIP;
+    }
+    if (hipMemcpy(st->d_planes, planes.data(), pbytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(st->d_lens, lens.data(), lbytes, hipMemcpyHostToDevice) != hipSuccess) {
+        g_last_error = "hipMemcpy(store) failed";
+        isocon_store_destroy(st);
+        return ISOCON_E_HIP;
+    }
+    st->device_bytes = pbytes + lbytes;
+    st->dev.planes = st->d_planes;
+    st->dev.lens = st->d_lens;
+    st->dev.n = n;
+    st->dev.nchunks = nchunks;
+    st->lens.resize(n);
+    *out = st;
+    return ISOCON_OK;
+}
+
+void isocon_store_destroy(isocon_store *s)
+{
+    if (!s) return;
+    if (s->d_planes) (void)hipFree(s->d_planes);
+    if (s->d_lens) (void)hipFree(s->d_lens);
+    delete s;
+}
+
+uint32_t isocon_store_size(const isocon_store *s) { return s ? s->dev.n : 0; }
+uint64_t isocon_store_device_bytes(const isocon_store *s) { return s ? s->device_bytes : 0; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// explicit pair lists
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int W>
+int launch_band_tiles(const DevStore &S, const std::vector<uint32_t> &tile_shared, const std::vector<uint32_t> &lane_ids,
+                      const std::vector<int32_t> &lane_k, std::vector<int32_t> &out, EventTimer &tm)
+{
+    const size_t nt = tile_shared.size();
+    out.assign(nt * 64, -1);
+    if (!nt) return ISOCON_OK;
+    DevBuf d_ts, d_ids, d_k, d_out;
+    int rc;
+    if ((rc = d_ts.alloc(nt * 4)) || (rc = d_ids.alloc(nt * 64 * 4)) || (rc = d_k.alloc(nt * 64 * 4)) || (rc = d_out.alloc(nt * 64 * 4))) return rc;
+    ISO_HIP_CHECK(hipMemcpy(d_ts.p, tile_shared.data(), nt * 4, hipMemcpyHostToDevice));
+    ISO_HIP_CHECK(hipMemcpy(d_ids.p, lane_ids.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+    ISO_HIP_CHECK(hipMemcpy(d_k.p, lane_k.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+    tm.start();
+    hipLaunchKernelGGL(k_ed_band_tiles<W>, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, 0, S, d_ts.as<uint32_t>(),
+                       d_ids.as<uint32_t>(), d_k.as<int32_t>(), d_out.as<int32_t>(), (uint32_t)nt);
+    ISO_HIP_CHECK(hipGetLastError());
+    tm.stop();
+    ISO_HIP_CHECK(hipMemcpy(out.data(), d_out.p, nt * 64 * 4, hipMemcpyDeviceToHost));
+    return ISOCON_OK;
+}
+
+int run_band_stage(int W, const DevStore &S, const std::vector<uint32_t> &ts, const std::vector<uint32_t> &ids,
+                   const std::vector<int32_t> &ks, std::vector<int32_t> &out, EventTimer &tm)
+{
+    switch (W) {
+    case 1: return launch_band_tiles<1>(S, ts, ids, ks, out, tm);
+    case 2: return launch_band_tiles<2>(S, ts, ids, ks, out, tm);
+    case 4: return launch_band_tiles<4>(S, ts, ids, ks, out, tm);
+    case 8: return launch_band_tiles<8>(S, ts, ids, ks, out, tm);
+    default: return ISOCON_E_ARG;
+    }
+}
+
+int run_full(const isocon_store *st, const std::vector<uint32_t> &a, const std::vector<uint32_t> &b,
+             const std::vector<int32_t> &k, std::vector<int32_t> &out, EventTimer &tm)
+{
+    const size_t np = a.size();
+    out.assign(np, -1);
+    if (!np) return ISOCON_OK;
+    DevBuf d_a, d_b, d_k, d_out;
+    int rc;
+    if ((rc = d_a.alloc(np * 4)) || (rc = d_b.alloc(np * 4)) || (rc = d_k.alloc(np * 4)) || (rc = d_out.alloc(np * 4))) return rc;
+    ISO_HIP_CHECK(hipMemcpy(d_a.p, a.data(), np * 4, hipMemcpyHostToDevice));
+    ISO_HIP_CHECK(hipMemcpy(d_b.p, b.data(), np * 4, hipMemcpyHostToDevice));
+    ISO_HIP_CHECK(hipMemcpy(d_k.p, k.data(), np * 4, hipMemcpyHostToDevice));
+    bool multipass = false;
+    int32_t maxtext = 0;
+    for (size_t p = 0; p < np; ++p) {
+        const int32_t la = st->lens[a[p]], lb = st->lens[b[p]];
+        if (std::min(la, lb) > 4096) multipass = true;
+        maxtext = std::max(maxtext, std::max(la, lb));
+    }
+    const size_t lds = multipass ? (size_t)((maxtext + 15) & ~15) : 0;
+    if (lds > 160 * 1024) { g_last_error = "sequence longer than 163840 bases in the un-banded kernel"; return ISOCON_E_UNSUPPORTED; }
+    if (lds > 64 * 1024)
+        ISO_HIP_CHECK(hipFuncSetAttribute((const void *)k_ed_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    tm.start();
+    hipLaunchKernelGGL(k_ed_full, dim3((unsigned)np), dim3(64), lds, 0, st->dev, d_a.as<uint32_t>(), d_b.as<uint32_t>(),
+                       d_k.as<int32_t>(), d_out.as<int32_t>(), (uint32_t)np);
+    ISO_HIP_CHECK(hipGetLastError());
+    tm.stop();
+    ISO_HIP_CHECK(hipMemcpy(out.data(), d_out.p, np * 4, hipMemcpyDeviceToHost));
+    return ISOCON_OK;
+}
+
+}  // namespace
+
+namespace isocon {
+
+// Shared by isocon_ed_pairs and the NN fallback: exact bounded/unbounded distances for an explicit pair list.
+// Stages: 64-row band (k <= 63), 128, 256, 512 rows, then the un-banded kernel.
+int ed_pairs_impl(const isocon_store *st, const uint32_t *a, const uint32_t *b, const int32_t *k, uint64_t n_pairs,
+                  int32_t *out_ed, float *kernel_ms, uint64_t *full_pairs)
+{
+    EventTimer tm;
+    const uint32_t n = st->dev.n;
+    for (uint64_t p = 0; p < n_pairs; ++p)
+        if (a[p] >= n || b[p] >= n) return ISOCON_E_ARG;
+    // which side is shared more often?  (edit distance is symmetric)
+    bool swap_roles = false;
+    {
+        std::vector<uint8_t> seen_a(n, 0), seen_b(n, 0);
+        size_t da = 0, db = 0;
+        for (uint64_t p = 0; p < n_pairs; ++p) {
+            if (!seen_a[a[p]]) { seen_a[a[p]] = 1; ++da; }
+            if (!seen_b[b[p]]) { seen_b[b[p]] = 1; ++db; }
+        }
+        swap_roles = db < da;
+    }
+    std::vector<uint64_t> pending(n_pairs);
+    std::iota(pending.begin(), pending.end(), 0);
+    static const int stages[4] = {1, 2, 4, 8};
+    for (int si = 0; si < 4 && !pending.empty(); ++si) {
+        const int W = stages[si];
+        const int32_t kcap = 64 * W - 1;
+        auto sh = [&](uint64_t p) { return swap_roles ? b[p] : a[p]; };
+        auto ln = [&](uint64_t p) { return swap_roles ? a[p] : b[p]; };
+        std::sort(pending.begin(), pending.end(), [&](uint64_t x, uint64_t y) {
+            if (sh(x) != sh(y)) return sh(x) < sh(y);
+            const int32_t lx = st->lens[ln(x)], ly = st->lens[ln(y)];
+            if (lx != ly) return lx < ly;
+            return x < y;
+        });
+        std::vector<uint64_t> todo = pending, next;
+        for (int round = 0; round < 2 && !todo.empty(); ++round) {
+            // round 0: tiles of up to 64 lanes per shared sequence; round 1: one lane per tile for pairs whose
+            // tile could not certify the threshold (heterogeneous length differences)
+            std::vector<uint32_t> ts, ids;
+            std::vector<int32_t> ks;
+            std::vector<uint64_t> slot_pair;
+            size_t i = 0;
+            while (i < todo.size()) {
+                size_t j = i;
+                const uint32_t s0 = sh(todo[i]);
+                const size_t lim = round == 0 ? 64 : 1;
+                while (j < todo.size() && j - i < lim && sh(todo[j]) == s0) ++j;
+                ts.push_back(s0);
+                for (size_t l = 0; l < 64; ++l) {
+                    if (i + l < j) {
+                        const uint64_t p = todo[i + l];
+                        ids.push_back(ln(p));
+                        const int32_t kr = k ? k[p] : -1;
+                        ks.push_back(kr < 0 ? kcap : std::min(kr, kcap));
+                        slot_pair.push_back(p);
+                    } else {
+                        ids.push_back(0xffffffffu);
+                        ks.push_back(-1);
+                        slot_pair.push_back(~(uint64_t)0);
+                    }
+                }
+                i = j;
+            }
+            std::vector<int32_t> res;
+            int rc = run_band_stage(W, st->dev, ts, ids, ks, res, tm);
+            if (rc) return rc;
+            std::vector<uint64_t> retry;
+            for (size_t sidx = 0; sidx < slot_pair.size(); ++sidx) {
+                const uint64_t p = slot_pair[sidx];
+                if (p == ~(uint64_t)0) continue;
+                const int32_t r = res[sidx];
+                const int32_t kr = k ? k[p] : -1;
+                if (r >= 0) out_ed[p] = r;
+                else if (r == -2) retry.push_back(p);
+                else if (kr >= 0 && kr <= kcap) out_ed[p] = -1;
+                else next.push_back(p);
+            }
+            todo.swap(retry);
+        }
+        if (!todo.empty()) { g_last_error = "internal: single-lane tile undetermined"; return ISOCON_E_HIP; }
+        pending.swap(next);
+    }
+    if (full_pairs) *full_pairs = pending.size();
+    if (!pending.empty()) {
+        std::vector<uint32_t> fa, fb;
+        std::vector<int32_t> fk, res;
+        for (uint64_t p : pending) { fa.push_back(a[p]); fb.push_back(b[p]); fk.push_back(k ? k[p] : -1); }
+        int rc = run_full(st, fa, fb, fk, res, tm);
+        if (rc) return rc;
+        for (size_t i = 0; i < pending.size(); ++i) out_ed[pending[i]] = res[i];
+    }
+    if (kernel_ms) *kernel_ms = tm.total;
+    return ISOCON_OK;
+}
+
+}  // namespace isocon
+
+extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const int32_t *k, uint64_t n_pairs,
+                               int32_t *out_ed, float *kernel_ms)
+{
+    if (!s || (n_pairs && (!a || !b || !out_ed))) return ISOCON_E_ARG;
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (!n_pairs) return ISOCON_OK;
+    return ed_pairs_impl(s, a, b, k, n_pairs, out_ed, kernel_ms, nullptr);
+}
+
+#include "nn_host.inc"
+#include "sg_host.inc"

@@ -1,0 +1,82 @@
+"""GPU drop-in for /root/reference/modules/edlib_alignment_module.py (same names, arguments, return shapes).
+
+All distances come from isocon_ed_pairs (include/isocon_hip.h); `nr_cores` is accepted and ignored (the reference
+forks a Pool per call, EAM:28-41 -- here one batched launch replaces it).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .store import SeqStore
+
+
+def _intern(pairs):
+    """[(x, y), ...] -> (unique sequence list, a ids, b ids)."""
+    index, seqs = {}, []
+    a = np.empty(len(pairs), dtype=np.uint32)
+    b = np.empty(len(pairs), dtype=np.uint32)
+    for p, (x, y) in enumerate(pairs):
+        ia = index.get(x)
+        if ia is None:
+            ia = index[x] = len(seqs)
+            seqs.append(x)
+        ib = index.get(y)
+        if ib is None:
+            ib = index[y] = len(seqs)
+            seqs.append(y)
+        a[p], b[p] = ia, ib
+    return seqs, a, b
+
+
+def _distances(pairs):
+    if not pairs:
+        return np.zeros(0, dtype=np.int32)
+    seqs, a, b = _intern(pairs)
+    st = SeqStore(seqs)
+    try:
+        ed = st.ed_pairs(a, b, None)
+    finally:
+        st.close()
+    assert (ed >= 0).all()  # EAM:113
+    return ed
+
+
+def edlib_align_sequences(matches, nr_cores=1):
+    """EAM:10-49.  {s1: iterable(s2)} -> {s1: {s2: ed}} keyed by the sequences; keys without members are absent."""
+    pairs = [(s1, s2) for s1 in matches for s2 in matches[s1]]
+    ed = _distances(pairs)
+    exact_edit_distances = {}
+    for (s1, s2), d in zip(pairs, ed):
+        exact_edit_distances.setdefault(s1, {})[s2] = int(d)
+    return exact_edit_distances
+
+
+def edlib_align_sequences_keeping_accession(matches, nr_cores=1):
+    """EAM:51-99.  {acc1: {acc2: (s1, s2)}} -> {acc1: {acc2: (s1, s2, ed)}}."""
+    keys = [(a1, a2) for a1 in matches for a2 in matches[a1]]
+    pairs = [(matches[a1][a2][0], matches[a1][a2][1]) for a1, a2 in keys]
+    ed = _distances(pairs)
+    exact_matches = {}
+    for (a1, a2), (s1, s2), d in zip(keys, pairs, ed):
+        exact_matches.setdefault(a1, {})[a2] = (s1, s2, int(d))
+    return exact_matches
+
+
+def edlib_alignment(x, y, i, j, x_acc="", y_acc=""):
+    """EAM:107-128 (single pair)."""
+    ed = int(_distances([(x, y)])[0])
+    if x_acc == y_acc == "":
+        return (x, y, ed)
+    return (x_acc, y_acc, (x, y, ed))
+
+
+def edlib_alignment_helper(arguments):
+    """EAM:103-105."""
+    args, kwargs = arguments
+    return edlib_alignment(*args, **kwargs)
+
+
+def edlib_traceback(x, y, mode="NW", task="path", k=1):
+    """EAM:130-135.  Its only caller is dead code in the reference v0.3.3; edlib's CIGAR
+    tie-breaking is unpinned, so no GPU path is offered."""
+    raise NotImplementedError("edlib_traceback (edlib task='path') has no GPU implementation; dead code in IsoCon v0.3.3")

@@ -1,0 +1,171 @@
+"""GPU drop-in for /root/reference/modules/nearest_neighbor_graph.py (NNG).
+
+compute_nearest_neighbor_graph / compute_2set_nearest_neighbor_graph keep the reference's signatures and return the
+same dict-of-dict with the same key order.  The adaptive loops NNG:110-198 / :341-424 are
+replaced by isocon_nn_graph (include/isocon_hip.h); `params.nr_cores` is ignored (the result of the reference is
+independent of it).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .store import SeqStore
+
+LAST_STATS = {}  # statistics block of the most recent device call (bench / tests)
+
+
+def _rows_to_dict(accs, is_query, best, row_ptr, cols):
+    out = {}
+    cols = cols.tolist()
+    row_ptr = row_ptr.tolist()
+    best = best.tolist()
+    for i, acc in enumerate(accs):
+        if not is_query[i]:
+            continue
+        d = best[i]
+        out[acc] = {accs[c]: d for c in cols[row_ptr[i]:row_ptr[i + 1]]}
+    return out
+
+
+def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
+    seqs = [s for s, _ in seq_to_acc_list_sorted]
+    accs = [a for _, a in seq_to_acc_list_sorted]
+    conv = np.fromiter((1 if s in has_converged else 0 for s in seqs), dtype=np.uint8, count=len(seqs))
+    st = SeqStore(seqs)
+    try:
+        best, row_ptr, cols, stats = st.nn_graph(is_converged=conv, depth=depth)
+    finally:
+        st.close()
+    LAST_STATS.clear()
+    LAST_STATS.update(stats)
+    # every entry gets a key; converged ones an empty dict (NNG:120-123)
+    return _rows_to_dict(accs, np.ones(len(accs), dtype=bool), best, row_ptr, cols)
+
+
+def get_nearest_neighbors(batch_of_queries, global_index_in_matrix, start_index, seq_to_acc_list_sorted, has_converged,
+                          neighbor_search_depth):
+    """NNG:110-198.  The rows of the queries [start_index, start_index+len(batch)) of the exact graph."""
+    full = _nn_1set(seq_to_acc_list_sorted, has_converged, neighbor_search_depth)
+    keep = [seq_to_acc_list_sorted[i][1] for i in range(start_index, start_index + len(batch_of_queries))]
+    return {acc: full[acc] for acc in keep}
+
+
+def get_nearest_neighbors_helper(arguments):
+    args, kwargs = arguments
+    return get_nearest_neighbors(*args, **kwargs)
+
+
+def get_exact_nearest_neighbor_graph(seq_to_acc_list_sorted, has_converged, params):
+    """NNG:19-82 (serial and Pool branches give the same dict; one device call here)."""
+    return _nn_1set(seq_to_acc_list_sorted, has_converged, params.neighbor_search_depth)
+
+
+def compute_nearest_neighbor_graph(S, has_converged, params):
+    """NNG:237-296 -> (nearest_neighbor_graph, isolated)."""
+    seq_to_acc = {seq: acc for (acc, seq) in S.items()}
+    seq_to_acc_list_sorted = sorted(seq_to_acc.items(), key=lambda x: len(x[0]))
+    nearest_neighbor_graph = get_exact_nearest_neighbor_graph(seq_to_acc_list_sorted, has_converged, params)
+    seen = set(S[acc1] for acc1 in nearest_neighbor_graph)
+    isolated = set(seq_to_acc).difference(seen)
+    return nearest_neighbor_graph, isolated
+
+
+def _replay_2set_depth(seqs, accs, is_t, depth, st):
+    """neighbor_search_depth smaller than the number of candidates (never the case with the reference's default
+    2**32): NNG:416 stops after `depth` candidate alignments, an order-dependent rule.  Distances to the candidates
+    come from the GPU (bounded by len(read), NNG:356); the stop/depth bookkeeping of NNG:362-419 is replayed here."""
+    n = len(seqs)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
+    t_idx = np.nonzero(is_t)[0]
+    q_idx = np.nonzero(~is_t)[0]
+    a = np.repeat(q_idx, len(t_idx)).astype(np.uint32)
+    b = np.tile(t_idx, len(q_idx)).astype(np.uint32)
+    k = lens[a].astype(np.int32)
+    ed = st.ed_pairs(a, b, k).reshape(len(q_idx), len(t_idx)) if len(a) else np.zeros((len(q_idx), 0), np.int32)
+    col_of = {int(t): c for c, t in enumerate(t_idx)}
+    out = {}
+    for r, i in enumerate(q_idx.tolist()):
+        best_ed = int(lens[i])
+        cur = {}
+        stop_up = stop_down = False
+        processed = 0
+        j = 1
+        while True:
+            if i - j < 0:
+                stop_down = True
+            if i + j >= n:
+                stop_up = True
+            if not stop_down and abs(lens[i] - lens[i - j]) > best_ed:
+                stop_down = True
+            if not stop_up and abs(lens[i] - lens[i + j]) > best_ed:
+                stop_up = True
+            for side_stopped, p in ((stop_down, i - j), (stop_up, i + j)):
+                if side_stopped or not is_t[p]:
+                    continue
+                processed += 1
+                d = int(ed[r, col_of[p]])
+                d = d if 0 <= d <= best_ed else -1
+                if 0 <= d < best_ed:
+                    best_ed = d
+                    cur = {accs[p]: d}
+                elif d == best_ed:
+                    cur[accs[p]] = d
+            if stop_down and stop_up:
+                break
+            if processed >= depth:
+                break
+            j += 1
+        out[accs[i]] = cur
+    return out
+
+
+def _nn_2set(seq_to_acc_list_sorted_all, target_accessions, depth):
+    seqs = [s for s, _ in seq_to_acc_list_sorted_all]
+    accs = [a for _, a in seq_to_acc_list_sorted_all]
+    is_t = np.fromiter((acc in target_accessions for acc in accs), dtype=bool, count=len(accs))
+    st = SeqStore(seqs)
+    try:
+        if depth < int(is_t.sum()):
+            return _replay_2set_depth(seqs, accs, is_t, depth, st)
+        best, row_ptr, cols, stats = st.nn_graph(is_target=is_t.astype(np.uint8), depth=depth)
+    finally:
+        st.close()
+    LAST_STATS.clear()
+    LAST_STATS.update(stats)
+    return _rows_to_dict(accs, ~is_t, best, row_ptr, cols)
+
+
+def get_nearest_neighbors_2set(batch, start_index, seq_to_acc_list_sorted, target_accessions, neighbor_search_depth):
+    """NNG:341-424 for the entries [start_index, start_index+len(batch))."""
+    full = _nn_2set(seq_to_acc_list_sorted, target_accessions, neighbor_search_depth)
+    keep = [seq_to_acc_list_sorted[i][1] for i in range(start_index, start_index + len(batch))]
+    return {acc: full[acc] for acc in keep if acc in full}
+
+
+def get_nearest_neighbors_2set_helper(arguments):
+    args, kwargs = arguments
+    return get_nearest_neighbors_2set(*args, **kwargs)
+
+
+def get_exact_nearest_neighbor_graph_2set(seq_to_acc_list_sorted_all, target_accessions, params):
+    """NNG:300-334."""
+    return _nn_2set(seq_to_acc_list_sorted_all, target_accessions, params.neighbor_search_depth)
+
+
+def compute_2set_nearest_neighbor_graph(X, C, params):
+    """NNG:201-234: reads X against candidates C -> {read_acc: {cand_acc: ed}}."""
+    seq_to_acc_queries = [(seq, acc) for (acc, seq) in X.items()]
+    seq_to_acc_targets = [(seq, acc) for (acc, seq) in C.items()]
+    seq_to_acc_list_sorted_all = sorted(seq_to_acc_queries + seq_to_acc_targets, key=lambda x: len(x[0]))
+    return get_exact_nearest_neighbor_graph_2set(seq_to_acc_list_sorted_all, set(C.keys()), params)
+
+
+def edlib_ed(x, y, mode="NW", task="distance", k=1):
+    """NNG:104-107 (single pair)."""
+    if mode != "NW" or task != "distance":
+        raise NotImplementedError("only the hot path's mode='NW', task='distance' is implemented")
+    st = SeqStore([x, y])
+    try:
+        return int(st.ed_pairs([0], [1], [k])[0])
+    finally:
+        st.close()

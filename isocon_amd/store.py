@@ -1,0 +1,168 @@
+"""Packed sequence set resident in HBM (isocon_store of include/isocon_hip.h)."""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class SeqStore(object):
+    """Uploads a list of ACGT strings once; ids are positions in that list."""
+
+    def __init__(self, seqs):
+        L = _lib.lib()
+        self.n = len(seqs)
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.uint64, count=self.n)
+        self.lens = lens.astype(np.int64)
+        off = np.zeros(self.n + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        buf = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8) if self.n else np.zeros(1, np.uint8)
+        if buf.size == 0:
+            buf = np.zeros(1, np.uint8)
+        h = ctypes.c_void_p()
+        _lib.check(L.isocon_store_create(_ptr(buf, _lib.u8p), _ptr(off, _lib.u64p), self.n, ctypes.byref(h)),
+                   "isocon_store_create")
+        self._h = h
+        self._L = L
+
+    @property
+    def handle(self):
+        return self._h
+
+    def device_bytes(self) -> int:
+        return int(self._L.isocon_store_device_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.isocon_store_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- batched edit distance over explicit pairs ------------------------------------------------------------
+    def ed_pairs(self, a, b, k=None, return_ms=False):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        if len(a) != len(b):
+            raise ValueError("pair arrays differ in length")
+        kk = None if k is None else np.ascontiguousarray(k, dtype=np.int32)
+        out = np.full(len(a), -1, dtype=np.int32)
+        ms = ctypes.c_float(0)
+        _lib.check(self._L.isocon_ed_pairs(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), _ptr(kk, _lib.i32p), len(a),
+                                           _ptr(out, _lib.i32p), ctypes.byref(ms)), "isocon_ed_pairs")
+        return (out, ms.value) if return_ms else out
+
+    # ---- nearest-neighbour graph (store must be length-sorted) ------------------------------------------------
+    def nn_graph(self, is_converged=None, is_target=None, depth=2 ** 32):
+        """Returns (best[n], row_ptr[n+1], cols, stats dict)."""
+        n = self.n
+        conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
+        targ = None if is_target is None else np.ascontiguousarray(is_target, dtype=np.uint8)
+        best = np.empty(max(n, 1), dtype=np.int32)
+        row_ptr = np.zeros(n + 1, dtype=np.uint64)
+        cap = max(4 * n, 1024)
+        needed = ctypes.c_uint64(0)
+        stats = _lib.NNStats()
+        depth = int(min(depth, 2 ** 63 - 1))
+        while True:
+            cols = np.empty(cap, dtype=np.uint32)
+            rc = self._L.isocon_nn_graph(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), depth, _ptr(best, _lib.i32p),
+                                         _ptr(row_ptr, _lib.u64p), _ptr(cols, _lib.u32p), cap, ctypes.byref(needed),
+                                         ctypes.byref(stats))
+            if rc == _lib.ISOCON_E_CAPACITY:
+                cap = int(needed.value) + 16
+                continue
+            _lib.check(rc, "isocon_nn_graph")
+            return best[:n], row_ptr.astype(np.int64), cols[:int(row_ptr[n])], stats.as_dict()
+
+    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32):
+        """One shard / one phase (see include/isocon_hip.h).  `best` is updated in place; returns (hits[k,3], stats)."""
+        conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
+        targ = None if is_target is None else np.ascontiguousarray(is_target, dtype=np.uint8)
+        assert best.dtype == np.int32 and best.flags.c_contiguous and len(best) >= self.n
+        cap = max(16 * self.n, 1 << 16)
+        n_hits = ctypes.c_uint64(0)
+        stats = _lib.NNStats()
+        depth = int(min(depth, 2 ** 63 - 1))
+        best0 = best.copy()
+        while True:
+            hits = np.empty((cap, 3), dtype=np.int32)
+            rc = self._L.isocon_nn_partial(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), depth, q_begin, q_end, phase,
+                                           _ptr(best, _lib.i32p), _ptr(hits, _lib.i32p), cap, ctypes.byref(n_hits),
+                                           ctypes.byref(stats))
+            if rc == _lib.ISOCON_E_CAPACITY:
+                cap = int(n_hits.value) + 16
+                best[:] = best0
+                continue
+            _lib.check(rc, "isocon_nn_partial")
+            return hits[:int(n_hits.value)], stats.as_dict()
+
+    # ---- semi-global affine alignment with traceback ----------------------------------------------------------
+    def sg_trace(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ms=False):
+        """Returns (ops uint32[], ops_ptr int64[n+1], res int32[n,6]) -- see include/isocon_hip.h."""
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        n = len(a)
+        mm = np.ascontiguousarray(np.broadcast_to(np.asarray(mismatch, dtype=np.int8), (n,)))
+        res = np.zeros((max(n, 1), 6), dtype=np.int32)
+        ops_ptr = np.zeros(n + 1, dtype=np.uint64)
+        cap = max(64 * n, 1024)
+        needed = ctypes.c_uint64(0)
+        ms = ctypes.c_float(0)
+        while True:
+            ops = np.empty(cap, dtype=np.uint32)
+            rc = self._L.isocon_sg_trace_batch(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), n, match, _ptr(mm, _lib.i8p),
+                                               open_, ext, tie_policy, _ptr(ops, _lib.u32p), _ptr(ops_ptr, _lib.u64p), cap,
+                                               ctypes.byref(needed), _ptr(res, _lib.i32p), ctypes.byref(ms))
+            if rc == _lib.ISOCON_E_CAPACITY:
+                cap = int(needed.value) + 16
+                continue
+            _lib.check(rc, "isocon_sg_trace_batch")
+            out = (ops[:int(ops_ptr[n])], ops_ptr.astype(np.int64), res[:n])
+            return out + (ms.value,) if return_ms else out
+
+
+def nn_finalize(n, best, hits):
+    """Host-side CSR assembly from reduced best[] and gathered hit triples (isocon_nn_finalize)."""
+    L = _lib.load()
+    best = np.ascontiguousarray(best, dtype=np.int32)
+    hits = np.ascontiguousarray(hits, dtype=np.int32).reshape(-1, 3)
+    out_best = np.empty(max(n, 1), dtype=np.int32)
+    row_ptr = np.zeros(n + 1, dtype=np.uint64)
+    cap = max(len(hits), 16)
+    cols = np.empty(cap, dtype=np.uint32)
+    needed = ctypes.c_uint64(0)
+    _lib.check(L.isocon_nn_finalize(n, _ptr(best, _lib.i32p), _ptr(hits, _lib.i32p), len(hits), _ptr(out_best, _lib.i32p),
+                                    _ptr(row_ptr, _lib.u64p), _ptr(cols, _lib.u32p), cap, ctypes.byref(needed)),
+               "isocon_nn_finalize")
+    return out_best[:n], row_ptr.astype(np.int64), cols[:int(row_ptr[n])]
+
+
+# small cache: the reference's callers hand the same sequence set to NNG, EAM and SWM within one iteration
+_CACHE = OrderedDict()
+_CACHE_SIZE = 2
+
+
+def store_for(seqs) -> SeqStore:
+    key = tuple(seqs)
+    st = _CACHE.get(key)
+    if st is None:
+        st = SeqStore(key)
+        _CACHE[key] = st
+        while len(_CACHE) > _CACHE_SIZE:
+            _, old = _CACHE.popitem(last=False)
+            old.close()
+    else:
+        _CACHE.move_to_end(key)
+    return st

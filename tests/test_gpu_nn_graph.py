@@ -1,0 +1,115 @@
+"""GPU parity: nearest-neighbour graphs against fixtures produced by the REFERENCE's own NNG module (run under the
+edlib shim, tests/golden/make_golden.py) -- dict content AND key order must match."""
+import numpy as np
+import pytest
+
+from conftest import Params, golden, list_to_dd, ordered
+
+pytestmark = pytest.mark.gpu
+
+
+def test_1set_golden_cases():
+    from isocon_amd import nearest_neighbor_graph as NNG
+    for case in golden("g2_nn_graph_1set.json")["cases"]:
+        S = dict(case["S"])
+        p = Params(case["nr_cores"], case["depth"])
+        graph, isolated = NNG.compute_nearest_neighbor_graph(S, set(case["has_converged"]), p)
+        assert ordered(graph) == ordered(list_to_dd(case["graph"])), (case["nr_cores"], case["depth"])
+        assert sorted(isolated) == case["isolated"]
+
+
+def test_1set_reference_test_data_n200():
+    from isocon_amd import nearest_neighbor_graph as NNG
+    case = golden("g2_nn_graph_n200.json")
+    graph, isolated = NNG.compute_nearest_neighbor_graph(dict(case["S"]), set(), Params(1))
+    assert ordered(graph) == ordered(list_to_dd(case["graph"]))
+    assert sorted(isolated) == case["isolated"]
+
+
+def test_2set_golden_cases():
+    from isocon_amd import nearest_neighbor_graph as NNG
+    for case in golden("g2_nn_graph_2set.json")["cases"]:
+        p = Params(case["nr_cores"], case["depth"])
+        graph = NNG.compute_2set_nearest_neighbor_graph(dict(case["X"]), dict(case["C"]), p)
+        assert ordered(graph) == ordered(list_to_dd(case["graph"])), (case["nr_cores"], case["depth"])
+
+
+def test_1set_synthetic_vs_oracle_loop():
+    """5 k x 1.5 kb is config C2; here a 1.2 k-read slice of it keeps the CPU oracle within seconds."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    accs, seqs, _ = synth.make_reads(1200, 1500, 3, seed=20001)
+    S = dict(zip(accs, seqs))
+    conv = set(seqs[:40])
+    g_gpu, iso_gpu = NNG.compute_nearest_neighbor_graph(S, conv, Params(1))
+    g_cpu, iso_cpu = O.compute_nearest_neighbor_graph(S, conv, Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
+    assert iso_gpu == iso_cpu
+
+
+def test_1set_far_apart_queries_need_wide_bands():
+    """Reads whose nearest neighbour is > 63 / > 511 edits away go through the 128..512-row bands and the un-banded
+    kernel; same-length unrelated sequences exercise the early exit."""
+    import random
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    rng = random.Random(3)
+    nrng = np.random.Generator(np.random.PCG64(4))
+    S = {}
+    base = "".join(rng.choice("ACGT") for _ in range(1800))
+    for i, rate in enumerate([0.0, 0.03, 0.05, 0.08, 0.12, 0.2, 0.3]):
+        prof = dict(rate=rate, ins=0.4, dele=0.3, sub=0.3)
+        for j in range(3):
+            S["r%d_%d" % (i, j)] = synth.mutate(nrng, np.frombuffer(base.encode(), np.uint8), prof).tobytes().decode()
+    for j in range(6):
+        S["junk%d" % j] = "".join(rng.choice("ACGT") for _ in range(1790 + 4 * j))
+    S["short"] = "ACGTAC"
+    S["short2"] = "ACGAAC"
+    g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
+
+
+def test_2set_synthetic_vs_oracle_loop():
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    accs, seqs, isoforms = synth.make_reads(800, 1500, 6, seed=77)
+    X = dict(zip(accs, seqs))
+    C = {"c%d" % i: s for i, s in enumerate(isoforms[:4])}     # reads of isoforms 4,5 have no close candidate
+    C["exact"] = seqs[17]
+    g_gpu = NNG.compute_2set_nearest_neighbor_graph(X, C, Params(1))
+    g_cpu = O.compute_2set_nearest_neighbor_graph(X, C, Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
+    for depth in (1, 2):
+        g_gpu = NNG.compute_2set_nearest_neighbor_graph(X, C, Params(1, depth))
+        g_cpu = O.compute_2set_nearest_neighbor_graph(X, C, Params(1, depth))
+        assert ordered(g_gpu) == ordered(g_cpu), depth
+
+
+def test_sharded_partial_matches_single_call():
+    """Two shards through isocon_nn_partial + min-reduce + isocon_nn_finalize == one isocon_nn_graph call."""
+    from isocon_amd import _lib, synth
+    from isocon_amd.store import SeqStore, nn_finalize
+    accs, seqs, _ = synth.make_reads(900, 800, 4, seed=5)
+    seqs = sorted(set(seqs), key=len)
+    st = SeqStore(seqs)
+    n = len(seqs)
+    best1, rp1, cols1, _ = st.nn_graph()
+    cut = n // 3
+    bests, hits = [], []
+    for (b, e) in ((0, cut), (cut, n)):
+        best = np.full(n, _lib.NN_INF, dtype=np.int32)
+        h, _ = st.nn_partial(b, e, 0, best)
+        bests.append(best); hits.append(h)
+    red = np.minimum(bests[0], bests[1])
+    for (b, e) in ((0, cut), (cut, n)):
+        best = red.copy()
+        h, _ = st.nn_partial(b, e, 1, best)
+        bests.append(best); hits.append(h)
+    red = np.minimum.reduce(bests)
+    best2, rp2, cols2 = nn_finalize(n, red, np.concatenate(hits))
+    assert best1.tolist() == best2.tolist()
+    assert rp1.tolist() == rp2.tolist() and cols1.tolist() == cols2.tolist()
