@@ -1,0 +1,133 @@
+"""GPU drop-in for /root/reference/modules/SW_alignment_module.py (SWM): same names, arguments and return shapes.
+
+The semi-global affine alignments + tracebacks come from isocon_sg_trace_batch (include/isocon_hip.h), which
+replaces parasail.sg_trace_scan_16/32 and the CIGAR decode of parasail_alignment (SWM:64-86).  TIE_POLICY selects
+the trace-back tie rules (0 = parasail's, as restated in oracle/isocon_oracle.c).  `nr_cores` is accepted and ignored.
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from .edlib_alignment_module import _intern
+from .store import SeqStore
+
+TIE_POLICY = 0
+_OPS = "=XID"
+
+
+def cigar_to_seq(cigar, query, ref):
+    """SWM:15-56: CIGAR string -> two gapped strings ('I' consumes the query, 'D' the reference)."""
+    q_aln, r_aln = [], []
+    q_index = r_index = 0
+    length_ = 0
+    for ch in cigar:
+        if "0" <= ch <= "9":
+            length_ = length_ * 10 + ord(ch) - 48
+            continue
+        if ch == "=" or ch == "X":
+            q_aln.append(query[q_index:q_index + length_])
+            r_aln.append(ref[r_index:r_index + length_])
+            q_index += length_
+            r_index += length_
+        elif ch == "I":
+            q_aln.append(query[q_index:q_index + length_])
+            r_aln.append("-" * length_)
+            q_index += length_
+        elif ch == "D":
+            q_aln.append("-" * length_)
+            r_aln.append(ref[r_index:r_index + length_])
+            r_index += length_
+        else:
+            print("error")
+            print(cigar)
+            sys.exit()  # SWM:51-54
+        length_ = 0
+    return "".join(q_aln), "".join(r_aln)
+
+
+def _ops_to_alignment(ops, query, ref):
+    """(len << 4 | code) ops -> gapped strings, without the detour over a CIGAR string."""
+    q_aln, r_aln = [], []
+    qi = ri = 0
+    for op in ops:
+        ln, code = op >> 4, op & 15
+        if code < 2:
+            q_aln.append(query[qi:qi + ln]); r_aln.append(ref[ri:ri + ln]); qi += ln; ri += ln
+        elif code == 2:
+            q_aln.append(query[qi:qi + ln]); r_aln.append("-" * ln); qi += ln
+        else:
+            q_aln.append("-" * ln); r_aln.append(ref[ri:ri + ln]); ri += ln
+    return "".join(q_aln), "".join(r_aln)
+
+
+def ops_to_cigar(ops):
+    return "".join("%d%s" % (op >> 4, _OPS[op & 15]) for op in ops)
+
+
+def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0):
+    """[(s1, s2)], per-pair mismatch penalties -> [(s1_aln, s2_aln, (matches, mismatches, indels))]."""
+    if not pairs:
+        return []
+    seqs, a, b = _intern(pairs)
+    st = SeqStore(seqs)
+    try:
+        ops, ops_ptr, res = st.sg_trace(a, b, np.asarray(mismatch, dtype=np.int8), match=match_score, open_=opening_penalty,
+                                        ext=gap_ext, tie_policy=TIE_POLICY)
+    finally:
+        st.close()
+    ops = ops.tolist()
+    ops_ptr = ops_ptr.tolist()
+    out = []
+    for p, (s1, s2) in enumerate(pairs):
+        s1_aln, s2_aln = _ops_to_alignment(ops[ops_ptr[p]:ops_ptr[p + 1]], s1, s2)
+        out.append((s1_aln, s2_aln, (int(res[p, 3]), int(res[p, 4]), int(res[p, 5]))))
+    return out
+
+
+def parasail_alignment(s1, s2, i, j, x_acc="", y_acc="", match_score=2, mismatch_penalty=-3, opening_penalty=2, gap_ext=0):
+    """SWM:64-86 (single pair)."""
+    stats = _align_pairs([(s1, s2)], [mismatch_penalty], match_score, opening_penalty, gap_ext)[0]
+    if x_acc == y_acc == "":
+        return (s1, s2, stats)
+    return (x_acc, y_acc, stats)
+
+
+def parasail_alignment_helper(arguments):
+    """SWM:59-61."""
+    args, kwargs = arguments
+    return parasail_alignment(*args, **kwargs)
+
+
+def _penalty(ed, s1, s2):
+    """SWM:102-109: mismatch penalty from the error-rate bucket of the INPUT edit distance."""
+    error_rate = float(ed) / min(len(s1), len(s2))
+    if error_rate <= 0.01:
+        return -1
+    elif 0.01 < error_rate <= 0.09:
+        return -2
+    return -4
+
+
+def sw_align_sequences(matches, nr_cores=1, mismatch_penalty=-1):
+    """SWM:89-164.  {s1: {s2: ed}} -> {s1: {s2: (s1_aln, s2_aln, (matches, mismatches, indels))}}."""
+    pairs = [(s1, s2) for s1 in matches for s2 in matches[s1]]
+    pens = [_penalty(matches[s1][s2], s1, s2) for s1, s2 in pairs]
+    exact_matches = {}
+    for (s1, s2), stats in zip(pairs, _align_pairs(pairs, pens)):
+        if stats:
+            exact_matches.setdefault(s1, {})[s2] = stats
+    return exact_matches
+
+
+def sw_align_sequences_keeping_accession(matches, nr_cores=1):
+    """SWM:167-249.  {acc1: {acc2: (s1, s2, ed)}} -> {acc1: {acc2: (s1_aln, s2_aln, (matches, mismatches, indels))}}."""
+    keys = [(a1, a2) for a1 in matches for a2 in matches[a1]]
+    pairs = [(matches[a1][a2][0], matches[a1][a2][1]) for a1, a2 in keys]
+    pens = [_penalty(matches[a1][a2][2], matches[a1][a2][0], matches[a1][a2][1]) for a1, a2 in keys]
+    exact_matches = {}
+    for (a1, a2), stats in zip(keys, _align_pairs(pairs, pens)):
+        if stats:
+            exact_matches.setdefault(a1, {})[a2] = stats
+    return exact_matches

@@ -1,0 +1,130 @@
+"""GPU parity: semi-global affine alignment + traceback (isocon_sg_trace_batch) against the CPU oracle (all tie
+policies) and against fixtures produced by the reference's SWM / GBA modules run under the parasail shim."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import Params, golden, list_to_dd, ordered
+
+pytestmark = pytest.mark.gpu
+
+
+def _rs(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def _mut(rng, s, rate):
+    out = []
+    for c in s:
+        r = rng.random()
+        if r < rate * 0.3:
+            continue
+        if r < rate * 0.6:
+            out.append(rng.choice("ACGT")); out.append(c); continue
+        if r < rate:
+            out.append(rng.choice("ACGT")); continue
+        out.append(c)
+    return "".join(out) or "A"
+
+
+def _check_batch(pairs, mism, policy, match=2, open_=2, ext=0):
+    from isocon_amd import SW_alignment_module as SWM
+    from isocon_amd.edlib_alignment_module import _intern
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    seqs, a, b = _intern(pairs)
+    st = SeqStore(seqs)
+    ops, ptr, res = st.sg_trace(a, b, np.asarray(mism, dtype=np.int8), match=match, open_=open_, ext=ext, tie_policy=policy)
+    for p, (s1, s2) in enumerate(pairs):
+        exp = O.sg_trace(s1, s2, match, int(mism[p]), open_, ext, policy)
+        got_cigar = SWM.ops_to_cigar(ops[ptr[p]:ptr[p + 1]].tolist())
+        got = dict(cigar=got_cigar, score=int(res[p, 0]), end_query=int(res[p, 1]), end_ref=int(res[p, 2]),
+                   matches=int(res[p, 3]), mismatches=int(res[p, 4]), indels=int(res[p, 5]))
+        assert got == exp, (p, len(s1), len(s2), int(mism[p]), policy, got, exp)
+
+
+def test_random_pairs_all_policies():
+    rng = random.Random(11)
+    pairs, mism = [], []
+    for it in range(120):
+        m = rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 200, 511, 512, 513, 700, 1100])
+        s1 = _rs(rng, m)
+        r = rng.random()
+        if r < 0.6:
+            s2 = _mut(rng, s1, rng.choice([0.01, 0.05, 0.2]))
+        elif r < 0.8:
+            s2 = _rs(rng, max(1, m + rng.randint(-40, 40)))
+        else:
+            cut = rng.randint(0, m - 1); ln = rng.randint(0, min(150, m - cut)); s2 = (s1[:cut] + s1[cut + ln:]) or "G"
+        if rng.random() < 0.3:
+            s1, s2 = s2, s1
+        pairs.append((s1, s2)); mism.append(rng.choice([-1, -2, -4, -3]))
+    for policy in (0, 1, 2, 3, 4, 8, 12, 16, 17, 31):
+        _check_batch(pairs, mism, policy)
+    _check_batch(pairs[:40], mism[:40], 0, open_=3, ext=1)     # hypothesis_test_module.py:99 scoring
+    _check_batch(pairs[:40], mism[:40], 0, open_=3, ext=0)     # end_invariant_functions.py:22 scoring
+
+
+def test_read_sized_pairs():
+    """2.5 kb reads (config C3 shape): 5 row passes of the forward kernel, exon-sized gaps, homopolymers."""
+    from isocon_amd import synth
+    rng = random.Random(2)
+    accs, seqs, isoforms = synth.make_reads(24, 2500, 4, seed=30001)
+    pairs = [(isoforms[i % 4], seqs[i]) for i in range(24)] + [(seqs[0], seqs[1]), (isoforms[0], isoforms[1])]
+    mism = [rng.choice([-1, -2, -4]) for _ in pairs]
+    _check_batch(pairs, mism, 0)
+
+
+def test_long_query_many_passes():
+    rng = random.Random(8)
+    s1 = _rs(rng, 5300)
+    s2 = _mut(rng, s1, 0.06)
+    _check_batch([(s1, s2), (s2, s1), (s1[:3000], s2)], [-2, -2, -4], 0)
+
+
+def test_sw_align_sequences_golden():
+    from isocon_amd import SW_alignment_module as SWM
+    g = golden("g4_sw_align.json")
+    assert g["tie_policy"] == SWM.TIE_POLICY
+    for name in ("tie_free", "tie_heavy", "buckets"):
+        matches = list_to_dd(g[name]["input"])
+        for cores in ("1", "2"):
+            got = SWM.sw_align_sequences(matches, nr_cores=int(cores))
+            exp = {k1: {k2: (v[0], v[1], tuple(v[2])) for k2, v in inner.items()} for k1, inner in list_to_dd(g[name]["expected"][cores]).items()}
+            assert ordered(got) == ordered(exp), name
+
+
+def test_sw_align_sequences_keeping_accession_golden():
+    from isocon_amd import SW_alignment_module as SWM
+    g = golden("g4_sw_align.json")["keeping_accession"]
+    matches = {a1: {a2: tuple(v) for a2, v in inner} for a1, inner in g["input"]}
+    got = SWM.sw_align_sequences_keeping_accession(matches, nr_cores=1)
+    exp = {k1: {k2: (v[0], v[1], tuple(v[2])) for k2, v in inner.items()} for k1, inner in list_to_dd(g["expected"]["1"]).items()}
+    assert ordered(got) == ordered(exp)
+
+
+def test_parasail_alignment_golden():
+    from isocon_amd import SW_alignment_module as SWM
+    for c in golden("g4_sw_align.json")["parasail_alignment"]:
+        r = SWM.parasail_alignment(c["s1"], c["s2"], 0, 0, mismatch_penalty=c["mismatch_penalty"],
+                                   opening_penalty=c["opening_penalty"], gap_ext=c["gap_ext"])
+        e = c["expected"]
+        assert (r[0], r[1]) == (e[0], e[1])
+        assert (r[2][0], r[2][1], tuple(r[2][2])) == (e[2][0], e[2][1], tuple(e[2][2]))
+    assert SWM.cigar_to_seq("2=1I1D1X", "ACGT", "ACTA") == ("ACG-T", "AC-TA")
+
+
+def test_get_best_alignments_golden():
+    from isocon_amd import get_best_alignments as GBA
+    g = golden("gba_best_matches.json")
+    approx = {k: v for k, v in g["approx"]}
+    got = GBA.find_best_matches(approx, Params(1))
+    exp = {k1: {k2: tuple(v) for k2, v in inner} for k1, inner in g["expected"]}
+    assert ordered(got) == ordered(exp)
+    paf = {k: [tuple(x) for x in v] for k, v in g["paf"]}
+    got2 = GBA.find_best_matches_2set(paf, dict(g["X"]), dict(g["C"]), Params(1))
+    exp2 = {k1: {k2: tuple(v) for k2, v in inner} for k1, inner in g["expected_2set"]}
+    assert ordered(got2) == ordered(exp2)
+    with pytest.raises(ZeroDivisionError):
+        GBA.find_best_matches({}, Params(1))
