@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- IsoCon hot path on MI355X: read x candidate alignments / s and NN-graph build wall-time.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torch.distributed.run, one rank per GPU).
+One "step" = one exact nearest-neighbour-graph build (compute_nearest_neighbor_graph semantics,
+/root/reference/modules/nearest_neighbor_graph.py:237-296) over the workload, inputs already packed and resident in
+HBM.  Workload = BASELINE.json configs[2]: 50 k synthetic CCS reads, ~2.5 kb, 10 isoforms (seed 30001).
+
+value = alignments / s, where the numerator is the reference-defined pair set that ANY run of the reference loop must
+evaluate: for every query the entries whose length is within its final NN distance (|len difference| <= best_ed is
+the loop's own window rule, NNG:145,152).  It is a lower bound of the reference's edlib call count (whose exact
+value depends on nr_cores through the chunk-local seed dictionary, NNG:112,125-129), is identical for the CPU
+baseline and the GPU, and is computable from the result alone.
+
+Extra objects on the JSON line: `roofline` (dominant kernel k_nn_scan_up, HBM bound on ALGORITHMIC bytes,
+SURVEY.md 8(d): len(q)+len(t)+8 bytes per aligned pair) and `cpu_baseline` (the C oracle -- a restatement of the
+edlib-based loop -- under a multiprocessing Pool on this host's cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def window_pairs(lens, best):
+    """sum over queries of |{t != q : |len_t - len_q| <= best_q}| (rows with no neighbour contribute 0)."""
+    lens = np.asarray(lens, dtype=np.int64)
+    b = np.asarray(best, dtype=np.int64)
+    has = b >= 0
+    lo = np.searchsorted(lens, lens - np.where(has, b, 0), "left")
+    hi = np.searchsorted(lens, lens + np.where(has, b, 0), "right")
+    return int(((hi - lo - 1) * has).sum())
+
+
+# ---- CPU baseline (oracle under a Pool; test infrastructure used as the reported baseline only) -------------------
+_G = {}
+
+
+def _cpu_query(i):
+    from oracle import oracle as O
+    row_ptr, cols, eds, calls = O.nn_1set(_G["seqs"], _G["conv"], int(i), 1, packed=_G["packed"])
+    best = int(eds[0]) if len(eds) else -1
+    return int(i), best, int(calls)
+
+
+def usable_cores():
+    """Threads this process may actually run concurrently: min(cpu_count, affinity, cgroup CPU quota)."""
+    c = os.cpu_count() or 1
+    try:
+        c = min(c, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                c = min(c, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            c = min(c, max(1, q // p))
+    except Exception:
+        pass
+    return c
+
+
+def usable_cores():
+    """Threads this process may actually run concurrently: min(cpu_count, affinity, cgroup CPU quota)."""
+    c = os.cpu_count() or 1
+    try:
+        c = min(c, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                c = min(c, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            c = min(c, max(1, q // p))
+    except Exception:
+        pass
+    return c
+
+
+def cpu_baseline(seqs, lens, budget_s=15.0, max_queries=4096):
+    """Times the oracle's restatement of get_nearest_neighbors (NNG:110-198, edlib-style banded Myers) on a bounded
+    sample of queries spread over the sorted order, Pool(processes=usable cores) as the reference does with nr_cores (NNG:30)."""
+    from multiprocessing import Pool
+    from oracle import oracle as O
+    O.build()
+    cores = usable_cores()
+    n = len(seqs)
+    _G["seqs"] = seqs
+    _G["conv"] = np.zeros(n, dtype=np.uint8)
+    _G["packed"] = O.pack(seqs)            # one ASCII buffer + offsets, inherited by the workers
+    order = np.random.Generator(np.random.PCG64(7)).permutation(n)[:max_queries]
+    done, t0 = [], time.perf_counter()
+    with Pool(processes=cores) as pool:    # fork: the sequence list is inherited, not pickled per task
+        pos = 0
+        t0 = time.perf_counter()
+        while pos < len(order):
+            chunk = order[pos:pos + 2 * cores]
+            done.extend(pool.map(_cpu_query, chunk.tolist(), chunksize=1))
+            pos += len(chunk)
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+    idx = np.array([d[0] for d in done])
+    best = np.array([d[1] for d in done])
+    calls = int(sum(d[2] for d in done))
+    has = best >= 0
+    lo = np.searchsorted(lens, lens[idx] - np.where(has, best, 0), "left")
+    hi = np.searchsorted(lens, lens[idx] + np.where(has, best, 0), "right")
+    pairs = int(((hi - lo - 1) * has).sum())
+    return {"value": pairs / dt, "unit": "alignments/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d queries (random, seed 7) against the full %d-sequence set, %.1f s wall, %d edlib-style "
+                      "calls (%.0f calls/s); oracle/isocon_oracle.c orc_nn_1set under multiprocessing.Pool(%d)"
+                      % (len(done), n, n, dt, calls, calls / dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=50000)
+    ap.add_argument("--length", type=int, default=2500)
+    ap.add_argument("--isoforms", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=30001)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("ISOCON_GPU_DEVICE", str(local_rank))
+
+    from isocon_amd import synth
+
+    accs, seqs, _ = synth.make_reads(args.reads, args.length, args.isoforms, args.seed)
+    seqs = sorted(set(seqs), key=len)          # unique strings, length-sorted (NNG:243-246)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+
+    # CPU baseline first: its fork()ed workers must exist (and be gone) before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(seqs, lens, budget_s=args.cpu_budget)
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    from isocon_amd.dist import sharded_nn_graph
+    from isocon_amd.store import SeqStore
+
+    store = SeqStore(seqs)                     # packed + uploaded: inputs resident in HBM before timing
+
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    last = {}
+
+    def step():
+        if world == 1:
+            best, row_ptr, cols, stats = store.nn_graph()
+            last.update(best=best, edges=len(cols), stats=[stats])
+        else:
+            best, row_ptr, cols, stats = sharded_nn_graph(store, dist=dist, return_stats=True)
+            last.update(best=best, edges=len(cols), stats=stats)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    scan_ms = []
+    for _ in range(args.steps):
+        step()
+        scan_ms.append(last["stats"][0]["scan_kernel_ms"] + last["stats"][0]["seed_kernel_ms"])
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    n_align = window_pairs(lens, last["best"])
+    value = n_align / (ms_per_step / 1e3)
+
+    # roofline of the dominant kernel on this rank (live HIP-event time of its launches inside the timed region)
+    st0 = last["stats"][0]
+    pairs_eval = int(st0["pairs_evaluated"])
+    mean_len = float(lens.mean())
+    alg_bytes = pairs_eval * (2.0 * mean_len + 8.0)
+    k_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
+    achieved = alg_bytes / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_nn_scan_up_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_nn_scan_up (seed + main launch of one step)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel_ms": k_ms, "pairs_per_launch": pairs_eval, "alg_bytes_per_pair": 2.0 * mean_len + 8.0,
+                "lane_columns_per_s": float(st0["cells_columns"]) / (k_ms / 1e3) if k_ms > 0 else 0.0}
+
+    result = {
+        "metric": "read x candidate alignments/sec (NN-graph build, 50k x 2.5kb reads)",
+        "value": value, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "C3: %d synthetic CCS reads (%d unique), ~%d bp, %d isoforms, seed %d; 1-set NN graph"
+                               % (args.reads, len(seqs), args.length, args.isoforms, args.seed),
+                   "alignments_per_step": n_align, "nn_graph_wall_ms": ms_per_step, "edges": int(last["edges"]),
+                   "median_nn_distance": float(np.median(last["best"][last["best"] >= 0])) if (last["best"] >= 0).any() else None,
+                   "parallelism": "1 process/GPU; pairs sharded by lower index; all_reduce(MIN)+all_gather over RCCL" if world > 1 else "single GPU"},
+        "roofline": roofline,
+    }
+    if cpu is not None:
+        result["cpu_baseline"] = cpu
+        result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"] if result["cpu_baseline"]["value"] else None
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

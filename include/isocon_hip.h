@@ -73,9 +73,9 @@ typedef struct {
     uint64_t fallback_queries;    /* queries that needed a band wider than 64 rows */
     uint64_t full_pairs;          /* pairs sent to the un-banded kernel */
     float kernel_ms;              /* HIP-event time of all kernels of the call */
-    float scan_kernel_ms;         /* ... of the dominant (64-row band scan) kernel */
-    uint32_t scan_launches;
-    uint32_t reserved;
+    float scan_kernel_ms;         /* ... of the dominant kernel launch (64-row band scan, main pass) */
+    float seed_kernel_ms;         /* ... of the seed pass that precedes it (1-set only) */
+    uint32_t scan_launches;       /* launches summed into scan_kernel_ms */
 } isocon_nn_stats;
 
 /*

@@ -30,11 +30,11 @@ f32p = ctypes.POINTER(ctypes.c_float)
 class NNStats(ctypes.Structure):
     _fields_ = [("pairs_evaluated", ctypes.c_uint64), ("cells_columns", ctypes.c_uint64), ("tiles", ctypes.c_uint64),
                 ("hits", ctypes.c_uint64), ("fallback_queries", ctypes.c_uint64), ("full_pairs", ctypes.c_uint64),
-                ("kernel_ms", ctypes.c_float), ("scan_kernel_ms", ctypes.c_float), ("scan_launches", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32)]
+                ("kernel_ms", ctypes.c_float), ("scan_kernel_ms", ctypes.c_float), ("seed_kernel_ms", ctypes.c_float),
+                ("scan_launches", ctypes.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 # name -> (restype, argtypes): every symbol include/isocon_hip.h declares

@@ -1,0 +1,89 @@
+"""One-process-per-GPU sharding of the nearest-neighbour search (torch.distributed; backend "nccl" = RCCL on ROCm).
+
+The packed sequence set is replicated on every GPU (31 MB for 50 k x 2.5 kb).  The 1-set search evaluates each
+unordered pair once, on the rank that owns the pair's LOWER index; ranks own contiguous index ranges balanced by
+estimated work.  Exchange steps (the only data-path collectives):
+    all_reduce(MIN) of best[n]   after the 64-row band phase and after the wide-band phase   (4 B x n)
+    all_gather of the candidate edges that attain best[] on their rank                         (12 B x edges)
+The reference has no distributed path (its Pool chunking: /root/reference/modules/nearest_neighbor_graph.py:33-35).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .store import nn_finalize
+
+
+def shard_ranges(lens, world_size, kcap=63, two_set_targets=None):
+    """Contiguous ranges of the length-sorted order with ~equal estimated work.
+
+    1-set: entry q is charged the number of longer-or-equal entries within kcap of its length (its upward window).
+    2-set: every query is charged the number of targets within kcap of its length."""
+    lens = np.asarray(lens, dtype=np.int64)
+    n = len(lens)
+    if world_size <= 1 or n == 0:
+        return [(0, n)] + [(n, n)] * (max(world_size, 1) - 1)
+    if two_set_targets is None:
+        hi = np.searchsorted(lens, lens + kcap, side="right")
+        work = (hi - np.arange(n) - 1).astype(np.float64) + 1.0
+    else:
+        t_lens = np.sort(lens[np.asarray(two_set_targets, dtype=bool)])
+        work = (np.searchsorted(t_lens, lens + kcap, "right") - np.searchsorted(t_lens, lens - kcap, "left")).astype(np.float64) + 1.0
+        work[np.asarray(two_set_targets, dtype=bool)] = 0.0
+    cum = np.cumsum(work)
+    cuts = [0]
+    for r in range(1, world_size):
+        cuts.append(int(np.searchsorted(cum, cum[-1] * r / world_size)))
+    cuts.append(n)
+    cuts = np.maximum.accumulate(np.asarray(cuts))
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world_size)]
+
+
+def _all_gather_rows(dist, rows, device):
+    """all_gather of a [k, 3] int32 array whose k differs per rank (padded to the max)."""
+    import torch
+    world = dist.get_world_size()
+    k = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
+    ks = [torch.zeros_like(k) for _ in range(world)]
+    dist.all_gather(ks, k)
+    kmax = int(max(int(x.item()) for x in ks))
+    buf = torch.zeros((max(kmax, 1), 3), dtype=torch.int32, device=device)
+    if rows.shape[0]:
+        buf[:rows.shape[0]] = torch.from_numpy(np.ascontiguousarray(rows)).to(device)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    parts = [outs[r][:int(ks[r].item())].cpu().numpy() for r in range(world)]
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, 3), np.int32)
+
+
+def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, dist=None, device=None, return_stats=False):
+    """Exact NN graph of `store` (length-sorted) computed by all ranks of the default process group.
+
+    `store` needs .n, .lens and .nn_partial(q_begin, q_end, phase, best, is_converged=, is_target=, depth=).
+    Every rank returns the full (best, row_ptr, cols)."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLC0415
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n = store.n
+    ranges = shard_ranges(store.lens, world, two_set_targets=is_target)
+    qb, qe = ranges[rank]
+    hits_all, stats_all = [], []
+    best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
+    for phase in (0, 1):
+        hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth)
+        t = torch.from_numpy(best).to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)           # exchange step 1 (and 2)
+        best[:] = t.cpu().numpy()
+        hits_all.append(hits)
+        stats_all.append(stats)
+    hits = np.concatenate(hits_all, axis=0) if hits_all else np.zeros((0, 3), np.int32)
+    if len(hits):   # only edges that attain the global minimum of their endpoint travel
+        keep = (hits[:, 2] >= 0) & (hits[:, 2] == best[np.clip(hits[:, 0], 0, max(n - 1, 0))])
+        hits = hits[keep]
+    gathered = _all_gather_rows(dist, hits.astype(np.int32), device)    # exchange step 3
+    out = nn_finalize(n, best[:n], gathered)
+    return out + (stats_all,) if return_stats else out

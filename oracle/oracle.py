@@ -110,8 +110,8 @@ def ed_pairs(seqs, a_idx, b_idx, k=None) -> np.ndarray:
     return out
 
 
-def _nn(fn, seqs, flags, start, count, depth):
-    buf, off = pack(seqs)
+def _nn(fn, seqs, flags, start, count, depth, packed=None):
+    buf, off = packed if packed is not None else pack(seqs)
     flags = np.ascontiguousarray(flags, dtype=np.uint8)
     row_ptr = np.zeros(count + 1, dtype=np.int64)
     cap = max(16 * count, 1024)
@@ -127,9 +127,10 @@ def _nn(fn, seqs, flags, start, count, depth):
         cap = -r
 
 
-def nn_1set(seqs, converged, start, count, depth=2 ** 32):
-    """C restatement of NNG:110-198 on a length-sorted list; returns (row_ptr, cols, eds, n_edlib_calls)."""
-    return _nn(lib().orc_nn_1set, seqs, converged, start, count, depth)
+def nn_1set(seqs, converged, start, count, depth=2 ** 32, packed=None):
+    """C restatement of NNG:110-198 on a length-sorted list; returns (row_ptr, cols, eds, n_edlib_calls).
+    `packed` = pack(seqs) computed once by the caller (bench.py's cpu_baseline) instead of per call."""
+    return _nn(lib().orc_nn_1set, seqs, converged, start, count, depth, packed)
 
 
 def nn_2set(seqs, is_target, start, count, depth=2 ** 32):
