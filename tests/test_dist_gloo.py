@@ -1,0 +1,101 @@
+"""CPU, world_size 2, gloo: the sharded nearest-neighbour protocol (isocon_amd/dist.py) -- shard by lower index,
+all_reduce(MIN) of best[], all_gather of the attaining edges, isocon_nn_finalize -- with the per-shard device work
+replaced by an oracle-backed stand-in that emits the same (best, hits) contract as isocon_nn_partial."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+NN_INF = 0x3FFFFFFF
+
+
+class FakeStore(object):
+    """Same interface as isocon_amd.store.SeqStore.nn_partial; distances from the CPU oracle."""
+
+    def __init__(self, seqs):
+        self.seqs = seqs
+        self.n = len(seqs)
+        self.lens = np.array([len(s) for s in seqs], dtype=np.int64)
+
+    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32):
+        from oracle import oracle as O
+        hits = []
+        n = self.n
+        if is_target is not None:
+            raise NotImplementedError
+        conv = np.zeros(n, bool) if is_converged is None else np.asarray(is_converged, bool)
+        if phase == 0:      # pairs owned through their lower index, band limit 63
+            for q in range(q_begin, q_end):
+                for t in range(q + 1, n):
+                    if self.lens[t] - self.lens[q] > 63:
+                        break
+                    d = O.ed_bounded(self.seqs[q], self.seqs[t], 63)
+                    if d <= 0:
+                        continue
+                    for (e, o) in ((q, t), (t, q)):
+                        if not conv[e] and d <= self.lens[e] and d <= best[e]:
+                            best[e] = d
+                            hits.append((e, o, d))
+        else:               # owned queries still unresolved: unbounded distances inside |len diff| <= len(q)
+            for q in range(q_begin, q_end):
+                if conv[q] or best[q] != NN_INF:
+                    continue
+                for t in range(n):
+                    if t == q or abs(self.lens[t] - self.lens[q]) > self.lens[q]:
+                        continue
+                    d = O.ed_bounded(self.seqs[q], self.seqs[t], int(self.lens[q]))
+                    if 0 < d <= best[q]:
+                        best[q] = d
+                        hits.append((q, t, d))
+        return np.array(hits, dtype=np.int32).reshape(-1, 3), {"phase": phase}
+
+
+def _worker(rank, world, port, seqs, conv, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isocon_amd.dist import sharded_nn_graph
+    best, row_ptr, cols = sharded_nn_graph(FakeStore(seqs), is_converged=conv, dist=dist, device=torch.device("cpu"))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), best=best, row_ptr=row_ptr, cols=cols)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_graph_equals_serial_oracle(tmp_path):
+    from isocon_amd import synth
+    from oracle import oracle as O
+    accs, seqs, _ = synth.make_reads(90, 150, 3, seed=9)
+    seqs = sorted(set(seqs), key=len)
+    seqs.append("ACGT" * 60 + "TTGACCA")          # isolated entry: resolved in phase 1 only
+    seqs = sorted(seqs, key=len)
+    n = len(seqs)
+    conv = np.zeros(n, np.uint8)
+    conv[[3, 10]] = 1
+    mp.spawn(_worker, args=(2, _free_port(), seqs, conv, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    for k in ("best", "row_ptr", "cols"):
+        assert r0[k].tolist() == r1[k].tolist()
+    # serial oracle loop (the reference's semantics)
+    row_ptr, cols, eds, _ = O.nn_1set(seqs, conv, 0, n)
+    assert r0["row_ptr"].tolist() == row_ptr.tolist()
+    assert r0["cols"].tolist() == cols.tolist()
+    exp_best = [int(eds[row_ptr[i]]) if row_ptr[i + 1] > row_ptr[i] else -1 for i in range(n)]
+    assert r0["best"].tolist() == exp_best

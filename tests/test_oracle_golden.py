@@ -1,0 +1,92 @@
+"""CPU: the oracle (C restatement + Python orchestration mirror) against the golden fixtures, which were produced
+by the REFERENCE's own modules (tests/golden/make_golden.py) -- this is what pins the oracle's orchestration."""
+import random
+
+from conftest import Params, golden, list_to_dd, ordered
+from oracle import oracle as O
+
+
+def test_g1_distances_dp_and_bounded():
+    cases = golden("g1_edit_distance.json")["cases"]
+    assert len(cases) > 500
+    for q, t, k, exp in cases:
+        d = O.ed_dp(q, t)
+        assert (d if (k < 0 or d <= k) else -1) == exp
+        assert O.ed_bounded(q, t, k) == exp
+
+
+def test_bounded_myers_vs_dp_random():
+    rng = random.Random(42)
+    for _ in range(400):
+        m = rng.randint(0, 300)
+        a = "".join(rng.choice("ACGT") for _ in range(m))
+        b = list(a)
+        for _ in range(rng.randint(0, 40)):
+            if b and rng.random() < 0.5:
+                del b[rng.randrange(len(b))]
+            else:
+                b.insert(rng.randint(0, len(b)), rng.choice("ACGT"))
+        b = "".join(b)
+        d = O.ed_dp(a, b)
+        for k in (-1, 0, d - 1, d, d + 1, 64, 500):
+            if k >= -1:
+                assert O.ed_bounded(a, b, k) == (d if (k < 0 or d <= k) else -1)
+
+
+def test_g2_nn_graph_1set_matches_reference_output():
+    for case in golden("g2_nn_graph_1set.json")["cases"]:
+        p = Params(case["nr_cores"], case["depth"])
+        graph, isolated = O.compute_nearest_neighbor_graph(dict(case["S"]), set(case["has_converged"]), p)
+        assert ordered(graph) == ordered(list_to_dd(case["graph"]))
+        assert sorted(isolated) == case["isolated"]
+
+
+def test_g2_n200_reference_test_data():
+    case = golden("g2_nn_graph_n200.json")
+    graph, isolated = O.compute_nearest_neighbor_graph(dict(case["S"]), set(), Params(1))
+    assert ordered(graph) == ordered(list_to_dd(case["graph"]))
+    assert O.LAST_CALLS["edlib_ed"] == case["n_edlib_calls_serial"] == 3020
+
+
+def test_g2_nn_graph_2set_matches_reference_output():
+    for case in golden("g2_nn_graph_2set.json")["cases"]:
+        p = Params(case["nr_cores"], case["depth"])
+        graph = O.compute_2set_nearest_neighbor_graph(dict(case["X"]), dict(case["C"]), p)
+        assert ordered(graph) == ordered(list_to_dd(case["graph"]))
+
+
+def test_g3_edlib_align_sequences():
+    g = golden("g3_edlib_align.json")
+    matches = {k: {s: 0 for s in v} for k, v in g["dict_input"]}
+    for cores in ("1", "2"):
+        assert ordered(O.edlib_align_sequences(matches, nr_cores=int(cores))) == ordered(list_to_dd(g["dict_expected"][cores]))
+    acc = {a1: {a2: tuple(v) for a2, v in inner} for a1, inner in g["acc_input"]}
+    assert ordered(O.edlib_align_sequences_keeping_accession(acc)) == ordered(list_to_dd(g["acc_expected"]["1"]))
+
+
+def test_g4_sw_align_and_gba():
+    g = golden("g4_sw_align.json")
+    for name in ("tie_free", "tie_heavy", "buckets"):
+        matches = list_to_dd(g[name]["input"])
+        exp = {k1: {k2: (v[0], v[1], tuple(v[2])) for k2, v in inner.items()} for k1, inner in list_to_dd(g[name]["expected"]["1"]).items()}
+        assert ordered(O.sw_align_sequences(matches)) == ordered(exp)
+    gb = golden("gba_best_matches.json")
+    got = O.find_best_matches({k: v for k, v in gb["approx"]}, Params(1))
+    assert ordered(got) == ordered({k1: {k2: tuple(v) for k2, v in inner} for k1, inner in gb["expected"]})
+
+
+def test_sg_trace_score_and_alignment_consistency():
+    """Scores are policy independent and equal the plain full-table DP; every CIGAR spans both sequences."""
+    rng = random.Random(7)
+    for _ in range(150):
+        a = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 90)))
+        b = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 90))) if rng.random() < 0.3 else a[:rng.randint(1, len(a))] + "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 6))) + a[rng.randint(0, len(a)):]
+        b = b or "T"
+        for (mm, op, ext) in ((-1, 2, 0), (-4, 2, 0), (-3, 3, 1)):
+            s = O.sg_score(a, b, 2, mm, op, ext)
+            for pol in (0, 1, 2, 4, 8, 16, 31):
+                r = O.sg_trace(a, b, 2, mm, op, ext, pol)
+                assert r["score"] == s
+                qa, ra = O.cigar_to_seq(r["cigar"], a, b)
+                assert qa.replace("-", "") == a and ra.replace("-", "") == b and len(qa) == len(ra)
+                assert r["matches"] + r["mismatches"] + r["indels"] == len(qa)
