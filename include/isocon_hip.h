@@ -67,7 +67,8 @@ int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const
 /* statistics block filled by the nearest-neighbour entry points (all counters are for the one call) */
 typedef struct {
     uint64_t pairs_evaluated;     /* (shared,lane) pairs the banded kernels actually ran */
-    uint64_t cells_columns;       /* text columns processed, summed over evaluated lanes */
+    uint64_t cells_columns;       /* text columns processed, summed over evaluated lanes (lanes x wave columns) */
+    uint64_t live_columns;        /* ... counting a lane only while its pair was still undecided */
     uint64_t tiles;               /* 64-lane tiles executed */
     uint64_t hits;                /* candidate edges recorded on the device */
     uint64_t fallback_queries;    /* queries that needed a band wider than 64 rows */

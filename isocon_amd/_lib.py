@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libisocon_hip.so")
+SO_PATH = os.environ.get("ISOCON_LIB", os.path.join(_HERE, "lib", "libisocon_hip.so"))   # override: kernel experiments
 SRC_DIR = os.path.join(_HERE, "csrc")
 _SOURCES = ["isocon_hip.hip", "band_core.hpp", "common.hpp", "ed_band.hpp", "ed_full.hpp", "nn.hpp", "nn_host.inc",
             "sg.hpp", "sg_host.inc"]
@@ -28,7 +28,7 @@ f32p = ctypes.POINTER(ctypes.c_float)
 
 
 class NNStats(ctypes.Structure):
-    _fields_ = [("pairs_evaluated", ctypes.c_uint64), ("cells_columns", ctypes.c_uint64), ("tiles", ctypes.c_uint64),
+    _fields_ = [("pairs_evaluated", ctypes.c_uint64), ("cells_columns", ctypes.c_uint64), ("live_columns", ctypes.c_uint64), ("tiles", ctypes.c_uint64),
                 ("hits", ctypes.c_uint64), ("fallback_queries", ctypes.c_uint64), ("full_pairs", ctypes.c_uint64),
                 ("kernel_ms", ctypes.c_float), ("scan_kernel_ms", ctypes.c_float), ("seed_kernel_ms", ctypes.c_float),
                 ("scan_launches", ctypes.c_uint32)]

@@ -10,15 +10,25 @@ namespace isocon {
 struct TileStats {
     uint32_t lanes_run;   // lanes that entered the DP
     uint32_t cols;        // columns the wave executed
+    uint32_t live_cols;   // sum over 32-column halves of (lanes still undecided at the start of the half) x 32
 };
 
 // Runs one tile.  `shared` and `m` must be wave-uniform.  Returns per lane:
 //   >= 0 : exact distance (<= k_req);  -1 : distance > k_req (certified);  -2 : undetermined, the tile's common
 //   window could not certify k_req for this lane's length difference (caller re-tiles the pair).
-template <int W>
+//
+// Window source (gfx950 issue costs, scripts/ubench/valu_rate2.hip: and/or/xor/not/add/sub/lshr on VGPR operands
+// issue in ~2.3 cycles per wave-instruction, anything with an SGPR operand and all VOP3-only integer ops in ~4.2):
+//   LDS == false : the pattern window lives in SGPRs and is slid by the scalar unit (any W);
+//   LDS == true  : W == 1, the workgroup has tabulated the 64-bit window of BOTH complemented bit-planes for every
+//                  bit offset o in [-63, m+64) in LDS (tab[o+63] = {~lo, ~hi}); each column is one broadcast
+//                  ds_read_b128 and the Eq logic runs on VGPR operands only.
+template <int W, bool LDS = false>
 __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t shared, int32_t m, uint32_t tid,
-                                                 int32_t n, int32_t k_req, bool active, TileStats *st)
+                                                 int32_t n, int32_t k_req, bool active, TileStats *st,
+                                                 const uint4 *tab = nullptr)
 {
+    static_assert(!LDS || W == 1, "the LDS window table is built for the 64-row band");
     const int32_t d = m - n;
     const int32_t ad = d < 0 ? -d : d;
     active = active && k_req >= 0 && ad <= k_req;
@@ -30,7 +40,7 @@ __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t sha
     a0 = uniform_i32(a0);
     const int32_t n_min = uniform_i32(wave_min_i32(active ? n : 0x7fffffff));
     const int32_t n_max = uniform_i32(wave_max_i32(active ? n : 0));
-    if (st) { st->lanes_run = 0; st->cols = 0; }
+    if (st) { st->lanes_run = 0; st->cols = 0; st->live_cols = 0; }
     if (n_max == 0) return trivial ? ad : -1;
 
     const LaneGeom g = lane_geom<W>(d, k_req, a0);
@@ -52,21 +62,27 @@ __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t sha
     auto chunk_lo = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + shared) * 2] : 0; };
     auto chunk_hi = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + shared) * 2 + 1] : 0; };
 
-    uint64_t NL[W], NH[W], VM[W], FL, FH;
+    uint64_t NL[W], NH[W], VM[W], FL = 0, FH = 0;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-        NL[i] = ~stream64(chunk_lo, a0 + 64 * i);
-        NH[i] = ~stream64(chunk_hi, a0 + 64 * i);
+        if (!LDS) {
+            NL[i] = ~stream64(chunk_lo, a0 + 64 * i);
+            NH[i] = ~stream64(chunk_hi, a0 + 64 * i);
+        }
         VM[i] = valid_word(nv, i);
     }
+    const uint4 *wtab = LDS ? tab + (a0 + 63) : nullptr;   // wtab[j-1] = window of column j
 
     const ulonglong2 *P2 = reinterpret_cast<const ulonglong2 *>(planes);
     ulonglong2 tnext = P2[(size_t)tid];
     int32_t cols = 0;
+    uint32_t live_cols = 0;
     bool stop = false;
     for (int32_t c = 0; 64 * c < n_max && !stop; ++c) {
-        FL = ~stream64(chunk_lo, a0 + 64 * W + 64 * c);
-        FH = ~stream64(chunk_hi, a0 + 64 * W + 64 * c);
+        if (!LDS) {
+            FL = ~stream64(chunk_lo, a0 + 64 * W + 64 * c);
+            FH = ~stream64(chunk_hi, a0 + 64 * W + 64 * c);
+        }
         const ulonglong2 tcur = tnext;
         if (64 * (c + 1) < n_max) tnext = P2[(size_t)(c + 1) * nseq + tid];
 #pragma unroll 1
@@ -77,13 +93,21 @@ __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t sha
             const uint32_t wl = (uint32_t)(h ? (tcur.x >> 32) : tcur.x);
             const uint32_t wh = (uint32_t)(h ? (tcur.y >> 32) : tcur.y);
             const bool fast = cnt == 32 && jb >= nv && jb + 32 <= n_min;
+            live_cols += (uint32_t)__popcll(__ballot(live)) * (uint32_t)cnt;
             if (fast) {
-#pragma unroll 8
+#pragma unroll 32
                 for (int jj = 0; jj < 32; ++jj) {
                     const uint32_t slo = (uint32_t)__builtin_amdgcn_sbfe((int)wl, jj, 1);
                     const uint32_t shi = (uint32_t)__builtin_amdgcn_sbfe((int)wh, jj, 1);
-                    band_step<W, false>(L, NL, NH, VM, slo, shi);
-                    window_slide<W>(NL, NH, VM, FL, FH);
+                    if (LDS) {
+                        const uint4 w = wtab[jb + jj];
+                        NL[0] = ((uint64_t)w.y << 32) | w.x;
+                        NH[0] = ((uint64_t)w.w << 32) | w.z;
+                        band_step<W, false>(L, NL, NH, VM, slo, shi);
+                    } else {
+                        band_step<W, false>(L, NL, NH, VM, slo, shi);
+                        window_slide<W>(NL, NH, VM, FL, FH);
+                    }
                 }
                 cols = jb + 32;
                 if (live && n == cols) {
@@ -96,8 +120,17 @@ __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t sha
                 for (int jj = 0; jj < cnt; ++jj) {
                     const uint32_t slo = (uint32_t)__builtin_amdgcn_sbfe((int)wl, jj, 1);
                     const uint32_t shi = (uint32_t)__builtin_amdgcn_sbfe((int)wh, jj, 1);
-                    band_step<W, true>(L, NL, NH, VM, slo, shi);
-                    window_slide<W>(NL, NH, VM, FL, FH);
+                    if (LDS) {
+                        const uint4 w = wtab[jb + jj];
+                        NL[0] = ((uint64_t)w.y << 32) | w.x;
+                        NH[0] = ((uint64_t)w.w << 32) | w.z;
+                        const int32_t vb = nv - (jb + jj);      // virtual rows still inside the window
+                        VM[0] = vb <= 0 ? ~(uint64_t)0 : (vb >= 64 ? 0 : (~(uint64_t)0 << vb));
+                        band_step<W, true>(L, NL, NH, VM, slo, shi);
+                    } else {
+                        band_step<W, true>(L, NL, NH, VM, slo, shi);
+                        window_slide<W>(NL, NH, VM, FL, FH);
+                    }
                     if (live && n == jb + jj + 1) {
                         const int32_t dv = band_diag_value<W>(L, nv, n);
                         res = dv <= k_eff ? dv : fail;
@@ -117,6 +150,7 @@ __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t sha
     if (st) {
         st->lanes_run = (uint32_t)__popcll(__ballot(active && g.k_eff >= 0));
         st->cols = (uint32_t)cols;
+        st->live_cols = live_cols;
     }
     return res;
 }

@@ -49,12 +49,12 @@ __device__ __forceinline__ void nn_append(const NNParams &P, bool want, int32_t 
     }
 }
 
-struct WaveAcc { unsigned long long pairs, cols, tiles; };
+struct WaveAcc { unsigned long long pairs, cols, tiles, live; };
 
 // One tile: shared entry s (wave-uniform) against the lane entries p (p < 0 = empty lane).
-template <int W>
+template <int W, bool LDS = false>
 __device__ __forceinline__ void nn_process_tile(const DevStore &S, const NNParams &P, uint32_t s, int32_t m,
-                                                bool s_isq, bool s_ist, int64_t p, WaveAcc &acc)
+                                                bool s_isq, bool s_ist, int64_t p, WaveAcc &acc, const uint4 *tab = nullptr)
 {
     const bool valid = p >= 0 && p < (int64_t)S.n && (uint32_t)p != s;
     const uint32_t tid = valid ? (uint32_t)p : s;
@@ -69,10 +69,11 @@ __device__ __forceinline__ void nn_process_tile(const DevStore &S, const NNParam
     int32_t k = ks > kl ? ks : kl;
     if (k > P.kcap) k = P.kcap;
     TileStats st;
-    const int32_t r = band_tile_run<W>(S, s, m, tid, n_t, k, valid && k >= 0, &st);
+    const int32_t r = band_tile_run<W, LDS>(S, s, m, tid, n_t, k, valid && k >= 0, &st, tab);
     acc.pairs += st.lanes_run;
     acc.cols += (unsigned long long)st.lanes_run * st.cols;
     acc.tiles += 1;
+    acc.live += st.live_cols;
     bool hit_s = false, hit_l = false;
     if (r >= P.min_d) {
         if (upd_s && r <= m) { const int32_t old = atomicMin(P.best + s, r); hit_s = r <= old; }
@@ -90,6 +91,7 @@ __device__ __forceinline__ void nn_flush_acc(const NNParams &P, const WaveAcc &a
         atomicAdd(c + 0, acc.pairs);
         atomicAdd(c + 1, acc.cols);
         atomicAdd(c + 2, acc.tiles);
+        atomicAdd(c + 3, acc.live);
     }
 }
 
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
     const uint32_t q = q_begin + (uint32_t)((blockIdx.x * 4u + (uint32_t)wave) / (uint32_t)wpq);
-    WaveAcc acc = {0, 0, 0};
+    WaveAcc acc = {0, 0, 0, 0};
     if (q < q_end) {
         const int32_t m = S.lens[q];
         const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
@@ -117,6 +119,51 @@ __global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint
     nn_flush_acc(P, acc);
 }
 
+// Same scan with the query's window table in LDS (see band_tile_run<1, true>): one workgroup of NWAVES waves per
+// entry q; dynamic LDS = 16 B x (maxlen + 192).  This is the main-pass kernel of the 1-set search.
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParams P, uint32_t q_begin, uint32_t q_end,
+                                                              int32_t tile_begin, int32_t tile_end)
+{
+    extern __shared__ uint4 wtab[];
+    const int32_t wave = threadIdx.x >> 6;
+    const int32_t lane = threadIdx.x & 63;
+    const uint32_t q = q_begin + blockIdx.x;
+    WaveAcc acc = {0, 0, 0, 0};
+    if (q >= q_end) return;
+    const int32_t m = S.lens[q];
+    {   // anything to do at all?  (uniform)
+        const int64_t t0 = (int64_t)q + 1 + (int64_t)tile_begin * 64;
+        if (t0 >= (int64_t)S.n || t0 - (int64_t)q > (int64_t)P.depth || S.lens[t0] - m > P.kcap) return;
+    }
+    // window table: entry e <-> bit offset o = e - 63 of the query's bit-plane stream, complemented
+    {
+        const uint64_t *planes = S.planes;
+        const uint32_t nseq = S.n;
+        const int32_t nchunks = (int32_t)S.nchunks;
+        auto chunk_lo = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2] : 0; };
+        auto chunk_hi = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2 + 1] : 0; };
+        const int32_t entries = m + 192;
+        for (int32_t e = threadIdx.x; e < entries; e += NWAVES * 64) {
+            const uint64_t nl = ~stream64(chunk_lo, e - 63), nh = ~stream64(chunk_hi, e - 63);
+            uint4 w;
+            w.x = (uint32_t)nl; w.y = (uint32_t)(nl >> 32); w.z = (uint32_t)nh; w.w = (uint32_t)(nh >> 32);
+            wtab[e] = w;
+        }
+    }
+    __syncthreads();
+    const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
+    for (int32_t tile = tile_begin + wave; tile < tile_end; tile += NWAVES) {
+        const int64_t t0 = (int64_t)q + 1 + (int64_t)tile * 64;
+        if (t0 >= (int64_t)S.n || t0 - (int64_t)q > (int64_t)P.depth) break;
+        if (S.lens[t0] - m > P.kcap) break;
+        int64_t p = t0 + lane;
+        if (p - (int64_t)q > (int64_t)P.depth) p = -1;
+        nn_process_tile<1, true>(S, P, q, m, q_isq, q_ist, p, acc, wtab);
+    }
+    nn_flush_acc(P, acc);
+}
+
 // Explicit tiles: shared entry tile_shared[t] against the entries lane_ids[64t + lane] (0xffffffff = empty lane).
 template <int W>
 __global__ __launch_bounds__(256) void k_nn_tiles(DevStore S, NNParams P, const uint32_t *__restrict__ tile_shared,
@@ -124,7 +171,7 @@ __global__ __launch_bounds__(256) void k_nn_tiles(DevStore S, NNParams P, const 
 {
     const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
     const int32_t lane = threadIdx.x & 63;
-    WaveAcc acc = {0, 0, 0};
+    WaveAcc acc = {0, 0, 0, 0};
     if (t < n_tiles) {
         const uint32_t s = (uint32_t)uniform_i32((int32_t)tile_shared[t]);
         const int32_t m = S.lens[s];

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint64_t plane_bits64(const uint64_t *planes, uint32_
 // next pass.  Trace layout: code of cell (i, j) lives at  ((pass*steps + j + l) * 64 + l) * R/2 + r/2,
 // pass = i / (64R), l = (i % (64R)) / R, r = i % R, steps = n + 63.
 template <int R, bool GENERAL>
-__global__ __launch_bounds__(64) void k_sg_forward(DevStore S, const SgPair *__restrict__ pairs, SgParams prm,
+__global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *__restrict__ pairs, SgParams prm,
                                                     uint8_t *__restrict__ trace, int2 *__restrict__ bound_all,
                                                     int32_t *__restrict__ endinfo)
 {

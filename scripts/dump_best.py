@@ -1,0 +1,12 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from isocon_amd import synth
+from isocon_amd.store import SeqStore
+accs, seqs, _ = synth.make_reads(50000, 2500, 10, 30001)
+seqs = sorted(set(seqs), key=len)
+st = SeqStore(seqs)
+best, rp, cols, stats = st.nn_graph()
+os.makedirs("gpurun_out", exist_ok=True)
+np.save("gpurun_out/best_c3.npy", best)
+print(stats)
