@@ -18,8 +18,40 @@ thread_local std::string g_last_error;
 
 using namespace isocon;
 
+// Grow-only device scratch owned by the store: repeated calls reuse their buffers instead of paying
+// hipMalloc/hipFree (tens of ms for the multi-GB trace scratch) every time.
+struct ScratchPool {
+    struct Slot { void *p = nullptr; size_t cap = 0; };
+    Slot slots[32];
+    void *get(int idx, size_t bytes)
+    {
+        Slot &s = slots[idx];
+        if (bytes == 0) bytes = 16;
+        if (s.cap < bytes) {
+            if (s.p) (void)hipFree(s.p);
+            s.p = nullptr; s.cap = 0;
+            const size_t want = bytes + bytes / 8;
+            if (hipMalloc(&s.p, want) == hipSuccess) s.cap = want;
+            else if (hipMalloc(&s.p, bytes) == hipSuccess) s.cap = bytes;
+            else { s.p = nullptr; (void)hipGetLastError(); }
+        }
+        return s.p;
+    }
+    void release()
+    {
+        for (Slot &s : slots) { if (s.p) (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+    }
+};
+
+enum {
+    SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS,
+    SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND
+};
+
 struct isocon_store {
     DevStore dev;
+    ScratchPool pool;
     std::vector<int32_t> lens;   // host copy
     uint64_t device_bytes = 0;
     uint64_t *d_planes = nullptr;
@@ -29,12 +61,24 @@ struct isocon_store {
 
 namespace {
 
+// A device buffer: pooled (slot of the store's ScratchPool) when constructed with a pool, private otherwise.
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ScratchPool *pool = nullptr;
+    int slot = -1;
+    DevBuf() {}
+    DevBuf(ScratchPool *pl, int sl) : pool(pl), slot(sl) {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p && !pool) (void)hipFree(p); }
     template <class T> T *as() { return static_cast<T *>(p); }
     int alloc(size_t bytes)
     {
+        if (pool) {
+            p = pool->get(slot, bytes);
+            if (!p) { g_last_error = "hipMalloc(scratch slot " + std::to_string(slot) + ", " + std::to_string(bytes) + " B) failed"; return ISOCON_E_HIP; }
+            return ISOCON_OK;
+        }
         if (p) { (void)hipFree(p); p = nullptr; }
         ISO_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
         return ISOCON_OK;
@@ -163,6 +207,7 @@ void isocon_store_destroy(isocon_store *s)
     if (!s) return;
     if (s->d_planes) (void)hipFree(s->d_planes);
     if (s->d_lens) (void)hipFree(s->d_lens);
+    s->pool.release();
     delete s;
 }
 
@@ -177,13 +222,13 @@ uint64_t isocon_store_device_bytes(const isocon_store *s) { return s ? s->device
 namespace {
 
 template <int W>
-int launch_band_tiles(const DevStore &S, const std::vector<uint32_t> &tile_shared, const std::vector<uint32_t> &lane_ids,
+int launch_band_tiles(isocon_store *st, const DevStore &S, const std::vector<uint32_t> &tile_shared, const std::vector<uint32_t> &lane_ids,
                       const std::vector<int32_t> &lane_k, std::vector<int32_t> &out, EventTimer &tm)
 {
     const size_t nt = tile_shared.size();
     out.assign(nt * 64, -1);
     if (!nt) return ISOCON_OK;
-    DevBuf d_ts, d_ids, d_k, d_out;
+    DevBuf d_ts(&st->pool, SLOT_ED_TS), d_ids(&st->pool, SLOT_ED_IDS), d_k(&st->pool, SLOT_ED_K), d_out(&st->pool, SLOT_ED_OUT);
     int rc;
     if ((rc = d_ts.alloc(nt * 4)) || (rc = d_ids.alloc(nt * 64 * 4)) || (rc = d_k.alloc(nt * 64 * 4)) || (rc = d_out.alloc(nt * 64 * 4))) return rc;
     ISO_HIP_CHECK(hipMemcpy(d_ts.p, tile_shared.data(), nt * 4, hipMemcpyHostToDevice));
@@ -198,25 +243,25 @@ int launch_band_tiles(const DevStore &S, const std::vector<uint32_t> &tile_share
     return ISOCON_OK;
 }
 
-int run_band_stage(int W, const DevStore &S, const std::vector<uint32_t> &ts, const std::vector<uint32_t> &ids,
+int run_band_stage(int W, isocon_store *st, const DevStore &S, const std::vector<uint32_t> &ts, const std::vector<uint32_t> &ids,
                    const std::vector<int32_t> &ks, std::vector<int32_t> &out, EventTimer &tm)
 {
     switch (W) {
-    case 1: return launch_band_tiles<1>(S, ts, ids, ks, out, tm);
-    case 2: return launch_band_tiles<2>(S, ts, ids, ks, out, tm);
-    case 4: return launch_band_tiles<4>(S, ts, ids, ks, out, tm);
-    case 8: return launch_band_tiles<8>(S, ts, ids, ks, out, tm);
+    case 1: return launch_band_tiles<1>(st, S, ts, ids, ks, out, tm);
+    case 2: return launch_band_tiles<2>(st, S, ts, ids, ks, out, tm);
+    case 4: return launch_band_tiles<4>(st, S, ts, ids, ks, out, tm);
+    case 8: return launch_band_tiles<8>(st, S, ts, ids, ks, out, tm);
     default: return ISOCON_E_ARG;
     }
 }
 
-int run_full(const isocon_store *st, const std::vector<uint32_t> &a, const std::vector<uint32_t> &b,
+int run_full(isocon_store *st, const std::vector<uint32_t> &a, const std::vector<uint32_t> &b,
              const std::vector<int32_t> &k, std::vector<int32_t> &out, EventTimer &tm)
 {
     const size_t np = a.size();
     out.assign(np, -1);
     if (!np) return ISOCON_OK;
-    DevBuf d_a, d_b, d_k, d_out;
+    DevBuf d_a(&st->pool, SLOT_FULL_A), d_b(&st->pool, SLOT_FULL_B), d_k(&st->pool, SLOT_FULL_K), d_out(&st->pool, SLOT_FULL_OUT);
     int rc;
     if ((rc = d_a.alloc(np * 4)) || (rc = d_b.alloc(np * 4)) || (rc = d_k.alloc(np * 4)) || (rc = d_out.alloc(np * 4))) return rc;
     ISO_HIP_CHECK(hipMemcpy(d_a.p, a.data(), np * 4, hipMemcpyHostToDevice));
@@ -248,7 +293,7 @@ namespace isocon {
 
 // Shared by isocon_ed_pairs and the NN fallback: exact bounded/unbounded distances for an explicit pair list.
 // Stages: 64-row band (k <= 63), 128, 256, 512 rows, then the un-banded kernel.
-int ed_pairs_impl(const isocon_store *st, const uint32_t *a, const uint32_t *b, const int32_t *k, uint64_t n_pairs,
+int ed_pairs_impl(isocon_store *st, const uint32_t *a, const uint32_t *b, const int32_t *k, uint64_t n_pairs,
                   int32_t *out_ed, float *kernel_ms, uint64_t *full_pairs)
 {
     EventTimer tm;
@@ -310,7 +355,7 @@ int ed_pairs_impl(const isocon_store *st, const uint32_t *a, const uint32_t *b, 
                 i = j;
             }
             std::vector<int32_t> res;
-            int rc = run_band_stage(W, st->dev, ts, ids, ks, res, tm);
+            int rc = run_band_stage(W, st, st->dev, ts, ids, ks, res, tm);
             if (rc) return rc;
             std::vector<uint64_t> retry;
             for (size_t sidx = 0; sidx < slot_pair.size(); ++sidx) {

@@ -1,0 +1,81 @@
+"""GPU, BASELINE.json's full size (config C3: 50 k reads x ~2.5 kb, 10 isoforms): size-independent properties of the
+exact NN graph plus oracle spot checks -- the CPU oracle needs ~0.2 s per query at this size, so only a sample of rows
+is recomputed with the reference loop."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3():
+    from isocon_amd import synth
+    from isocon_amd.store import SeqStore
+    accs, seqs, _ = synth.make_reads(50000, 2500, 10, seed=30001)
+    seqs = sorted(set(seqs), key=len)
+    st = SeqStore(seqs)
+    best, row_ptr, cols, stats = st.nn_graph()
+    return seqs, st, best, row_ptr, cols, stats
+
+
+def test_c3_structure_and_symmetry(c3):
+    seqs, st, best, row_ptr, cols, stats = c3
+    n = len(seqs)
+    lens = st.lens
+    assert row_ptr[-1] == len(cols) and (np.diff(row_ptr) >= 0).all()
+    has = np.diff(row_ptr) > 0
+    assert has.all()                                   # dense isoform clusters: every read has a neighbour
+    assert (best[has] > 0).all() and (best <= lens).all()
+    rows = np.repeat(np.arange(n), np.diff(row_ptr))
+    assert (cols != rows).all()
+    assert (np.abs(lens[cols] - lens[rows]) <= best[rows]).all()       # a neighbour at distance d differs by <= d in length
+    assert (best[cols] <= best[rows]).all()                            # symmetry of the metric: my NN's NN is at least as close
+    # reference insertion order: ascending |offset|, lower index first
+    off = np.abs(cols.astype(np.int64) - rows)
+    same = rows[1:] == rows[:-1]
+    assert ((off[1:] > off[:-1]) | ((off[1:] == off[:-1]) & (cols[1:] > cols[:-1])))[same].all()
+
+
+def test_c3_idempotent(c3):
+    seqs, st, best, row_ptr, cols, stats = c3
+    b2, r2, c2, _ = st.nn_graph()
+    assert (b2 == best).all() and (r2 == row_ptr).all() and (c2 == cols).all()
+
+
+def test_c3_edges_are_true_distances(c3):
+    """every reported edge re-aligned through the independent pair-list entry point (unbounded)"""
+    seqs, st, best, row_ptr, cols, stats = c3
+    rows = np.repeat(np.arange(len(seqs)), np.diff(row_ptr))
+    ed = st.ed_pairs(rows[:20000], cols[:20000], None)
+    assert (ed == best[rows[:20000]]).all()
+
+
+def test_c3_sampled_rows_equal_reference_loop(c3):
+    from oracle import oracle as O
+    seqs, st, best, row_ptr, cols, stats = c3
+    packed = O.pack(seqs)
+    conv = np.zeros(len(seqs), np.uint8)
+    rng = np.random.default_rng(3)
+    for i in rng.choice(len(seqs), 24, replace=False).tolist():
+        rp, c, e, _ = O.nn_1set(seqs, conv, i, 1, packed=packed)
+        assert cols[row_ptr[i]:row_ptr[i + 1]].tolist() == c.tolist(), i
+        assert (e == best[i]).all()
+
+
+def test_c3_alignments_roundtrip(c3):
+    """SW on 256 (read, NN) pairs at full length: un-gapped alignment == input (correction_module.py:273-275),
+    counts consistent, score identity."""
+    from isocon_amd import SW_alignment_module as SWM
+    seqs, st, best, row_ptr, cols, stats = c3
+    q = np.arange(0, len(seqs), len(seqs) // 256)[:256]
+    t = cols[row_ptr[q]]
+    mm = np.full(len(q), -2, dtype=np.int8)
+    ops, ptr, res = st.sg_trace(t, q, mm)
+    for p in range(len(q)):
+        s1, s2 = seqs[int(t[p])], seqs[int(q[p])]
+        a1, a2 = SWM._ops_to_alignment(ops[ptr[p]:ptr[p + 1]].tolist(), s1, s2)
+        assert a1.replace("-", "") == s1 and a2.replace("-", "") == s2 and len(a1) == len(a2)
+        m = sum(1 for x, y in zip(a1, a2) if x == y and x != "-")
+        x = sum(1 for x, y in zip(a1, a2) if x != y and x != "-" and y != "-")
+        assert (m, x, len(a1) - m - x) == tuple(res[p, 3:6])
+        assert x + (len(a1) - m - x) >= best[q[p]]          # an alignment cannot beat the edit distance
