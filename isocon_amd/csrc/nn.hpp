@@ -164,6 +164,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParam
     nn_flush_acc(P, acc);
 }
 
+// planes2[chunk][newpos] = planes[chunk][perm[newpos]]  (16 B per element; used to group similar sequences of equal length)
+__global__ __launch_bounds__(256) void k_permute_planes(const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ dst,
+                                                         const uint32_t *__restrict__ perm, uint32_t n, uint32_t nchunks)
+{
+    const size_t total = (size_t)n * nchunks;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t c = (uint32_t)(i / n), pos = (uint32_t)(i - (size_t)c * n);
+        dst[i] = src[(size_t)c * n + perm[pos]];
+    }
+}
+
 // Explicit tiles: shared entry tile_shared[t] against the entries lane_ids[64t + lane] (0xffffffff = empty lane).
 template <int W>
 __global__ __launch_bounds__(256) void k_nn_tiles(DevStore S, NNParams P, const uint32_t *__restrict__ tile_shared,
