@@ -236,7 +236,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_nn_scan_up_hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("nn_scan_main_hbm_bytes_per_launch")
         except Exception:
             traffic = None
     is_default = (args.reads, args.length, args.isoforms, args.seed) == (50000, 2500, 10, 30001)

@@ -1,0 +1,82 @@
+"""GPU: edge cases of the hot-path entry points (empty / singleton / all-converged inputs, duplicates, tiny strings)."""
+import numpy as np
+import pytest
+
+from conftest import Params, ordered
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nn_graph_degenerate_inputs():
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from oracle import oracle as O
+    p = Params(1)
+    for S in ({}, {"a": "ACGTACGT"}, {"a": "ACGT", "b": "ACGT"}, {"a": "A", "b": "C", "c": "AC"}):
+        if not S:
+            continue   # the reference itself is never called with an empty dict (graphs.py:56-58 guards)
+        g, iso = NNG.compute_nearest_neighbor_graph(dict(S), set(), p)
+        ge, isoe = O.compute_nearest_neighbor_graph(dict(S), set(), p)
+        assert ordered(g) == ordered(ge) and iso == isoe
+    S = {"r%d" % i: "ACGTTGCA" * 5 + "A" * i for i in range(6)}
+    allc = set(S.values())
+    g, iso = NNG.compute_nearest_neighbor_graph(S, allc, p)          # every entry converged: all rows empty
+    assert ordered(g) == ordered(O.compute_nearest_neighbor_graph(S, allc, p)[0])
+    assert all(v == {} for v in g.values())
+
+
+def test_nn_graph_distance_equal_to_length_is_admitted():
+    """best_ed starts at len(seq1) and the equality branch admits d == len(seq1) (NNG:129,161)."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from oracle import oracle as O
+    S = {"a": "AAAA", "b": "CCCC", "c": "GGGGGG"}
+    g, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert ordered(g) == ordered(O.compute_nearest_neighbor_graph(S, set(), Params(1))[0])
+    assert g["a"] == {"b": 4}
+
+
+def test_2set_duplicate_sequences_and_no_candidates_in_reach():
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from oracle import oracle as O
+    X = {"r1": "ACGTACGTAC", "r2": "ACGTACGTAC", "r3": "TTTT"}
+    C = {"c1": "ACGTACGTAC", "c2": "ACGTACGTAC", "c3": "ACGTACGAAC"}
+    g = NNG.compute_2set_nearest_neighbor_graph(X, C, Params(1))
+    assert ordered(g) == ordered(O.compute_2set_nearest_neighbor_graph(X, C, Params(1)))
+    assert g["r1"] == {"c1": 0, "c2": 0} or set(g["r1"]) == {"c1", "c2"}
+    assert g["r3"] == {}
+
+
+def test_wrappers_with_empty_inputs():
+    from isocon_amd import SW_alignment_module as SWM
+    from isocon_amd import edlib_alignment_module as EAM
+    assert EAM.edlib_align_sequences({"ACGT": []}) == {}
+    assert EAM.edlib_align_sequences_keeping_accession({}) == {}
+    assert SWM.sw_align_sequences({}) == {}
+    assert SWM.sw_align_sequences({"ACGT": {}}) == {}
+    assert SWM.sw_align_sequences_keeping_accession({"a": {}}) == {}
+
+
+def test_sw_tiny_and_asymmetric_lengths():
+    from isocon_amd import SW_alignment_module as SWM
+    from oracle import oracle as O
+    cases = [("A", "A"), ("A", "C"), ("A", "ACGTACGT"), ("ACGTACGT", "G"), ("ACGT" * 200, "ACGT"), ("AC", "ACGT" * 150)]
+    for s1, s2 in cases:
+        for mm in (-1, -4):
+            got = SWM.parasail_alignment(s1, s2, 0, 0, mismatch_penalty=mm)
+            assert got == O.parasail_alignment(s1, s2, 0, 0, mismatch_penalty=mm), (s1[:10], s2[:10], mm)
+
+
+def test_hit_list_overflow_restart_is_transparent():
+    """Many exact ties (identical distances everywhere) make the device hit list overflow its first capacity."""
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    base = "".join(rng.choice(list("ACGT"), 200))
+    seqs = []
+    for i in range(200):                     # every pair of these is at distance 2 (two distinct substitution sites)
+        s = list(base); s[i] = "A" if s[i] != "A" else "C"; seqs.append("".join(s))
+    seqs = sorted(set(seqs), key=len)
+    st = SeqStore(seqs)
+    best, rp, cols, stats = st.nn_graph()
+    row_ptr, c, e, _ = O.nn_1set(seqs, np.zeros(len(seqs), np.uint8), 0, len(seqs))
+    assert rp.tolist() == row_ptr.tolist() and cols.tolist() == c.tolist()
+    assert (best == 2).all()
