@@ -39,6 +39,8 @@ int isocon_init(int device_ordinal);
 const char *isocon_strerror(int status);
 const char *isocon_last_error(void);
 int isocon_device_count(void);
+/* Free the process-wide device scratch (trace buffers, hit lists ...) that calls keep for reuse. */
+void isocon_release_scratch(void);
 
 /*
  * Pack n sequences (ASCII, concatenated; sequence i = ascii[offsets[i] .. offsets[i+1])) into 2 bit-planes per
@@ -125,6 +127,18 @@ int isocon_sg_trace_batch(isocon_store *s, const uint32_t *a, const uint32_t *b,
                           const int8_t *mismatch_per_pair, int32_t open, int32_t ext, int32_t tie_policy,
                           uint32_t *out_ops, uint64_t *out_ops_ptr, uint64_t ops_cap, uint64_t *n_ops_needed,
                           int32_t *out_res, float *kernel_ms);
+
+/*
+ * Same as isocon_sg_trace_batch plus the two gapped strings per pair (what cigar_to_seq builds from the CIGAR in the
+ * reference, modules/SW_alignment_module.py:15-56,78): out_aln_a / out_aln_b hold, for pair p, the bytes
+ * [out_aln_ptr[p], out_aln_ptr[p+1]) = the aligned query / reference with '-' for gaps (equal lengths).
+ * ISOCON_E_CAPACITY + *n_aln_needed when aln_cap is too small.  Both sequences of every pair must be non-empty.
+ */
+int isocon_sg_strings_batch(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t match,
+                            const int8_t *mismatch_per_pair, int32_t open, int32_t ext, int32_t tie_policy,
+                            uint32_t *out_ops, uint64_t *out_ops_ptr, uint64_t ops_cap, uint64_t *n_ops_needed,
+                            int32_t *out_res, uint8_t *out_aln_a, uint8_t *out_aln_b, uint64_t *out_aln_ptr,
+                            uint64_t aln_cap, uint64_t *n_aln_needed, float *kernel_ms);
 
 #ifdef __cplusplus
 }

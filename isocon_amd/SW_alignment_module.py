@@ -70,20 +70,20 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0):
     """[(s1, s2)], per-pair mismatch penalties -> [(s1_aln, s2_aln, (matches, mismatches, indels))]."""
     if not pairs:
         return []
+    if any(len(s1) == 0 or len(s2) == 0 for s1, s2 in pairs):
+        raise ValueError("empty sequence in an alignment pair")
     seqs, a, b = _intern(pairs)
     st = SeqStore(seqs)
     try:
-        ops, ops_ptr, res = st.sg_trace(a, b, np.asarray(mismatch, dtype=np.int8), match=match_score, open_=opening_penalty,
-                                        ext=gap_ext, tie_policy=TIE_POLICY)
+        aln_a, aln_b, ptr, res = st.sg_strings(a, b, np.asarray(mismatch, dtype=np.int8), match=match_score, open_=opening_penalty,
+                                               ext=gap_ext, tie_policy=TIE_POLICY)
     finally:
         st.close()
-    ops = ops.tolist()
-    ops_ptr = ops_ptr.tolist()
-    out = []
-    for p, (s1, s2) in enumerate(pairs):
-        s1_aln, s2_aln = _ops_to_alignment(ops[ops_ptr[p]:ops_ptr[p + 1]], s1, s2)
-        out.append((s1_aln, s2_aln, (int(res[p, 3]), int(res[p, 4]), int(res[p, 5]))))
-    return out
+    aln_a = aln_a.decode("ascii")
+    aln_b = aln_b.decode("ascii")
+    ptr = ptr.tolist()
+    counts = res[:, 3:6].tolist()
+    return [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], tuple(counts[p])) for p in range(len(pairs))]
 
 
 def parasail_alignment(s1, s2, i, j, x_acc="", y_acc="", match_score=2, mismatch_penalty=-3, opening_penalty=2, gap_ext=0):

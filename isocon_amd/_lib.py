@@ -43,6 +43,7 @@ SYMBOLS = {
     "isocon_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "isocon_last_error": (ctypes.c_char_p, []),
     "isocon_device_count": (ctypes.c_int, []),
+    "isocon_release_scratch": (None, []),
     "isocon_store_create": (ctypes.c_int, [u8p, u64p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
     "isocon_store_destroy": (None, [ctypes.c_void_p]),
     "isocon_store_size": (ctypes.c_uint32, [ctypes.c_void_p]),
@@ -57,6 +58,9 @@ SYMBOLS = {
     "isocon_sg_trace_batch": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, ctypes.c_int32, i8p,
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, u32p, u64p, ctypes.c_uint64,
                                              u64p, i32p, f32p]),
+    "isocon_sg_strings_batch": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, ctypes.c_int32, i8p,
+                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, u32p, u64p, ctypes.c_uint64,
+                                               u64p, i32p, u8p, u8p, u64p, ctypes.c_uint64, u64p, f32p]),
 }
 
 _lib = None

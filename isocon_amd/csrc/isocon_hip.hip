@@ -48,12 +48,16 @@ struct ScratchPool {
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
     SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM,
-    SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND
+    SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB
 };
+
+// One pool per process (one process drives one GPU): scratch outlives the individual stores, because the Python
+// wrappers create a fresh store per call (the reference's functions are stateless).
+static ScratchPool g_scratch;
 
 struct isocon_store {
     DevStore dev;
-    ScratchPool pool;
+    ScratchPool &pool = g_scratch;
     std::vector<int32_t> lens;   // host copy
     uint64_t device_bytes = 0;
     uint64_t *d_planes = nullptr;
@@ -129,6 +133,8 @@ int isocon_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+void isocon_release_scratch(void) { g_scratch.release(); }
 
 int isocon_init(int device_ordinal)
 {
@@ -209,7 +215,6 @@ void isocon_store_destroy(isocon_store *s)
     if (!s) return;
     if (s->d_planes) (void)hipFree(s->d_planes);
     if (s->d_lens) (void)hipFree(s->d_lens);
-    s->pool.release();
     delete s;
 }
 

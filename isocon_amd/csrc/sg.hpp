@@ -270,6 +270,66 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     o[0] = score; o[1] = eq; o[2] = er; o[3] = nmatch; o[4] = nmis; o[5] = (int32_t)(alen - nmatch - nmis);
 }
 
+// Gapped strings (what cigar_to_seq builds in the reference, SW_alignment_module.py:15-56): one block per pair, one op
+// per thread (strided); '=' / 'X' copy both bases, 'I' = query base over '-', 'D' = '-' over ref base.
+__global__ __launch_bounds__(256) void k_sg_expand(DevStore S, const SgPair *__restrict__ pairs, const uint32_t *__restrict__ ops,
+                                                    const uint32_t *__restrict__ opcount, const uint64_t *__restrict__ aln_off,
+                                                    uint8_t *__restrict__ aln_a, uint8_t *__restrict__ aln_b, uint32_t n_pairs)
+{
+    __shared__ uint32_t s_pos[3];   // running (alignment column, query index, ref index) while thread 0 scans the ops
+    extern __shared__ uint32_t s_start[];   // per op: alignment column, query index, ref index (3 words)
+    const uint32_t p = blockIdx.x;
+    if (p >= n_pairs) return;
+    const SgPair pr = pairs[p];
+    const uint64_t cap = (uint64_t)S.lens[pr.a] + S.lens[pr.b] + 2;
+    const uint32_t cnt = opcount[p];
+    const uint32_t *po = ops + pr.ops_off + (cap - cnt);
+    const uint64_t base = aln_off[p];
+    const uint64_t *planes = S.planes;
+    const uint32_t nseq = S.n;
+    const char lut[4] = {'A', 'C', 'G', 'T'};
+    (void)s_pos;
+    // chunks of up to 1024 ops: thread 0 prefix-sums, then everyone expands
+    uint32_t col = 0, qi = 0, ri = 0;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 1024) {
+        const uint32_t kn = (cnt - k0) < 1024 ? (cnt - k0) : 1024;
+        if (threadIdx.x == 0) {
+            uint32_t c = col, q = qi, r = ri;
+            for (uint32_t k = 0; k < kn; ++k) {
+                const uint32_t op = po[k0 + k], len = op >> 4, code = op & 15u;
+                s_start[3 * k] = c; s_start[3 * k + 1] = q; s_start[3 * k + 2] = r;
+                c += len;
+                if (code != 3) q += len;
+                if (code != 2) r += len;
+            }
+            s_start[3 * kn] = c; s_start[3 * kn + 1] = q; s_start[3 * kn + 2] = r;
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < kn; k += 256) {
+            const uint32_t op = po[k0 + k], len = op >> 4, code = op & 15u;
+            const uint32_t c0 = s_start[3 * k], q0 = s_start[3 * k + 1], r0 = s_start[3 * k + 2];
+            for (uint32_t x = 0; x < len; ++x) {
+                char ca = '-', cb = '-';
+                if (code != 3) {
+                    const uint32_t i = q0 + x;
+                    const uint64_t lo = planes[((size_t)(i >> 6) * nseq + pr.a) * 2], hi = planes[((size_t)(i >> 6) * nseq + pr.a) * 2 + 1];
+                    ca = lut[((lo >> (i & 63)) & 1) | (((hi >> (i & 63)) & 1) << 1)];
+                }
+                if (code != 2) {
+                    const uint32_t j = r0 + x;
+                    const uint64_t lo = planes[((size_t)(j >> 6) * nseq + pr.b) * 2], hi = planes[((size_t)(j >> 6) * nseq + pr.b) * 2 + 1];
+                    cb = lut[((lo >> (j & 63)) & 1) | (((hi >> (j & 63)) & 1) << 1)];
+                }
+                aln_a[base + c0 + x] = (uint8_t)ca;
+                aln_b[base + c0 + x] = (uint8_t)cb;
+            }
+        }
+        __syncthreads();
+        col = s_start[3 * kn]; qi = s_start[3 * kn + 1]; ri = s_start[3 * kn + 2];
+        __syncthreads();
+    }
+}
+
 // dense copy of the right-aligned op regions
 __global__ __launch_bounds__(256) void k_sg_compact(const SgPair *__restrict__ pairs, const DevStore S,
                                                      const uint32_t *__restrict__ ops, const uint32_t *__restrict__ opcount,

@@ -133,6 +133,38 @@ class SeqStore(object):
             return out + (ms.value,) if return_ms else out
 
 
+def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0):
+    """Gapped strings straight from the device: returns (aln_a bytes, aln_b bytes, aln_ptr int64[n+1], res int32[n,6])."""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    n = len(a)
+    mm = np.ascontiguousarray(np.broadcast_to(np.asarray(mismatch, dtype=np.int8), (n,)))
+    res = np.zeros((max(n, 1), 6), dtype=np.int32)
+    ops_ptr = np.zeros(n + 1, dtype=np.uint64)
+    aln_ptr = np.zeros(n + 1, dtype=np.uint64)
+    ops_cap = max(64 * n, 1024)
+    aln_cap = int((self.lens[a] + self.lens[b]).sum() // 2 + 64 * n + 1024) if n else 1024
+    need_ops, need_aln = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    while True:
+        ops = np.empty(ops_cap, dtype=np.uint32)
+        aln_a = np.empty(aln_cap, dtype=np.uint8)
+        aln_b = np.empty(aln_cap, dtype=np.uint8)
+        rc = self._L.isocon_sg_strings_batch(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), n, match, _ptr(mm, _lib.i8p), open_, ext,
+                                             tie_policy, _ptr(ops, _lib.u32p), _ptr(ops_ptr, _lib.u64p), ops_cap, ctypes.byref(need_ops),
+                                             _ptr(res, _lib.i32p), _ptr(aln_a, _lib.u8p), _ptr(aln_b, _lib.u8p), _ptr(aln_ptr, _lib.u64p),
+                                             aln_cap, ctypes.byref(need_aln), None)
+        if rc == _lib.ISOCON_E_CAPACITY:
+            ops_cap = max(ops_cap, int(need_ops.value) + 16)
+            aln_cap = max(aln_cap, int(need_aln.value) + 16)
+            continue
+        _lib.check(rc, "isocon_sg_strings_batch")
+        end = int(aln_ptr[n])
+        return aln_a[:end].tobytes(), aln_b[:end].tobytes(), aln_ptr.astype(np.int64), res[:n]
+
+
+SeqStore.sg_strings = _sg_strings
+
+
 def nn_finalize(n, best, hits):
     """Host-side CSR assembly from reduced best[] and gathered hit triples (isocon_nn_finalize)."""
     L = _lib.load()
