@@ -173,7 +173,15 @@ __global__ __launch_bounds__(256) void k_ed_band_tiles(DevStore S, const uint32_
     const uint32_t tid = valid ? id : shared;
     const int32_t n = S.lens[tid];
     const int32_t k = valid ? lane_k[(size_t)wave * 64 + lane] : -1;
-    const int32_t r = band_tile_run<W>(S, shared, m, tid, n, k, valid, nullptr);
+    // lanes the common window could not certify (-2) are re-run among themselves (see nn_process_tile)
+    int32_t r = -1;
+    bool pending = valid;
+    for (int round = 0; round < 64; ++round) {
+        const int32_t rr = band_tile_run<W>(S, shared, m, tid, n, k, pending, nullptr);
+        if (pending) r = rr;
+        pending = pending && rr == -2;
+        if (__ballot(pending) == 0) break;
+    }
     out[(size_t)wave * 64 + lane] = r;
 }
 

@@ -1,6 +1,7 @@
 // isocon_hip.hip -- C ABI of libisocon_hip.so (see include/isocon_hip.h).  Host orchestration + kernel launches.
 // gfx950 only.  One process drives one GPU (isocon_init selects it).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

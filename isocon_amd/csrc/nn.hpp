@@ -68,12 +68,22 @@ __device__ __forceinline__ void nn_process_tile(const DevStore &S, const NNParam
     if (upd_l) { const int32_t bl = load_relaxed_agent(P.best + tid); kl = bl < n_t ? bl : n_t; }
     int32_t k = ks > kl ? ks : kl;
     if (k > P.kcap) k = P.kcap;
-    TileStats st;
-    const int32_t r = band_tile_run<W, LDS>(S, s, m, tid, n_t, k, valid && k >= 0, &st, tab);
-    acc.pairs += st.lanes_run;
-    acc.cols += (unsigned long long)st.lanes_run * st.cols;
+    // A tile whose lanes differ much in length cannot certify every lane with ONE common window (result -2 for
+    // the lanes with the smaller |length difference|).  Those lanes are simply run again among themselves: the lane
+    // that fixes the window origin is always certified, so every round retires at least one lane.
+    int32_t r = -1;
+    bool pending = valid && k >= 0;
+    for (int round = 0; round < 64; ++round) {
+        TileStats st;
+        const int32_t rr = band_tile_run<W, LDS>(S, s, m, tid, n_t, k, pending, &st, tab);
+        acc.pairs += round == 0 ? st.lanes_run : 0;
+        acc.cols += (unsigned long long)st.lanes_run * st.cols;
+        acc.live += st.live_cols;
+        if (pending) r = rr;
+        pending = pending && rr == -2;
+        if (__ballot(pending) == 0) break;
+    }
     acc.tiles += 1;
-    acc.live += st.live_cols;
     bool hit_s = false, hit_l = false;
     if (r >= P.min_d) {
         if (upd_s && r <= m) { const int32_t old = atomicMin(P.best + s, r); hit_s = r <= old; }
