@@ -202,10 +202,10 @@ def main():
     def step():
         if world == 1:
             best, row_ptr, cols, stats = store.nn_graph()
-            last.update(best=best, edges=len(cols), stats=[stats])
+            last.update(best=best, edges=len(cols), stats=[stats], row_ptr=row_ptr, cols=cols)
         else:
             best, row_ptr, cols, stats = sharded_nn_graph(store, dist=dist, return_stats=True)
-            last.update(best=best, edges=len(cols), stats=stats)
+            last.update(best=best, edges=len(cols), stats=stats, row_ptr=row_ptr, cols=cols)
 
     for _ in range(args.warmup):
         step()
@@ -259,6 +259,26 @@ def main():
                    "parallelism": "1 process/GPU; pairs sharded by lower index; all_reduce(MIN)+all_gather over RCCL" if world > 1 else "single GPU"},
         "roofline": roofline,
     }
+    # not part of the timed region: the other two kernels of the path on (read, first NN) pairs of the same set
+    try:
+        if world == 1:
+            row_ptr = last["row_ptr"]
+            has = np.nonzero(row_ptr[1:] > row_ptr[:-1])[0]
+            q = has[:: max(1, len(has) // 4096)][:4096]
+            t = last["cols"][row_ptr[q]]
+            t0 = time.perf_counter(); ed, ed_ms = store.ed_pairs(t, q, None, return_ms=True); ed_wall = time.perf_counter() - t0
+            mm = np.full(len(q), -2, dtype=np.int8)
+            store.sg_trace(t[:64], q[:64], mm[:64])
+            t0 = time.perf_counter(); ops, ptr, res, sw_ms = store.sg_trace(t, q, mm, return_ms=True); sw_wall = time.perf_counter() - t0
+            cells = float((lens[t] * lens[q]).sum())
+            result["other_kernels"] = {
+                "pairs": int(len(q)),
+                "ed_pairs_per_s_kernel": len(q) / (ed_ms / 1e3) if ed_ms > 0 else None, "ed_pairs_wall_ms": ed_wall * 1e3,
+                "sw_pairs_per_s_kernel": len(q) / (sw_ms / 1e3) if sw_ms > 0 else None, "sw_wall_ms": sw_wall * 1e3,
+                "sw_cell_updates_per_s": cells / (sw_ms / 1e3) if sw_ms > 0 else None,
+                "sw_trace_hbm_write_GBps": (cells / 2) / (sw_ms / 1e3) / 1e9 if sw_ms > 0 else None}
+    except Exception as e:  # the headline line must still be printed
+        result["other_kernels"] = {"error": repr(e)}
     if cpu is not None:
         result["cpu_baseline"] = cpu
         result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"] if result["cpu_baseline"]["value"] else None
