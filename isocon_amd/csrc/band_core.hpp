@@ -40,6 +40,19 @@ ISO_HD int popc64(uint64_t x)
 #endif
 }
 
+// a | ~(b | c) on 64 bits.  gfx950 has V_BITOP3_B32 (arbitrary 3-input boolean, truth table = f(0xF0, 0xCC, 0xAA)):
+// one 4-cycle-class instruction per 32-bit half instead of v_or + v_bfi.
+ISO_HD uint64_t or_nor(uint64_t a, uint64_t b, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0xF1);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0xF1);
+    return ((uint64_t)hi << 32) | lo;
+#else
+    return a | ~(b | c);
+#endif
+}
+
 // Geometry of one lane inside a tile whose band origin is a0 (<= 0) and whose window has 64*W rows.
 struct LaneGeom {
     int32_t k_eff;   // largest threshold this lane can certify with the tile's window (-1: none)
@@ -115,14 +128,14 @@ ISO_HD void band_step(BandLane<W> &L, const uint64_t (&NL)[W], const uint64_t (&
         uint64_t c = s < x;
         if (W > 1) { const uint64_t s2 = s + carry; c |= (s2 < s); s = s2; carry = c; }
         D0[i] = (s ^ vp) | eq | vn;
-        HP[i] = vn | ~(D0[i] | vp);
+        HP[i] = or_nor(vn, D0[i], vp);
         HN[i] = D0[i] & vp;
     }
     L.ztop += (uint32_t)D0[0] & 1u;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
         const uint64_t d0s = (D0[i] >> 1) | ((i + 1 < W) ? (D0[(i + 1 < W) ? i + 1 : i] << 63) : 0);
-        L.VP[i] = HN[i] | ~(d0s | HP[i]);
+        L.VP[i] = or_nor(HN[i], d0s, HP[i]);
         L.VN[i] = d0s & HP[i];
     }
 }
