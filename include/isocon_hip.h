@@ -103,8 +103,9 @@ int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t 
  * modules/nearest_neighbor_graph.py:33-35).  best_inout[n] is IN/OUT (0x3fffffff = no neighbour known yet).
  *   phase 0: 64-row band over every admissible pair whose LOWER index (1-set) / whose query (2-set) lies in
  *            [q_begin, q_end).  Pass best_inout all 0x3fffffff.
- *   phase 1: wide bands / un-banded kernel for the owned queries in [q_begin, q_end) that are still unresolved
- *            in best_inout (which must be the element-wise MIN over all ranks' phase-0 results).
+ *   phase 1: 128/256/512-row bands over the pairs whose lower index lies in [q_begin, q_end) and that involve an entry
+ *            still unresolved in best_inout (which must be the element-wise MIN over all ranks' phase-0 results),
+ *            then the un-banded kernel for the owned queries whose neighbour is further than 511 edits.
  * Each call returns up to hits_cap candidate edges (endpoint, neighbour, distance) as int32 triples.  The caller
  * min-reduces best over ranks after each phase, all-gathers the triples and calls isocon_nn_finalize.
  */

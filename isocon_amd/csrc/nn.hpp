@@ -105,8 +105,11 @@ __device__ __forceinline__ void nn_flush_acc(const NNParams &P, const WaveAcc &a
     }
 }
 
-// Implicit upward scan (64-row band): shared entry q against q+1+64*tile+lane for tile in [tile_begin, tile_end),
-// while the length difference stays within kcap.  wpq waves cooperate on one q (wpq in {1,2,4}).
+// Implicit upward scan (64*W-row band, scalar-unit window): shared entry q against q+1+64*tile+lane for tile in
+// [tile_begin, tile_end), while the length difference stays within kcap.  wpq waves cooperate on one q (1, 2 or 4).
+// W = 1: seed pass.  W = 2, 4, 8: the wide-band phase -- only entries flagged as (still unresolved) queries make a
+// pair active, every other tile is skipped after its role/threshold loads.
+template <int W>
 __global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint32_t q_begin, uint32_t q_end,
                                                      int32_t tile_begin, int32_t tile_end, int32_t wpq)
 {
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint
             if (S.lens[t0] - m > P.kcap) break;       // lengths ascend: nothing further can be within kcap
             int64_t p = t0 + lane;
             if (p - (int64_t)q > (int64_t)P.depth) p = -1;
-            nn_process_tile<1>(S, P, q, m, q_isq, q_ist, p, acc);
+            nn_process_tile<W>(S, P, q, m, q_isq, q_ist, p, acc);
         }
     }
     nn_flush_acc(P, acc);

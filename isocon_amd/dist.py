@@ -2,7 +2,9 @@
 
 The packed sequence set is replicated on every GPU (31 MB for 50 k x 2.5 kb).  The 1-set search evaluates each
 unordered pair once, on the rank that owns the pair's LOWER index; ranks own contiguous index ranges balanced by
-estimated work.  Exchange steps (the only data-path collectives):
+estimated work.  Phase 0 = 64-row band over all admissible pairs; phase 1 = 128/256/512-row bands (same ownership
+rule, only entries still unresolved after the min-reduction act as queries) and the un-banded kernel for the owned
+queries whose neighbour is further than 511 edits.  Exchange steps (the only data-path collectives):
     all_reduce(MIN) of best[n]   after the 64-row band phase and after the wide-band phase   (4 B x n)
     all_gather of the candidate edges that attain best[] on their rank                         (12 B x edges)
 The reference has no distributed path (its Pool chunking: /root/reference/modules/nearest_neighbor_graph.py:33-35).
