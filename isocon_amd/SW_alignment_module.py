@@ -10,8 +10,7 @@ import sys
 
 import numpy as np
 
-from .edlib_alignment_module import _intern
-from .store import SeqStore
+from .store import store_for_pairs
 
 TIE_POLICY = 0
 _OPS = "=XID"
@@ -72,13 +71,13 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0):
         return []
     if any(len(s1) == 0 or len(s2) == 0 for s1, s2 in pairs):
         raise ValueError("empty sequence in an alignment pair")
-    seqs, a, b = _intern(pairs)
-    st = SeqStore(seqs)
+    st, a, b, owned = store_for_pairs(pairs)
     try:
         aln_a, aln_b, ptr, res = st.sg_strings(a, b, np.asarray(mismatch, dtype=np.int8), match=match_score, open_=opening_penalty,
                                                ext=gap_ext, tie_policy=TIE_POLICY)
     finally:
-        st.close()
+        if owned:
+            st.close()
     aln_a = aln_a.decode("ascii")
     aln_b = aln_b.decode("ascii")
     ptr = ptr.tolist()

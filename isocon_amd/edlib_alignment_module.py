@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .store import SeqStore
+from .store import SeqStore, store_for_pairs
 
 
 def _intern(pairs):
@@ -31,12 +31,12 @@ def _intern(pairs):
 def _distances(pairs):
     if not pairs:
         return np.zeros(0, dtype=np.int32)
-    seqs, a, b = _intern(pairs)
-    st = SeqStore(seqs)
+    st, a, b, owned = store_for_pairs(pairs)
     try:
         ed = st.ed_pairs(a, b, None)
     finally:
-        st.close()
+        if owned:
+            st.close()
     assert (ed >= 0).all()  # EAM:113
     return ed
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .store import SeqStore
+from .store import SeqStore, remember
 
 LAST_STATS = {}  # statistics block of the most recent device call (bench / tests)
 
@@ -34,8 +34,10 @@ def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
     st = SeqStore(seqs)
     try:
         best, row_ptr, cols, stats = st.nn_graph(is_converged=conv, depth=depth)
-    finally:
+    except Exception:
         st.close()
+        raise
+    remember(st, seqs)      # EAM / SWM are called next on pairs of these very sequences
     LAST_STATS.clear()
     LAST_STATS.update(stats)
     # every entry gets a key; converged ones an empty dict (NNG:120-123)

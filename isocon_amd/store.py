@@ -181,20 +181,51 @@ def nn_finalize(n, best, hits):
     return out_best[:n], row_ptr.astype(np.int64), cols[:int(row_ptr[n])]
 
 
-# small cache: the reference's callers hand the same sequence set to NNG, EAM and SWM within one iteration
-_CACHE = OrderedDict()
-_CACHE_SIZE = 2
+# The reference's callers hand the SAME sequence set to NNG, then EAM, then SWM within one correction iteration
+# (isocon_get_candidates.py:129-130,38,47).  The most recent store is kept (with a sequence -> id index) so the pair-list
+# wrappers can address it instead of packing and uploading the strings again.
+_RECENT = {"store": None, "index": None}
 
 
-def store_for(seqs) -> SeqStore:
-    key = tuple(seqs)
-    st = _CACHE.get(key)
-    if st is None:
-        st = SeqStore(key)
-        _CACHE[key] = st
-        while len(_CACHE) > _CACHE_SIZE:
-            _, old = _CACHE.popitem(last=False)
-            old.close()
-    else:
-        _CACHE.move_to_end(key)
-    return st
+def remember(store, seqs):
+    old = _RECENT["store"]
+    if old is not None and old is not store:
+        old.close()
+    _RECENT["store"] = store
+    _RECENT["index"] = {s: i for i, s in enumerate(seqs)}
+
+
+def forget():
+    if _RECENT["store"] is not None:
+        _RECENT["store"].close()
+    _RECENT["store"] = None
+    _RECENT["index"] = None
+
+
+def store_for_pairs(pairs):
+    """[(x, y), ...] -> (store, a ids, b ids, owned).  Reuses the remembered store when it holds every sequence of the
+    pair list; otherwise packs a private one (owned = True: the caller closes it)."""
+    index = _RECENT["index"]
+    n = len(pairs)
+    a = np.empty(n, dtype=np.uint32)
+    b = np.empty(n, dtype=np.uint32)
+    if index is not None and _RECENT["store"] is not None and getattr(_RECENT["store"], "_h", None):
+        try:
+            for p, (x, y) in enumerate(pairs):
+                a[p] = index[x]
+                b[p] = index[y]
+            return _RECENT["store"], a, b, False
+        except KeyError:
+            pass
+    index, seqs = {}, []
+    for p, (x, y) in enumerate(pairs):
+        ia = index.get(x)
+        if ia is None:
+            ia = index[x] = len(seqs)
+            seqs.append(x)
+        ib = index.get(y)
+        if ib is None:
+            ib = index[y] = len(seqs)
+            seqs.append(y)
+        a[p], b[p] = ia, ib
+    return SeqStore(seqs), a, b, True
