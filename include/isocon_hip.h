@@ -141,6 +141,15 @@ int isocon_sg_strings_batch(isocon_store *s, const uint32_t *a, const uint32_t *
                             int32_t *out_res, uint8_t *out_aln_a, uint8_t *out_aln_b, uint64_t *out_aln_ptr,
                             uint64_t aln_cap, uint64_t *n_aln_needed, float *kernel_ms);
 
+/*
+ * Exon-difference filter on CIGAR ops (host-only helper, no GPU): out_flag[p] = 1 iff filter_exon_differences
+ * (modules/functions.py:23-50, mask rule :218-236) would drop the pair, i.e. one of the gapped strings has a run of
+ * >= min_exon_diff gaps inside the window that excludes min(ignore_ends_len, end-gap) columns at either end.
+ * ops / ops_ptr as returned by isocon_sg_trace_batch.
+ */
+int isocon_exon_filter_from_ops(const uint32_t *ops, const uint64_t *ops_ptr, uint64_t n_pairs, int32_t min_exon_diff,
+                                int32_t ignore_ends_len, uint8_t *out_flag);
+
 #ifdef __cplusplus
 }
 #endif

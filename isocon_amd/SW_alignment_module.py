@@ -14,6 +14,9 @@ from .store import store_for_pairs
 
 TIE_POLICY = 0
 _OPS = "=XID"
+# id(result tuple) -> (the tuple, its CIGAR ops as uint32 array) for the alignments of the most recent batch call; lets
+# isocon_amd.functions.filter_exon_differences work on run-length ops instead of re-scanning the gapped strings.
+_OPS_CACHE = {}
 
 
 def cigar_to_seq(cigar, query, ref):
@@ -73,8 +76,9 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0):
         raise ValueError("empty sequence in an alignment pair")
     st, a, b, owned = store_for_pairs(pairs)
     try:
-        aln_a, aln_b, ptr, res = st.sg_strings(a, b, np.asarray(mismatch, dtype=np.int8), match=match_score, open_=opening_penalty,
-                                               ext=gap_ext, tie_policy=TIE_POLICY)
+        aln_a, aln_b, ptr, res, ops, ops_ptr = st.sg_strings(a, b, np.asarray(mismatch, dtype=np.int8), match=match_score,
+                                                             open_=opening_penalty, ext=gap_ext, tie_policy=TIE_POLICY,
+                                                             return_ops=True)
     finally:
         if owned:
             st.close()
@@ -82,7 +86,12 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0):
     aln_b = aln_b.decode("ascii")
     ptr = ptr.tolist()
     counts = res[:, 3:6].tolist()
-    return [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], tuple(counts[p])) for p in range(len(pairs))]
+    out = [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], tuple(counts[p])) for p in range(len(pairs))]
+    _OPS_CACHE.clear()
+    op = ops_ptr.tolist()
+    for p, t in enumerate(out):
+        _OPS_CACHE[id(t)] = (t, ops[op[p]:op[p + 1]])
+    return out
 
 
 def parasail_alignment(s1, s2, i, j, x_acc="", y_acc="", match_score=2, mismatch_penalty=-3, opening_penalty=2, gap_ext=0):

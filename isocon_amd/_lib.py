@@ -61,6 +61,7 @@ SYMBOLS = {
     "isocon_sg_strings_batch": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, ctypes.c_int32, i8p,
                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, u32p, u64p, ctypes.c_uint64,
                                                u64p, i32p, u8p, u8p, u64p, ctypes.c_uint64, u64p, f32p]),
+    "isocon_exon_filter_from_ops": (ctypes.c_int, [u32p, u64p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, u8p]),
 }
 
 _lib = None

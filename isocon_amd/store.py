@@ -133,7 +133,7 @@ class SeqStore(object):
             return out + (ms.value,) if return_ms else out
 
 
-def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0):
+def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ops=False):
     """Gapped strings straight from the device: returns (aln_a bytes, aln_b bytes, aln_ptr int64[n+1], res int32[n,6])."""
     a = np.ascontiguousarray(a, dtype=np.uint32)
     b = np.ascontiguousarray(b, dtype=np.uint32)
@@ -159,7 +159,10 @@ def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0):
             continue
         _lib.check(rc, "isocon_sg_strings_batch")
         end = int(aln_ptr[n])
-        return aln_a[:end].tobytes(), aln_b[:end].tobytes(), aln_ptr.astype(np.int64), res[:n]
+        out = (aln_a[:end].tobytes(), aln_b[:end].tobytes(), aln_ptr.astype(np.int64), res[:n])
+        if return_ops:
+            out = out + (ops[:int(ops_ptr[n])].copy(), ops_ptr.astype(np.int64))
+        return out
 
 
 SeqStore.sg_strings = _sg_strings

@@ -40,6 +40,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     from modules import edlib_alignment_module as R_EAM  # noqa: E402
     from modules import SW_alignment_module as R_SWM  # noqa: E402
     from modules import get_best_alignments as R_GBA  # noqa: E402
+    from modules import functions as R_FUN  # noqa: E402
 
 
 class Params(object):
@@ -249,6 +250,24 @@ def main():
     gba["expected_2set"] = [[k1, [[k2, list(v)] for k2, v in inner.items()]]
                             for k1, inner in quiet(R_GBA.find_best_matches_2set, paf, X, Cg, Params(1)).items()]
     dump("gba_best_matches.json", gba)
+
+    # ---- G6: functions.filter_exon_differences on SW outputs with exon-sized / end gaps
+    gene = "".join(rng.choice("ACGT") for _ in range(420))
+    variants = [gene[:150] + gene[190:],                 # 40-base internal gap
+                gene[:150] + gene[168:],                 # 18-base internal gap (< 20)
+                gene[25:], gene[:-30],                   # end gaps longer than ignore_ends_len
+                gene[8:], gene[:-6],                     # short end gaps
+                gene[:60] + gene[81:300] + gene[322:],   # two gaps of 21 and 22
+                "".join(rng.choice("ACGT") for _ in range(30)) + gene]   # query-side leading gap
+    ed_in = {gene: {v: O.ed_dp(gene, v) for v in variants}, variants[0]: {gene: O.ed_dp(gene, variants[0])}}
+    aligned = quiet(R_SWM.sw_align_sequences, ed_in, nr_cores=1)
+    g6 = dict(alignments=[[k1, [[k2, [v[0], v[1], list(v[2])]] for k2, v in inner.items()]] for k1, inner in aligned.items()], cases=[])
+    for (mn, ig) in ((20, 15), (20, 0), (5, 3), (41, 15), (40, 15), (19, 30)):
+        work = {k1: dict(inner) for k1, inner in aligned.items()}
+        filtered = quiet(R_FUN.filter_exon_differences, work, mn, ig)
+        g6["cases"].append(dict(min_exon_diff=mn, ignore_ends_len=ig, filtered=sorted(filtered),
+                                remaining=[[k1, list(inner.keys())] for k1, inner in work.items()]))
+    dump("g6_exon_filter.json", g6)
 
 
 if __name__ == "__main__":
