@@ -15,9 +15,16 @@
 
 namespace isocon {
 
-// trace nibble: bits 0-1 = source of H (0 diagonal/match, 3 diagonal/mismatch, 1 F = vertical gap = consumes a
-// query base = 'I', 2 E = horizontal gap = consumes a ref base = 'D'); bit 2: E came from E (extend); bit 3: F from F.
-static constexpr uint32_t SG_SRC_DIAG_EQ = 0, SG_SRC_F = 1, SG_SRC_E = 2, SG_SRC_DIAG_X = 3, SG_E_EXT = 4, SG_F_EXT = 8;
+// trace nibble = four raw decision bits, each the SIGN BIT of a score difference (no compare / select instructions:
+// on gfx950 `v_cmp` + `v_cndmask ... vcc` pairs cost an order of magnitude more than the arithmetic, scripts/ubench):
+//   bit 3  F opened  (F[i][j] = H[i-1][j] - open  rather than F[i-1][j] - ext)
+//   bit 2  E opened  (E[i][j] = H[i][j-1] - open  rather than E[i][j-1] - ext)
+//   bit 1  H came from a gap (else from the diagonal)
+//   bit 0  gap: 1 = E (horizontal, consumes a ref base, 'D'), 0 = F (vertical, consumes a query base, 'I');
+//          diagonal: 1 = mismatch, 0 = match
+// The tie policies only shift the differences by 0 or 1 (wave-uniform constants), so one kernel serves all of them.
+// A lane's 8 nibbles of one column form one dword, row r in bits [31-4r, 28-4r].
+static constexpr uint32_t SG_BIT_FOPEN = 8, SG_BIT_EOPEN = 4, SG_BIT_GAP = 2, SG_BIT_X = 1;
 static constexpr int32_t SG_NEG = -(1 << 28);
 
 // tie policy bits, identical to oracle/isocon_oracle.c
@@ -49,12 +56,15 @@ __device__ __forceinline__ uint64_t plane_bits64(const uint64_t *planes, uint32_
 // pass.  The bottom row (H, F) of a pass is parked in `bound` (one int2 per column) and read back by lane 0 of the
 // next pass.  Trace layout: code of cell (i, j) lives at  ((pass*steps + j + l) * 64 + l) * R/2 + r/2,
 // pass = i / (64R), l = (i % (64R)) / R, r = i % R, steps = n + 63.
-template <int R, bool GENERAL>
+// POL0: the three cell-level tie rules are parasail's (policy bits 0, 1, 4 clear); EXT0: gap extension costs 0
+// (the reference's alignment call, SW_alignment_module.py:64).  Both are compile-time so the common case drops the
+// corresponding subtractions.
+template <int R, bool POL0, bool EXT0>
 __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *__restrict__ pairs, SgParams prm,
                                                     uint8_t *__restrict__ trace, int2 *__restrict__ bound_all,
                                                     int32_t *__restrict__ endinfo)
 {
-    static_assert(R == 8 || R == 16, "strip height");
+    static_assert(R == 8, "strip height (one trace dword per lane and column)");
     const uint32_t pidx = blockIdx.x;
     const int lane = threadIdx.x;
     const SgPair pr = pairs[pidx];
@@ -62,6 +72,20 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
     const int32_t m = uniform_i32(S.lens[ia]), n = uniform_i32(S.lens[ib]);
     const int32_t match = prm.match, mism = uniform_i32(pr.mismatch), open = prm.open, ext = prm.ext;
     const int32_t policy = prm.policy;
+    // tie policies as 0/1 offsets on the differences whose sign bits become the trace (see the nibble comment)
+    const int32_t c_open = (policy & SG_POL_OPEN_ON_TIE) ? 1 : 0;   // opened iff open-value >  ext-value (default) / >= (tie -> open)
+    const int32_t c_gap = (policy & SG_POL_GAP_FIRST) ? 1 : 0;      // gap iff diag <  best gap (default) / <=
+    const int32_t c_ef = (policy & SG_POL_E_BEFORE_F) ? 1 : 0;      // E iff F < E (default) / F <= E
+    // The per-cell constants live in VGPRs on purpose: a VALU instruction with an SGPR operand issues in ~4.2 cycles
+    // on gfx950, the same instruction on VGPR operands in ~2.3 (scripts/ubench/valu_rate2.hip).
+    int32_t open_v, ext_v, mism_v, delta_v, c_open_v, c_gap_v, c_ef_v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(open_v) : "s"(open));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ext_v) : "s"(ext));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(mism_v) : "s"(mism));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(delta_v) : "s"(match - mism));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c_open_v) : "s"(c_open));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c_gap_v) : "s"(c_gap));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c_ef_v) : "s"(c_ef));
     const uint64_t *planes = S.planes;
     const uint32_t nseq = S.n;
     const int32_t nchunks = (int32_t)S.nchunks;
@@ -86,26 +110,41 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
         int32_t diag_in = 0;     // H[row0-1][j-1]
         int32_t sendH = 0, sendFC = SG_NEG * 4;
         uint64_t tlo = 0, thi = 0;
+        int32_t bndH = 0, bndF = SG_NEG;   // lane l: boundary (H, F) of column 64*(s/64) + l
         const bool lane_has_rows = row0 < m;
 #pragma unroll 1
         for (int32_t s = 0; s < steps; ++s) {
             if ((s & 63) == 0) {   // wave-uniform: next 64 ref bases
                 const int32_t tc = s >> 6;
-                if (tc < nchunks) { tlo = planes[((size_t)tc * nseq + ib) * 2]; thi = planes[((size_t)tc * nseq + ib) * 2 + 1]; }
-                else { tlo = 0; thi = 0; }
+                uint64_t a = 0, b = 0;
+                if (tc < nchunks) { a = planes[((size_t)tc * nseq + ib) * 2]; b = planes[((size_t)tc * nseq + ib) * 2 + 1]; }
+                // into SGPRs right here: a vector load whose result is first read many steps later would otherwise
+                // put an `s_waitcnt vmcnt(0)` (which also waits for the trace stores in flight) into every step
+                tlo = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)a);
+                thi = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)b);
+            }
+            if (pass > 0 && (s & 63) == 0) {
+                // bottom row of the previous pass for the next 64 columns: one coalesced, L1-bypassing load per lane
+                // (the values were written by lane 63 of this very wave); lane 0 picks its column by readlane below
+                const int32_t col = s + lane;
+                if (col < n) {
+                    const int32_t *bp = reinterpret_cast<const int32_t *>(bound + col);
+                    bndH = __hip_atomic_load(bp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bndF = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else { bndH = 0; bndF = SG_NEG; }
+                // consume the loads HERE: otherwise the compiler parks an `s_waitcnt vmcnt(0)` in front of the
+                // readlanes of EVERY step, which also waits for the trace stores in flight (vmcnt counts stores) and
+                // serialises each step on the HBM write latency.
+                asm volatile("" : "+v"(bndH), "+v"(bndF));
             }
             int32_t Hup = __shfl_up(sendH, 1, 64);
             const int32_t FC = __shfl_up(sendFC, 1, 64);
             int32_t Fup, ch;
+            const int32_t b_h = __builtin_amdgcn_readlane(bndH, s & 63), b_f = __builtin_amdgcn_readlane(bndF, s & 63);
             if (lane == 0) {
                 ch = (int32_t)(((tlo >> (s & 63)) & 1) | (((thi >> (s & 63)) & 1) << 1));
                 if (pass == 0 || s >= n) { Hup = 0; Fup = SG_NEG; }
-                else {
-                    // bottom row of the previous pass; bypass this CU's L1 (written by lane 63 of this very wave)
-                    const int32_t *bp = reinterpret_cast<const int32_t *>(bound + s);
-                    Hup = __hip_atomic_load(bp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    Fup = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                else { Hup = b_h; Fup = b_f; }
             } else {
                 Fup = FC >> 2;
                 ch = FC & 3;
@@ -117,61 +156,70 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
                 const uint64_t slo = (ch & 1) ? ~(uint64_t)0 : 0, shi = (ch & 2) ? ~(uint64_t)0 : 0;
                 const uint32_t eq = (uint32_t)(~(qlo ^ slo) & ~(qhi ^ shi));
                 int32_t diag = (j == 0) ? 0 : diag_in;   // left boundary column: H[.][-1] = 0
-                uint32_t tw[R / 8];
+                uint32_t tw = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int32_t Hl = Hp[r], El = Ep[r];
-                    const int32_t Fopn = Hup - open, Fext = Fup - ext;
-                    const int32_t Eopn = Hl - open, Eext = El - ext;
-                    bool fext, eext;
-                    if (GENERAL && (policy & SG_POL_OPEN_ON_TIE)) { fext = Fopn < Fext; eext = Eopn < Eext; }
-                    else { fext = Fopn <= Fext; eext = Eopn <= Eext; }
+                    const int32_t Fopn = Hup - open_v, Fext = EXT0 ? Fup : Fup - ext_v;
+                    const int32_t Eopn = Hl - open_v, Eext = EXT0 ? El : El - ext_v;
                     const int32_t Fv = Fopn > Fext ? Fopn : Fext;
                     const int32_t Ev = Eopn > Eext ? Eopn : Eext;
-                    const uint32_t eqbit = (eq >> r) & 1u;
-                    const int32_t Hd = diag + (eqbit ? match : mism);
-                    const int32_t g = Fv > Ev ? Fv : Ev;
-                    const int32_t Hv = Hd > g ? Hd : g;
-                    const uint32_t dcode = eqbit ? SG_SRC_DIAG_EQ : SG_SRC_DIAG_X;
-                    uint32_t src;
-                    if (!GENERAL) {
-                        src = (Hd >= g) ? dcode : ((Fv >= Ev) ? SG_SRC_F : SG_SRC_E);
+                    const int32_t e = __builtin_amdgcn_sbfe((int32_t)eq, r, 1);        // -1 where the bases are equal
+                    const int32_t Hd = diag + mism_v + (e & delta_v);
+                    int32_t Hv, t_f, t_e, t_g, t_x;                                    // decisions = sign bits
+                    if (POL0) {
+                        const int32_t g = Fv > Ev ? Fv : Ev;
+                        Hv = Hd > g ? Hd : g;                   // (one v_max3)
+                        t_f = Fext - Fopn;                      // < 0 : F opened
+                        t_e = Eext - Eopn;                      // < 0 : E opened
+                        t_g = Hd - Hv;                          // < 0 : H came from a gap
+                        t_x = Fv - Ev;                          // < 0 : E rather than F
                     } else {
-                        const bool gap_first = (policy & SG_POL_GAP_FIRST) != 0, e_first = (policy & SG_POL_E_BEFORE_F) != 0;
-                        const bool isD = Hd == Hv, isF = Fv == Hv, isE = Ev == Hv;
-                        if (!gap_first && isD) src = dcode;
-                        else if (e_first) src = isE ? SG_SRC_E : (isF ? SG_SRC_F : dcode);
-                        else src = isF ? SG_SRC_F : (isE ? SG_SRC_E : dcode);
+                        const int32_t g = Fv > Ev ? Fv : Ev;
+                        Hv = Hd > g ? Hd : g;
+                        t_f = Fext - Fopn - c_open_v;
+                        t_e = Eext - Eopn - c_open_v;
+                        t_g = Hd - g - c_gap_v;
+                        t_x = Fv - Ev - c_ef_v;
                     }
-                    const uint32_t nib = src | (eext ? SG_E_EXT : 0u) | (fext ? SG_F_EXT : 0u);
-                    if ((r & 7) == 0) tw[r >> 3] = nib; else tw[r >> 3] |= nib << (4 * (r & 7));
+                    // bit 0: gap ? t_x : mismatch (= ~e)   ->  (a & b) | (~a & ~c), truth table 0xC5
+                    const uint32_t x = __builtin_amdgcn_bitop3_b32((uint32_t)t_g, (uint32_t)t_x, (uint32_t)e, 0xC5);
+                    tw = __builtin_amdgcn_alignbit(tw, (uint32_t)t_f, 31);
+                    tw = __builtin_amdgcn_alignbit(tw, (uint32_t)t_e, 31);
+                    tw = __builtin_amdgcn_alignbit(tw, (uint32_t)t_g, 31);
+                    tw = __builtin_amdgcn_alignbit(tw, x, 31);
                     diag = Hl;
                     Hp[r] = Hv;
                     Ep[r] = Ev;
                     Hup = Hv;
                     Fup = Fv;
                 }
-                // end-cell candidates: last query row (one lane of one pass), last ref column (every lane, once)
-                if (pass == pstar && lane == lstar) {
+                // end-cell candidates.  Both guards are WAVE-UNIFORM on purpose (scalar branches): left to itself the
+                // compiler if-converts these blocks into ~180 predicated instructions that run on every step.
+                if (pass == pstar) {                      // last query row: lane lstar, row rstar of this pass
+                    // (a select chain on the uniform rstar: indexing Hp[] dynamically would demote it to scratch)
                     int32_t hv = Hp[0];
 #pragma unroll
                     for (int r = 1; r < R; ++r) hv = (r == rstar) ? Hp[r] : hv;
-                    if (hv > rowbest) { rowbest = hv; rowj_first = j; rowj_last = j; }
-                    else if (hv == rowbest) rowj_last = j;
+                    if (lane == lstar) {
+                        if (hv > rowbest) { rowbest = hv; rowj_first = j; rowj_last = j; }
+                        else if (hv == rowbest) rowj_last = j;
+                    }
                 }
-                if (j == n - 1) {
+                if (s >= n - 1) {                         // only then can some lane sit on the last ref column
+                    if (j == n - 1) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (row0 + r < m) {
-                            if (Hp[r] > colbest) { colbest = Hp[r]; coli_first = row0 + r; coli_last = row0 + r; }
-                            else if (Hp[r] == colbest) coli_last = row0 + r;
+                        for (int r = 0; r < R; ++r) {
+                            if (row0 + r < m) {
+                                if (Hp[r] > colbest) { colbest = Hp[r]; coli_first = row0 + r; coli_last = row0 + r; }
+                                else if (Hp[r] == colbest) coli_last = row0 + r;
+                            }
                         }
                     }
                 }
                 // one contiguous 32*R-byte block per wave and step
                 uint32_t *dst = reinterpret_cast<uint32_t *>(tbase + (((size_t)pass * steps + s) * 64 + lane) * (R / 2));
-#pragma unroll
-                for (int w = 0; w < R / 8; ++w) dst[w] = tw[w];
+                dst[0] = tw;
                 if (lane == 63 && pass + 1 < passes) { int2 v; v.x = Hup; v.y = Fup; bound[j] = v; }
             }
             diag_in = diag_next;
@@ -245,20 +293,20 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     while (i >= 0 && j >= 0) {
         const int32_t pass = i / (64 * R), ip = i - pass * 64 * R;
         const int32_t l = ip / R, r = ip - l * R;
-        const uint8_t byte = tb[(((size_t)pass * steps + (size_t)(j + l)) * 64 + l) * (size_t)(R / 2) + (r >> 1)];
-        const uint32_t tr = (byte >> (4 * (r & 1))) & 15u;
+        const uint32_t word = *reinterpret_cast<const uint32_t *>(tb + (((size_t)pass * steps + (size_t)(j + l)) * 64 + l) * (size_t)(R / 2));
+        const uint32_t tr = (word >> (28 - 4 * r)) & 15u;
         if (where == 0) {
-            const uint32_t src = tr & 3u;
-            if (src == SG_SRC_DIAG_EQ) { emit(0, 1); ++nmatch; ++alen; --i; --j; }
-            else if (src == SG_SRC_DIAG_X) { emit(1, 1); ++nmis; ++alen; --i; --j; }
-            else where = (src == SG_SRC_F) ? 1 : 2;
+            if (!(tr & SG_BIT_GAP)) {
+                if (tr & SG_BIT_X) { emit(1, 1); ++nmis; } else { emit(0, 1); ++nmatch; }
+                ++alen; --i; --j;
+            } else where = (tr & SG_BIT_X) ? 2 : 1;
         } else if (where == 1) {
             emit(2, 1); ++alen;
-            where = (tr & SG_F_EXT) ? 1 : 0;
+            where = (tr & SG_BIT_FOPEN) ? 0 : 1;
             --i;
         } else {
             emit(3, 1); ++alen;
-            where = (tr & SG_E_EXT) ? 2 : 0;
+            where = (tr & SG_BIT_EOPEN) ? 0 : 2;
             --j;
         }
     }
