@@ -160,7 +160,9 @@ def main():
     from isocon_amd import synth
 
     accs, seqs, _ = synth.make_reads(args.reads, args.length, args.isoforms, args.seed)
-    seqs = sorted(set(seqs), key=len)          # unique strings, length-sorted (NNG:243-246)
+    # unique strings in first-appearance order, then a STABLE sort by length (NNG:243-246).  Not set(): its iteration
+    # order depends on the per-process string hash seed, and every rank must pack the very same order.
+    seqs = sorted(dict.fromkeys(seqs), key=len)
     lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
 
     # CPU baseline first: its fork()ed workers must exist (and be gone) before this process touches the GPU

@@ -71,6 +71,13 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     n = store.n
+    fp = getattr(store, "fingerprint", None)
+    if fp is not None:      # every rank must have packed the very same sequences in the very same order
+        t = torch.tensor([fp, -fp], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t[0].item()) != fp or int(t[1].item()) != -fp:
+            raise RuntimeError("sharded_nn_graph: the ranks hold different sequence sets / orders (fingerprint mismatch); "
+                               "build the store from a deterministic order (not from set())")
     ranges = shard_ranges(store.lens, world, two_set_targets=is_target)
     qb, qe = ranges[rank]
     hits_all, stats_all = [], []

@@ -31,6 +31,12 @@ class SeqStore(object):
                    "isocon_store_create")
         self._h = h
         self._L = L
+        # cheap identity of the packed set (lengths + 64 sampled sequences): ranks of a sharded run compare it
+        import zlib
+        fp = zlib.crc32(self.lens.tobytes())
+        for i in range(0, self.n, max(1, self.n // 64)):
+            fp = zlib.crc32(seqs[i].encode("ascii"), fp)
+        self.fingerprint = int(fp)
 
     @property
     def handle(self):

@@ -4,7 +4,7 @@ import numpy as np
 from isocon_amd import synth
 from isocon_amd.store import SeqStore
 accs, seqs, _ = synth.make_reads(50000, 2500, 10, 30001)
-seqs = sorted(set(seqs), key=len)
+seqs = sorted(dict.fromkeys(seqs), key=len)
 st = SeqStore(seqs)
 best, rp, cols, stats = st.nn_graph()
 os.makedirs("gpurun_out", exist_ok=True)

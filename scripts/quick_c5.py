@@ -6,7 +6,7 @@ from isocon_amd import synth
 from isocon_amd.store import SeqStore
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 accs, seqs, _ = synth.make_reads(n, 0, 50, 50001, profile=synth.ONT_PROFILE, families=5, length_range=(1000, 5000))
-seqs = sorted(set(seqs), key=len)
+seqs = sorted(dict.fromkeys(seqs), key=len)
 lens = np.array([len(s) for s in seqs])
 print("n", len(seqs), "len range", lens.min(), lens.max())
 st = SeqStore(seqs)

@@ -5,7 +5,7 @@ from isocon_amd import synth
 from isocon_amd.store import SeqStore
 for (n, L, iso, seed) in ((5000, 1500, 3, 20001), (50000, 2500, 10, 30001)):
     t = time.time(); accs, seqs, _ = synth.make_reads(n, L, iso, seed); print("gen", time.time() - t)
-    seqs = sorted(set(seqs), key=len)
+    seqs = sorted(dict.fromkeys(seqs), key=len)
     t = time.time(); st = SeqStore(seqs); print("store", time.time() - t, st.device_bytes() / 1e6, "MB", len(seqs))
     for rep in range(2):
         t = time.time(); best, rp, cols, stats = st.nn_graph(); dt = time.time() - t

@@ -6,7 +6,7 @@ from isocon_amd import synth
 from isocon_amd.store import SeqStore
 n, L, iso, seed = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (50000, 2500, 10, 30001)))
 accs, seqs, _ = synth.make_reads(n, L, iso, seed)
-seqs = sorted(set(seqs), key=len)
+seqs = sorted(dict.fromkeys(seqs), key=len)
 st = SeqStore(seqs)
 ms = []
 for rep in range(3):

@@ -7,7 +7,7 @@ from isocon_amd.store import SeqStore
 n, L, iso, seed = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (50000, 2500, 10, 30001)))
 npairs = int(sys.argv[5]) if len(sys.argv) > 5 else 8192
 accs, seqs, _ = synth.make_reads(n, L, iso, seed)
-seqs = sorted(set(seqs), key=len)
+seqs = sorted(dict.fromkeys(seqs), key=len)
 st = SeqStore(seqs)
 best, rp, cols, stats = st.nn_graph()
 has = np.nonzero(rp[1:] > rp[:-1])[0][:npairs]

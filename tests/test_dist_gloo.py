@@ -82,7 +82,7 @@ def test_two_rank_sharded_graph_equals_serial_oracle(tmp_path):
     from isocon_amd import synth
     from oracle import oracle as O
     accs, seqs, _ = synth.make_reads(90, 150, 3, seed=9)
-    seqs = sorted(set(seqs), key=len)
+    seqs = sorted(dict.fromkeys(seqs), key=len)
     seqs.append("ACGT" * 60 + "TTGACCA")          # isolated entry: resolved in phase 1 only
     seqs = sorted(seqs, key=len)
     n = len(seqs)

@@ -74,7 +74,7 @@ def test_hit_list_overflow_restart_is_transparent():
     seqs = []
     for i in range(200):                     # every pair of these is at distance 2 (two distinct substitution sites)
         s = list(base); s[i] = "A" if s[i] != "A" else "C"; seqs.append("".join(s))
-    seqs = sorted(set(seqs), key=len)
+    seqs = sorted(dict.fromkeys(seqs), key=len)
     st = SeqStore(seqs)
     best, rp, cols, stats = st.nn_graph()
     row_ptr, c, e, _ = O.nn_1set(seqs, np.zeros(len(seqs), np.uint8), 0, len(seqs))

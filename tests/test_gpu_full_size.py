@@ -12,7 +12,7 @@ def c3():
     from isocon_amd import synth
     from isocon_amd.store import SeqStore
     accs, seqs, _ = synth.make_reads(50000, 2500, 10, seed=30001)
-    seqs = sorted(set(seqs), key=len)
+    seqs = sorted(dict.fromkeys(seqs), key=len)
     st = SeqStore(seqs)
     best, row_ptr, cols, stats = st.nn_graph()
     return seqs, st, best, row_ptr, cols, stats

@@ -94,7 +94,7 @@ def test_sharded_partial_matches_single_call():
     from isocon_amd import _lib, synth
     from isocon_amd.store import SeqStore, nn_finalize
     accs, seqs, _ = synth.make_reads(900, 800, 4, seed=5)
-    seqs = sorted(set(seqs), key=len)
+    seqs = sorted(dict.fromkeys(seqs), key=len)
     st = SeqStore(seqs)
     n = len(seqs)
     best1, rp1, cols1, _ = st.nn_graph()
