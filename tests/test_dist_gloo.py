@@ -69,6 +69,32 @@ def _worker(rank, world, port, seqs, conv, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_mismatch(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isocon_amd.dist import sharded_nn_graph
+    st = FakeStore(["ACGT", "ACGTA", "ACGTAC"])
+    st.fingerprint = 1234 + rank          # the ranks packed different orders / sets
+    try:
+        sharded_nn_graph(st, dist=dist, device=torch.device("cpu"))
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, "mismatch%d.txt" % rank), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_ranks_with_different_stores_are_rejected(tmp_path):
+    mp.spawn(_worker_mismatch, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        assert "fingerprint mismatch" in open(tmp_path / ("mismatch%d.txt" % r)).read()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
