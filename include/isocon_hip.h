@@ -100,18 +100,20 @@ int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t 
 
 /*
  * Sharded variant for one-process-per-GPU runs (the reference has no distributed path; its Pool chunking is
- * modules/nearest_neighbor_graph.py:33-35).  best_inout[n] is IN/OUT (0x3fffffff = no neighbour known yet).
- *   phase 0: 64-row band over every admissible pair whose LOWER index (1-set) / whose query (2-set) lies in
- *            [q_begin, q_end).  Pass best_inout all 0x3fffffff.
- *   phase 1: 128/256/512-row bands over the pairs whose lower index lies in [q_begin, q_end) and that involve an entry
- *            still unresolved in best_inout (which must be the element-wise MIN over all ranks' phase-0 results),
- *            then the un-banded kernel for the owned queries whose neighbour is further than 511 edits.
+ * modules/nearest_neighbor_graph.py:33-35).  A rank OWNS the entries q_begin, q_begin + q_stride, ... < q_end (rank r of
+ * N: q_begin = r, q_end = n, q_stride = N -- a cyclic split balances the very uneven windows automatically).
+ * best_inout[n] is IN/OUT (0x3fffffff = no neighbour known yet).
+ *   phase 0: 64-row band over every admissible pair whose LOWER index (1-set) / whose query (2-set) is owned.
+ *            Pass best_inout all 0x3fffffff.
+ *   phase 1: 128/256/512-row bands over the pairs whose lower index is owned and that involve an entry still
+ *            unresolved in best_inout (which must be the element-wise MIN over all ranks' phase-0 results), then the
+ *            un-banded kernel for the owned queries whose neighbour is further than 511 edits.
  * Each call returns up to hits_cap candidate edges (endpoint, neighbour, distance) as int32 triples.  The caller
  * min-reduces best over ranks after each phase, all-gathers the triples and calls isocon_nn_finalize.
  */
 int isocon_nn_partial(isocon_store *s, const uint8_t *is_converged, const uint8_t *is_target, uint64_t depth,
-                      uint32_t q_begin, uint32_t q_end, int32_t phase, int32_t *best_inout, int32_t *out_hits,
-                      uint64_t hits_cap, uint64_t *n_hits, isocon_nn_stats *stats);
+                      uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t phase, int32_t *best_inout,
+                      int32_t *out_hits, uint64_t hits_cap, uint64_t *n_hits, isocon_nn_stats *stats);
 int isocon_nn_finalize(uint32_t n, const int32_t *best, const int32_t *hits, uint64_t n_hits,
                        int32_t *out_best, uint64_t *out_row_ptr, uint32_t *out_cols, uint64_t cols_cap,
                        uint64_t *n_cols_needed);

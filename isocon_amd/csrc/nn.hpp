@@ -110,12 +110,13 @@ __device__ __forceinline__ void nn_flush_acc(const NNParams &P, const WaveAcc &a
 // W = 1: seed pass.  W = 2, 4, 8: the wide-band phase -- only entries flagged as (still unresolved) queries make a
 // pair active, every other tile is skipped after its role/threshold loads.
 template <int W>
-__global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint32_t q_begin, uint32_t q_end,
+__global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint32_t q_begin, uint32_t q_end, uint32_t q_stride,
                                                      int32_t tile_begin, int32_t tile_end, int32_t wpq)
 {
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
-    const uint32_t q = q_begin + (uint32_t)((blockIdx.x * 4u + (uint32_t)wave) / (uint32_t)wpq);
+    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)((blockIdx.x * 4u + (uint32_t)wave) / (uint32_t)wpq) * q_stride;
+    const uint32_t q = q64 < (uint64_t)q_end ? (uint32_t)q64 : q_end;
     WaveAcc acc = {0, 0, 0, 0};
     if (q < q_end) {
         const int32_t m = S.lens[q];
@@ -135,13 +136,14 @@ __global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint
 // Same scan with the query's window table in LDS (see band_tile_run<1, true>): one workgroup of NWAVES waves per
 // entry q; dynamic LDS = 16 B x (maxlen + 192).  This is the main-pass kernel of the 1-set search.
 template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParams P, uint32_t q_begin, uint32_t q_end,
+__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParams P, uint32_t q_begin, uint32_t q_end, uint32_t q_stride,
                                                               int32_t tile_begin, int32_t tile_end)
 {
     extern __shared__ uint4 wtab[];
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
-    const uint32_t q = q_begin + blockIdx.x;
+    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)blockIdx.x * q_stride;
+    const uint32_t q = q64 < (uint64_t)q_end ? (uint32_t)q64 : q_end;
     WaveAcc acc = {0, 0, 0, 0};
     if (q >= q_end) return;
     const int32_t m = S.lens[q];

@@ -1,8 +1,9 @@
 """One-process-per-GPU sharding of the nearest-neighbour search (torch.distributed; backend "nccl" = RCCL on ROCm).
 
 The packed sequence set is replicated on every GPU (31 MB for 50 k x 2.5 kb).  The 1-set search evaluates each
-unordered pair once, on the rank that owns the pair's LOWER index; ranks own contiguous index ranges balanced by
-estimated work.  Phase 0 = 64-row band over all admissible pairs; phase 1 = 128/256/512-row bands (same ownership
+unordered pair once, on the rank that owns the pair's LOWER index; rank r of N owns the entries r, r+N, r+2N, ... of the
+length-sorted order (a cyclic split: every rank gets the same mix of dense and sparse length regions, so the very uneven
+windows balance by themselves; `shard_ranges` is the contiguous alternative, balanced by estimated window sizes).  Phase 0 = 64-row band over all admissible pairs; phase 1 = 128/256/512-row bands (same ownership
 rule, only entries still unresolved after the min-reduction act as queries) and the un-banded kernel for the owned
 queries whose neighbour is further than 511 edits.  Exchange steps (the only data-path collectives):
     all_reduce(MIN) of best[n]   after the 64-row band phase and after the wide-band phase   (4 B x n)
@@ -62,7 +63,7 @@ def _all_gather_rows(dist, rows, device):
 def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, dist=None, device=None, return_stats=False):
     """Exact NN graph of `store` (length-sorted) computed by all ranks of the default process group.
 
-    `store` needs .n, .lens and .nn_partial(q_begin, q_end, phase, best, is_converged=, is_target=, depth=).
+    `store` needs .n, .lens and .nn_partial(q_begin, q_end, phase, best, is_converged=, is_target=, depth=, q_stride=).
     Every rank returns the full (best, row_ptr, cols)."""
     import torch
     if dist is None:
@@ -78,12 +79,12 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         if int(t[0].item()) != fp or int(t[1].item()) != -fp:
             raise RuntimeError("sharded_nn_graph: the ranks hold different sequence sets / orders (fingerprint mismatch); "
                                "build the store from a deterministic order (not from set())")
-    ranges = shard_ranges(store.lens, world, two_set_targets=is_target)
-    qb, qe = ranges[rank]
+    qb, qe, qs = rank, n, world          # cyclic ownership
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
     for phase in (0, 1):
-        hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth)
+        hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth,
+                                       q_stride=qs)
         t = torch.from_numpy(best).to(device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)           # exchange step 1 (and 2)
         best[:] = t.cpu().numpy()

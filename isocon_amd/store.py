@@ -92,7 +92,7 @@ class SeqStore(object):
             _lib.check(rc, "isocon_nn_graph")
             return best[:n], row_ptr.astype(np.int64), cols[:int(row_ptr[n])], stats.as_dict()
 
-    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32):
+    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1):
         """One shard / one phase (see include/isocon_hip.h).  `best` is updated in place; returns (hits[k,3], stats)."""
         conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
         targ = None if is_target is None else np.ascontiguousarray(is_target, dtype=np.uint8)
@@ -104,7 +104,7 @@ class SeqStore(object):
         best0 = best.copy()
         while True:
             hits = np.empty((cap, 3), dtype=np.int32)
-            rc = self._L.isocon_nn_partial(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), depth, q_begin, q_end, phase,
+            rc = self._L.isocon_nn_partial(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), depth, q_begin, q_end, q_stride, phase,
                                            _ptr(best, _lib.i32p), _ptr(hits, _lib.i32p), cap, ctypes.byref(n_hits),
                                            ctypes.byref(stats))
             if rc == _lib.ISOCON_E_CAPACITY:

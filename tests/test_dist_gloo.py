@@ -23,7 +23,7 @@ class FakeStore(object):
         self.n = len(seqs)
         self.lens = np.array([len(s) for s in seqs], dtype=np.int64)
 
-    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32):
+    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1):
         from oracle import oracle as O
         hits = []
         n = self.n
@@ -31,7 +31,7 @@ class FakeStore(object):
             raise NotImplementedError
         conv = np.zeros(n, bool) if is_converged is None else np.asarray(is_converged, bool)
         if phase == 0:      # pairs owned through their lower index, band limit 63
-            for q in range(q_begin, q_end):
+            for q in range(q_begin, q_end, q_stride):
                 for t in range(q + 1, n):
                     if self.lens[t] - self.lens[q] > 63:
                         break
@@ -43,7 +43,7 @@ class FakeStore(object):
                             best[e] = d
                             hits.append((e, o, d))
         else:               # owned queries still unresolved: unbounded distances inside |len diff| <= len(q)
-            for q in range(q_begin, q_end):
+            for q in range(q_begin, q_end, q_stride):
                 if conv[q] or best[q] != NN_INF:
                     continue
                 for t in range(n):
