@@ -216,7 +216,7 @@ def main():
     scan_ms = []
     for _ in range(args.steps):
         step()
-        scan_ms.append(last["stats"][0]["scan_kernel_ms"] + last["stats"][0]["seed_kernel_ms"])
+        scan_ms.append(sum(x["scan_kernel_ms"] + x["seed_kernel_ms"] for x in last["stats"]))
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -228,7 +228,7 @@ def main():
     value = n_align / (ms_per_step / 1e3)
 
     # roofline of the dominant kernel on this rank (live HIP-event time of its launches inside the timed region)
-    st0 = last["stats"][0]
+    st0 = {k: sum(x[k] for x in last["stats"]) for k in ("pairs_evaluated", "cells_columns")}   # this rank, all phases
     pairs_eval = int(st0["pairs_evaluated"])
     mean_len = float(lens.mean())
     alg_bytes = pairs_eval * (2.0 * mean_len + 8.0)

@@ -103,11 +103,13 @@ int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t 
  * modules/nearest_neighbor_graph.py:33-35).  A rank OWNS the entries q_begin, q_begin + q_stride, ... < q_end (rank r of
  * N: q_begin = r, q_end = n, q_stride = N -- a cyclic split balances the very uneven windows automatically).
  * best_inout[n] is IN/OUT (0x3fffffff = no neighbour known yet).
- *   phase 0: 64-row band over every admissible pair whose LOWER index (1-set) / whose query (2-set) is owned.
- *            Pass best_inout all 0x3fffffff.
- *   phase 1: 128/256/512-row bands over the pairs whose lower index is owned and that involve an entry still
- *            unresolved in best_inout (which must be the element-wise MIN over all ranks' phase-0 results), then the
- *            un-banded kernel for the owned queries whose neighbour is further than 511 edits.
+ *   phase 0: seed pass -- every owned entry against its 64 nearest longer neighbours (64-row band).  Pass best_inout all
+ *            0x3fffffff.  (No-op for the 2-set graph.)
+ *   phase 1: 64-row band over every remaining admissible pair whose LOWER index (1-set) / whose query (2-set) is owned;
+ *            best_inout = element-wise MIN over all ranks' phase-0 results (tight thresholds on every rank).
+ *   phase 2: 128/256/512-row bands over the pairs whose lower index is owned and that involve an entry still
+ *            unresolved in best_inout (= MIN over all ranks' phase-1 results), then the un-banded kernel for the owned
+ *            queries whose neighbour is further than 511 edits.
  * Each call returns up to hits_cap candidate edges (endpoint, neighbour, distance) as int32 triples.  The caller
  * min-reduces best over ranks after each phase, all-gathers the triples and calls isocon_nn_finalize.
  */

@@ -3,10 +3,12 @@
 The packed sequence set is replicated on every GPU (31 MB for 50 k x 2.5 kb).  The 1-set search evaluates each
 unordered pair once, on the rank that owns the pair's LOWER index; rank r of N owns the entries r, r+N, r+2N, ... of the
 length-sorted order (a cyclic split: every rank gets the same mix of dense and sparse length regions, so the very uneven
-windows balance by themselves; `shard_ranges` is the contiguous alternative, balanced by estimated window sizes).  Phase 0 = 64-row band over all admissible pairs; phase 1 = 128/256/512-row bands (same ownership
-rule, only entries still unresolved after the min-reduction act as queries) and the un-banded kernel for the owned
-queries whose neighbour is further than 511 edits.  Exchange steps (the only data-path collectives):
-    all_reduce(MIN) of best[n]   after the 64-row band phase and after the wide-band phase   (4 B x n)
+windows balance by themselves; `shard_ranges` is the contiguous alternative, balanced by estimated window sizes).
+Phase 0 = seed pass (64 nearest longer neighbours of the owned entries); phase 1 = 64-row band over all other admissible
+pairs; phase 2 = 128/256/512-row bands (only entries still unresolved after the min-reduction act as queries) and the
+un-banded kernel for the owned queries whose neighbour is further than 511 edits.  Exchange steps (the only data-path
+collectives):
+    all_reduce(MIN) of best[n]   after each of the three phases (tight thresholds everywhere)   (4 B x n)
     all_gather of the candidate edges that attain best[] on their rank                         (12 B x edges)
 The reference has no distributed path (its Pool chunking: /root/reference/modules/nearest_neighbor_graph.py:33-35).
 """
@@ -82,7 +84,7 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
     qb, qe, qs = rank, n, world          # cyclic ownership
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
-    for phase in (0, 1):
+    for phase in (0, 1, 2):
         hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth,
                                        q_stride=qs)
         t = torch.from_numpy(best).to(device)
