@@ -113,3 +113,26 @@ def test_sharded_partial_matches_single_call():
         best2, rp2, cols2 = nn_finalize(n, red, np.concatenate(hits))
         assert best1.tolist() == best2.tolist()
         assert rp1.tolist() == rp2.tolist() and cols1.tolist() == cols2.tolist()
+
+
+def test_long_reads_take_the_other_main_pass_kernels():
+    """> 3.2 kb: 16-wave workgroups (window table > 53 KB); > 10 kb: scalar-window main pass.  Both against the oracle."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    for (n, L, seed) in ((220, 4600, 11), (36, 11000, 12)):
+        accs, seqs, _ = synth.make_reads(n, L, 3, seed=seed)
+        S = dict(zip(accs, seqs))
+        g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+        g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+        assert ordered(g_gpu) == ordered(g_cpu), (n, L)
+
+
+def test_empty_store_and_single_entry():
+    from isocon_amd.store import SeqStore
+    st = SeqStore([])
+    best, rp, cols, _ = st.nn_graph()
+    assert len(best) == 0 and rp.tolist() == [0] and len(cols) == 0
+    st1 = SeqStore(["ACGTACGT"])
+    best, rp, cols, _ = st1.nn_graph()
+    assert best.tolist() == [-1] and rp.tolist() == [0, 0]
