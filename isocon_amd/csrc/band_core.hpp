@@ -108,20 +108,16 @@ ISO_HD void band_init(BandLane<W> &L, int32_t nv /* = -a0 */, int32_t bstar)
     L.ztop = 0;
 }
 
-// One text column.  NL/NH = ~pattern bit-planes of the current window (wave-uniform), VM = valid-row mask
-// (only read when MASKED), slo/shi = text base bit-planes splat to 32 bits (0 or 0xffffffff).
-template <int W, bool MASKED>
-ISO_HD void band_step(BandLane<W> &L, const uint64_t (&NL)[W], const uint64_t (&NH)[W], const uint64_t (&VM)[W],
-                      uint32_t slo, uint32_t shi)
+// One text column given the match vectors: EQ[i] bit r = 1 iff the pattern row of window bit r (word i) equals the
+// column's text base (0 on virtual rows).
+template <int W>
+ISO_HD void band_step_eq(BandLane<W> &L, const uint64_t (&EQ)[W])
 {
-    const uint64_t sl = ((uint64_t)slo << 32) | slo;
-    const uint64_t sh = ((uint64_t)shi << 32) | shi;
     uint64_t D0[W], HP[W], HN[W];
     uint64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-        uint64_t eq = (NL[i] ^ sl) & (NH[i] ^ sh);
-        if (MASKED) eq &= VM[i];
+        const uint64_t eq = EQ[i];
         const uint64_t vp = L.VP[i], vn = L.VN[i];
         const uint64_t x = eq & vp;
         uint64_t s = x + vp;
@@ -134,10 +130,30 @@ ISO_HD void band_step(BandLane<W> &L, const uint64_t (&NL)[W], const uint64_t (&
     L.ztop += (uint32_t)D0[0] & 1u;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-        const uint64_t d0s = (D0[i] >> 1) | ((i + 1 < W) ? (D0[(i + 1 < W) ? i + 1 : i] << 63) : 0);
+        uint64_t d0s = (D0[i] >> 1) | ((i + 1 < W) ? (D0[(i + 1 < W) ? i + 1 : i] << 63) : 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(d0s));             // one 64-bit shift feeding both uses (else the halves get re-derived)
+#endif
         L.VP[i] = or_nor(HN[i], d0s, HP[i]);
         L.VN[i] = d0s & HP[i];
     }
+}
+
+// One text column.  NL/NH = ~pattern bit-planes of the current window (wave-uniform), VM = valid-row mask
+// (only read when MASKED), slo/shi = text base bit-planes splat to 32 bits (0 or 0xffffffff).
+template <int W, bool MASKED>
+ISO_HD void band_step(BandLane<W> &L, const uint64_t (&NL)[W], const uint64_t (&NH)[W], const uint64_t (&VM)[W],
+                      uint32_t slo, uint32_t shi)
+{
+    const uint64_t sl = ((uint64_t)slo << 32) | slo;
+    const uint64_t sh = ((uint64_t)shi << 32) | shi;
+    uint64_t EQ[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        EQ[i] = (NL[i] ^ sl) & (NH[i] ^ sh);
+        if (MASKED) EQ[i] &= VM[i];
+    }
+    band_step_eq<W>(L, EQ);
 }
 
 // D on the final diagonal after `cols` columns.

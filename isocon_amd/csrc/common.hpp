@@ -12,8 +12,11 @@ namespace isocon {
 //   A=0 C=1 G=2 T=3; bases past the end are 0; there are nchunks = ceil(maxlen/64)+1 chunks (last all-zero).
 //   Consecutive ids are adjacent in memory, so a wave whose lanes hold consecutive sequences loads
 //   64 x 16 B = 1 KiB contiguous per chunk.
+//   il (optional, built on demand for the LDS-table kernel): same indexing, 16 B per (chunk, id), the two code bits
+//   of each base adjacent: word x = bases 0..31, word y = bases 32..63, base j of a word at bits 2j, 2j+1.
 struct DevStore {
     const uint64_t *planes;
+    const uint64_t *il;
     const int32_t *lens;
     uint32_t n;
     uint32_t nchunks;

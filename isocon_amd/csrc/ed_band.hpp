@@ -20,9 +20,12 @@ struct TileStats {
 // Window source (gfx950 issue costs, scripts/ubench/valu_rate2.hip: and/or/xor/not/add/sub/lshr on VGPR operands
 // issue in ~2.3 cycles per wave-instruction, anything with an SGPR operand and all VOP3-only integer ops in ~4.2):
 //   LDS == false : the pattern window lives in SGPRs and is slid by the scalar unit (any W);
-//   LDS == true  : W == 1, the workgroup has tabulated the 64-bit window of BOTH complemented bit-planes for every
-//                  bit offset o in [-63, m+64) in LDS (tab[o+63] = {~lo, ~hi}); each column is one broadcast
-//                  ds_read_b128 and the Eq logic runs on VGPR operands only.
+//   LDS == true  : W == 1, the workgroup has tabulated in LDS, for every bit offset o in [-63, m+129) of the shared
+//                  sequence, the 32-row match masks of the four bases (tab[o+63] = {Eq_A, Eq_C, Eq_G, Eq_T}, zero on
+//                  rows outside the sequence).  A column is ONE ds_read2_b32 at a per-lane address (entry, base) and
+//                  (entry + 32, base): the 64-bit Eq vector arrives ready-made and no Eq logic, bit extraction or
+//                  virtual-row mask is left on the VALU.  Lane texts come from the interleaved store S.il
+//                  (2 bits per base) so that the address is shift + and_or.
 template <int W, bool LDS = false>
 __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t shared, int32_t m, uint32_t tid,
                                                  int32_t n, int32_t k_req, bool active, TileStats *st,
@@ -71,9 +74,11 @@ __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t sha
         }
         VM[i] = valid_word(nv, i);
     }
-    const uint4 *wtab = LDS ? tab + (a0 + 63) : nullptr;   // wtab[j-1] = window of column j
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+    // LDS byte address of the table entry of column 1 (entry index a0 + 63); entries are 16 B
+    const uint32_t tbase = LDS ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)tab + (uint32_t)(a0 + 63) * 16u : 0u;
 
-    const ulonglong2 *P2 = reinterpret_cast<const ulonglong2 *>(planes);
+    const ulonglong2 *P2 = reinterpret_cast<const ulonglong2 *>(LDS ? S.il : planes);
     ulonglong2 tnext = P2[(size_t)tid];
     int32_t cols = 0;
     uint32_t live_cols = 0;
@@ -90,21 +95,30 @@ __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t sha
             const int32_t jb = 64 * c + 32 * h;
             if (jb >= n_max) break;
             const int32_t cnt = (n_max - jb) < 32 ? (n_max - jb) : 32;
-            const uint32_t wl = (uint32_t)(h ? (tcur.x >> 32) : tcur.x);
-            const uint32_t wh = (uint32_t)(h ? (tcur.y >> 32) : tcur.y);
+            // planes: wl / wh = 32 columns of the low / high bit-plane; interleaved: wl = columns 0..15, wh = 16..31
+            const uint32_t wl = LDS ? (uint32_t)(h ? tcur.y : tcur.x) : (uint32_t)(h ? (tcur.x >> 32) : tcur.x);
+            const uint32_t wh = LDS ? (uint32_t)((h ? tcur.y : tcur.x) >> 32) : (uint32_t)(h ? (tcur.y >> 32) : tcur.y);
             const bool fast = cnt == 32 && jb >= nv && jb + 32 <= n_min;
             live_cols += (uint32_t)__popcll(__ballot(live)) * (uint32_t)cnt;
             if (fast) {
+                if constexpr (LDS) {
+                    uint32_t blk;      // table address of this 32-column block, in a VGPR (SGPR operands cost issue cycles)
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(blk) : "s"(tbase + (uint32_t)jb * 16u));
 #pragma unroll 32
-                for (int jj = 0; jj < 32; ++jj) {
-                    const uint32_t slo = (uint32_t)__builtin_amdgcn_sbfe((int)wl, jj, 1);
-                    const uint32_t shi = (uint32_t)__builtin_amdgcn_sbfe((int)wh, jj, 1);
-                    if (LDS) {
-                        const uint4 w = wtab[jb + jj];
-                        NL[0] = ((uint64_t)w.y << 32) | w.x;
-                        NH[0] = ((uint64_t)w.w << 32) | w.z;
-                        band_step<W, false>(L, NL, NH, VM, slo, shi);
-                    } else {
+                    for (int jj = 0; jj < 32; ++jj) {
+                        const uint32_t w2 = jj < 16 ? wl : wh;
+                        const int sh = 2 * (jj & 15);
+                        const uint32_t t = sh >= 2 ? (w2 >> (sh - 2)) : (w2 << 2);
+                        lds_u32 *p = (lds_u32 *)(uintptr_t)((t & 0xCu) | blk);
+                        uint64_t EQ[1];
+                        EQ[0] = ((uint64_t)p[4 * jj + 128] << 32) | p[4 * jj];
+                        band_step_eq<1>(L, EQ);
+                    }
+                } else {
+#pragma unroll 32
+                    for (int jj = 0; jj < 32; ++jj) {
+                        const uint32_t slo = (uint32_t)__builtin_amdgcn_sbfe((int)wl, jj, 1);
+                        const uint32_t shi = (uint32_t)__builtin_amdgcn_sbfe((int)wh, jj, 1);
                         band_step<W, false>(L, NL, NH, VM, slo, shi);
                         window_slide<W>(NL, NH, VM, FL, FH);
                     }
@@ -118,16 +132,15 @@ __device__ __forceinline__ int32_t band_tile_run(const DevStore &S, uint32_t sha
             } else {
 #pragma unroll 1
                 for (int jj = 0; jj < cnt; ++jj) {
-                    const uint32_t slo = (uint32_t)__builtin_amdgcn_sbfe((int)wl, jj, 1);
-                    const uint32_t shi = (uint32_t)__builtin_amdgcn_sbfe((int)wh, jj, 1);
-                    if (LDS) {
-                        const uint4 w = wtab[jb + jj];
-                        NL[0] = ((uint64_t)w.y << 32) | w.x;
-                        NH[0] = ((uint64_t)w.w << 32) | w.z;
-                        const int32_t vb = nv - (jb + jj);      // virtual rows still inside the window
-                        VM[0] = vb <= 0 ? ~(uint64_t)0 : (vb >= 64 ? 0 : (~(uint64_t)0 << vb));
-                        band_step<W, true>(L, NL, NH, VM, slo, shi);
+                    if constexpr (LDS) {
+                        const uint32_t b = ((jj < 16 ? wl : wh) >> (2 * (jj & 15))) & 3u;
+                        lds_u32 *p = (lds_u32 *)(uintptr_t)(tbase + (uint32_t)(jb + jj) * 16u + b * 4u);
+                        uint64_t EQ[1];
+                        EQ[0] = ((uint64_t)p[128] << 32) | p[0];      // already zero on virtual rows
+                        band_step_eq<1>(L, EQ);
                     } else {
+                        const uint32_t slo = (uint32_t)__builtin_amdgcn_sbfe((int)wl, jj, 1);
+                        const uint32_t shi = (uint32_t)__builtin_amdgcn_sbfe((int)wh, jj, 1);
                         band_step<W, true>(L, NL, NH, VM, slo, shi);
                         window_slide<W>(NL, NH, VM, FL, FH);
                     }

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParam
         const int64_t t0 = (int64_t)q + 1 + (int64_t)tile_begin * 64;
         if (t0 >= (int64_t)S.n || t0 - (int64_t)q > (int64_t)P.depth || S.lens[t0] - m > P.kcap) return;
     }
-    // window table: entry e <-> bit offset o = e - 63 of the query's bit-plane stream, complemented
+    // match-mask table: entry e <-> bit offset o = e - 63 of the query; 32 rows o..o+31 per base, rows outside [0, m) = 0
     {
         const uint64_t *planes = S.planes;
         const uint32_t nseq = S.n;
@@ -160,9 +160,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParam
         auto chunk_hi = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2 + 1] : 0; };
         const int32_t entries = m + 192;
         for (int32_t e = threadIdx.x; e < entries; e += NWAVES * 64) {
-            const uint64_t nl = ~stream64(chunk_lo, e - 63), nh = ~stream64(chunk_hi, e - 63);
+            const int32_t o = e - 63;
+            const uint32_t lo = (uint32_t)stream64(chunk_lo, o), hi = (uint32_t)stream64(chunk_hi, o);
+            const int32_t r0 = o < 0 ? -o : 0, r1 = (m - o) < 32 ? (m - o) : 32;       // valid rows [r0, r1)
+            uint32_t v = 0;
+            if (r1 > r0) v = (r1 >= 32 ? 0xffffffffu : ((1u << r1) - 1u)) & ~(r0 >= 32 ? 0xffffffffu : ((1u << r0) - 1u));
             uint4 w;
-            w.x = (uint32_t)nl; w.y = (uint32_t)(nl >> 32); w.z = (uint32_t)nh; w.w = (uint32_t)(nh >> 32);
+            w.x = ~lo & ~hi & v; w.y = lo & ~hi & v; w.z = ~lo & hi & v; w.w = lo & hi & v;
             wtab[e] = w;
         }
     }
@@ -180,6 +184,29 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParam
 }
 
 // planes2[chunk][newpos] = planes[chunk][perm[newpos]]  (16 B per element; used to group similar sequences of equal length)
+// il[chunk][id] = the 64 bases of planes[chunk][id] with the two code bits interleaved (x: bases 0..31, y: 32..63)
+__device__ __forceinline__ uint64_t spread32(uint32_t v)
+{
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_interleave_planes(const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ dst, size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const ulonglong2 p = src[i];
+        ulonglong2 o;
+        o.x = spread32((uint32_t)p.x) | (spread32((uint32_t)p.y) << 1);
+        o.y = spread32((uint32_t)(p.x >> 32)) | (spread32((uint32_t)(p.y >> 32)) << 1);
+        dst[i] = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_permute_planes(const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ dst,
                                                          const uint32_t *__restrict__ perm, uint32_t n, uint32_t nchunks)
 {
