@@ -12,7 +12,7 @@ the loop's own window rule, NNG:145,152).  It is a lower bound of the reference'
 value depends on nr_cores through the chunk-local seed dictionary, NNG:112,125-129), is identical for the CPU
 baseline and the GPU, and is computable from the result alone.
 
-Extra objects on the JSON line: `roofline` (dominant kernel k_nn_scan_up, HBM bound on ALGORITHMIC bytes,
+Extra objects on the JSON line: `roofline` (dominant kernel k_nn_scan_refill, HBM bound on ALGORITHMIC bytes,
 SURVEY.md 8(d): len(q)+len(t)+8 bytes per aligned pair) and `cpu_baseline` (the C oracle -- a restatement of the
 edlib-based loop -- under a multiprocessing Pool on this host's cores, bounded sample).
 """
@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+VALU_CYCLES_PER_COLUMN = 65.1                                        # measured issue costs x instruction mix of the main-pass column
+VALU_PEAK_LANE_COLS = 256 * 4 * 64 * 2.4e9 / VALU_CYCLES_PER_COLUMN    # 256 CUs x 4 SIMDs x 64 lanes at 2.4 GHz
 
 
 def window_pairs(lens, best):
@@ -244,10 +246,17 @@ def main():
     is_default = (args.reads, args.length, args.isoforms, args.seed) == (50000, 2500, 10, 30001)
     if not is_default:
         traffic = None          # the committed PMC figure belongs to the default workload only
-    roofline = {"bound": "hbm", "kernel": "k_nn_scan_lds (main pass) + k_nn_scan_up (seed pass) of one step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    lane_cols_s = float(st0["cells_columns"]) / (k_ms / 1e3) if k_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_nn_scan_refill (main pass) + k_nn_scan_up (seed pass) of one step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel_ms": k_ms, "pairs_per_launch": pairs_eval, "alg_bytes_per_pair": 2.0 * mean_len + 8.0,
-                "lane_columns_per_s": float(st0["cells_columns"]) / (k_ms / 1e3) if k_ms > 0 else 0.0}
+                "lane_columns_per_s": lane_cols_s,
+                # The byte model above charges every pair both sequences (what the reference hands to edlib); the kernel
+                # reads a query once per ~6 500 pairs (LDS table) and the neighbours from L2/MALL, so frac may exceed 1:
+                # HBM is not what bounds it.  The real ceiling is VALU issue: 20.5 instructions =
+                # 65.1 issue cycles per 64-lane DP column.
+                "issue_bound": {"unit": "lane-columns/s", "achieved": lane_cols_s, "peak": VALU_PEAK_LANE_COLS,
+                                "frac": lane_cols_s / VALU_PEAK_LANE_COLS, "cycles_per_wave_column_by_mix": VALU_CYCLES_PER_COLUMN}}
 
     result = {
         "metric": "read x candidate alignments/sec (NN-graph build, %dk x %.1fkb reads)" % (args.reads // 1000, args.length / 1000.0),

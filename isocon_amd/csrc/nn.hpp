@@ -219,7 +219,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     typedef __attribute__((address_space(3))) const uint32_t lds_u32;
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
-    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)blockIdx.x * q_stride;
+    const uint32_t bid = blockIdx.x;
+    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)bid * q_stride;
     if (q64 >= (uint64_t)q_end) return;
     const uint32_t q = (uint32_t)q64;
     const int32_t m = S.lens[q];
@@ -259,14 +260,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     bool run = false, upd_s = false, upd_l = false;
     uint32_t tid = q, blk = idle_blk, nsh = 0;
     int32_t n_t = 0, k_eff = -1, nv = 0, col = 0;
-    uint32_t cur[5] = {0, 0, 0, 0, 0}, nxt[5] = {0, 0, 0, 0, 0};
+    uint32_t cur[5] = {0, 0, 0, 0, 0};       // the 5 text dwords the lane's next block is cut from
     const uint32_t *tp = text;          // first dword of the lane's current block in the nibble store
     BandLane<1> L;
     band_init<1>(L, 0, 0);
     // wave state (uniform)
     uint32_t qhead = 0, qcount = 0;
     bool exhausted = false;
-    WaveAcc acc = {0, 0, 0, 0};
+    uint32_t n_pairs = 0, n_batches = 0, n_blocks = 0, n_live = 0;
 
     auto load5 = [](const uint32_t *p, uint32_t (&d)[5]) {
         const TextQuad t4 = *reinterpret_cast<const TextQuad *>(p);
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                 ring[slot][1] = (uint32_t)np | ((uint32_t)k << 20) | ((uint32_t)(-a0) << 26);
             }
             qcount += (uint32_t)__popcll(am);
-            acc.pairs += (uint32_t)__popcll(am);
-            acc.tiles += 1;
+            n_pairs += (uint32_t)__popcll(am);
+            n_batches += 1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -347,7 +348,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                 nsh = 4u * ((32u - phi) & 7u);
                 tp = text + (size_t)tid * text_stride + ((32u - phi) >> 3);
                 load5(tp, cur);
-                if (col + 32 < n_t) load5(tp + 4, nxt);
                 run = true;
             }
             const uint32_t taken = nfree < qcount ? nfree : qcount;
@@ -363,6 +363,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_alignbit(cur[i + 1], cur[i], nsh);
+        if (run && col + 32 < n_t) load5(tp + 4, cur);          // next block's text arrives while this one is computed
         if (__ballot(run && col + 32 > n_t) == 0) {
 #pragma unroll
             for (int jj = 0; jj < 32; ++jj) {
@@ -389,8 +390,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                 }
             }
         }
-        acc.cols += 64u * 32u;
-        acc.live += (uint32_t)__popcll(runmask) * 32u;
+        n_blocks += 1;
+        n_live += (uint32_t)__popcll(runmask);
         col += 32;
         const bool fin = run && col >= n_t;
         const int32_t dv = band_diag_value<1>(L, nv, fin ? n_t : col);
@@ -406,15 +407,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
             nn_append(P, hs, (int32_t)q, (int32_t)tid, r);
             nn_append(P, hl, (int32_t)tid, (int32_t)q, r);
         }
+        blk += 128u;
+        tp += 4;
         if (!run) blk = idle_blk;
-        if (run) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) cur[i] = nxt[i];
-            blk += 128u;
-            tp += 4;
-            if (col + 32 < n_t) load5(tp + 4, nxt);
-        }
     }
+    WaveAcc acc;
+    acc.pairs = n_pairs; acc.tiles = n_batches; acc.cols = (unsigned long long)n_blocks * 2048ull; acc.live = (unsigned long long)n_live * 32ull;
     nn_flush_acc(P, acc);
 }
 

@@ -1,0 +1,47 @@
+"""Turn gpurun_out/{prof,pmc_fetch,pmc_write}_<TAG> (written by scripts/profile_bench.sh) into the tracked files
+profiles/<TAG>_kernel_stats.csv, profiles/<TAG>_pmc_summary.txt, profiles/<TAG>_bench.json and profiles/traffic.json."""
+import csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(ROOT, "gpurun_out")
+prof = os.path.join(ROOT, "profiles")
+
+ks = glob.glob(os.path.join(out, "prof_" + tag, "*", "*_kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(prof, tag + "_kernel_stats.csv"))
+b = os.path.join(out, "bench_%s.json" % tag)
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(prof, tag + "_bench.json"))
+
+
+def rows(kind):
+    f = glob.glob(os.path.join(out, "pmc_%s_%s" % (kind, tag), "*", "*_counter_collection.csv"))
+    res = []
+    if not f:
+        return res
+    for r in csv.DictReader(open(f[0])):
+        if "isocon::k_" in r["Kernel_Name"]:
+            res.append((r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"]),
+                        int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return res
+
+
+lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+         "dispatches of one NN-graph step at C3 (50k x 2.5kb)"]
+fetch = rows("fetch"); write = rows("write")
+main = {}
+for name, grid, cn, val, dur in fetch + write:
+    lines.append("%s grid=%d %s=%f KiB dur_ns=%d" % (name, grid, cn, val, dur))
+    if "k_nn_scan_refill" in name or "k_nn_scan_lds" in name:
+        main[cn] = val
+        main["kernel"] = name
+lines.append("HBM traffic of the main launch = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md #HBM) + WRITE_SIZE, x 1024 B")
+open(os.path.join(prof, tag + "_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+if "FETCH_SIZE" in main and "WRITE_SIZE" in main:
+    t = {"round": tag, "kernel": main["kernel"] + " main pass, C3 (50k x 2.5kb)",
+         "nn_scan_main_hbm_bytes_per_launch": (2 * main["FETCH_SIZE"] + main["WRITE_SIZE"]) * 1024.0,
+         "fetch_size_kib": main["FETCH_SIZE"], "write_size_kib": main["WRITE_SIZE"],
+         "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md #HBM); source profiles/%s_pmc_summary.txt" % tag}
+    json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+print("\n".join(lines))
