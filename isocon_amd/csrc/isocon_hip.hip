@@ -25,7 +25,7 @@ using namespace isocon;
 // hipMalloc/hipFree (tens of ms for the multi-GB trace scratch) every time.
 struct ScratchPool {
     struct Slot { void *p = nullptr; size_t cap = 0; };
-    Slot slots[32];
+    Slot slots[48];
     void *get(int idx, size_t bytes)
     {
         Slot &s = slots[idx];
@@ -48,9 +48,10 @@ struct ScratchPool {
 
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
-    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL,
-    SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2,
+    SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB, SLOT_COUNT
 };
+static_assert(SLOT_COUNT <= 48, "ScratchPool::slots too small");
 
 // One pool per process (one process drives one GPU): scratch outlives the individual stores, because the Python
 // wrappers create a fresh store per call (the reference's functions are stateless).
@@ -69,6 +70,56 @@ struct isocon_store {
 namespace {
 
 // A device buffer: pooled (slot of the store's ScratchPool) when constructed with a pool, private otherwise.
+// Pinned staging for host<->device copies.  hipMemcpy on pageable memory pins the user pages on the fly and releases
+// them lazily: measured 17-27 ms showing up at the NEXT synchronisation after a 7 MB hit-list download.  One pinned
+// buffer per process, copies go through it in pieces.
+struct PinnedStage {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *get(size_t bytes)
+    {
+        if (cap < bytes) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) cap = bytes;
+            else { p = nullptr; (void)hipGetLastError(); }
+        }
+        return p;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+static PinnedStage g_stage;
+static constexpr size_t kStageBytes = (size_t)32 << 20;
+static constexpr size_t kStageMin = (size_t)32 << 10;      // smaller copies: the runtime's own staging path is fine
+
+static hipError_t copy_d2h(void *dst, const void *dsrc, size_t bytes)
+{
+    if (bytes < kStageMin) return hipMemcpy(dst, dsrc, bytes, hipMemcpyDeviceToHost);
+    char *st = static_cast<char *>(g_stage.get(kStageBytes));
+    if (!st) return hipMemcpy(dst, dsrc, bytes, hipMemcpyDeviceToHost);
+    for (size_t off = 0; off < bytes; off += kStageBytes) {
+        const size_t len = std::min(kStageBytes, bytes - off);
+        const hipError_t e = hipMemcpy(st, static_cast<const char *>(dsrc) + off, len, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        memcpy(static_cast<char *>(dst) + off, st, len);
+    }
+    return hipSuccess;
+}
+
+static hipError_t copy_h2d(void *ddst, const void *src, size_t bytes)
+{
+    if (bytes < kStageMin) return hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice);
+    char *st = static_cast<char *>(g_stage.get(kStageBytes));
+    if (!st) return hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice);
+    for (size_t off = 0; off < bytes; off += kStageBytes) {
+        const size_t len = std::min(kStageBytes, bytes - off);
+        memcpy(st, static_cast<const char *>(src) + off, len);
+        const hipError_t e = hipMemcpy(static_cast<char *>(ddst) + off, st, len, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 struct DevBuf {
     void *p = nullptr;
     ScratchPool *pool = nullptr;
@@ -135,7 +186,7 @@ int isocon_device_count(void)
     return n;
 }
 
-void isocon_release_scratch(void) { g_scratch.release(); }
+void isocon_release_scratch(void) { g_scratch.release(); g_stage.release(); }
 
 int isocon_init(int device_ordinal)
 {
@@ -195,8 +246,8 @@ int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t 
         isocon_store_destroy(st);
         return ISOCON_E_HIP;
     }
-    if (hipMemcpy(st->d_planes, planes.data(), pbytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(st->d_lens, lens.data(), lbytes, hipMemcpyHostToDevice) != hipSuccess) {
+    if (copy_h2d(st->d_planes, planes.data(), pbytes) != hipSuccess ||
+        copy_h2d(st->d_lens, lens.data(), lbytes) != hipSuccess) {
         g_last_error = "hipMemcpy(store) failed";
         isocon_store_destroy(st);
         return ISOCON_E_HIP;
@@ -240,15 +291,15 @@ int launch_band_tiles(isocon_store *st, const DevStore &S, const std::vector<uin
     DevBuf d_ts(&st->pool, SLOT_ED_TS), d_ids(&st->pool, SLOT_ED_IDS), d_k(&st->pool, SLOT_ED_K), d_out(&st->pool, SLOT_ED_OUT);
     int rc;
     if ((rc = d_ts.alloc(nt * 4)) || (rc = d_ids.alloc(nt * 64 * 4)) || (rc = d_k.alloc(nt * 64 * 4)) || (rc = d_out.alloc(nt * 64 * 4))) return rc;
-    ISO_HIP_CHECK(hipMemcpy(d_ts.p, tile_shared.data(), nt * 4, hipMemcpyHostToDevice));
-    ISO_HIP_CHECK(hipMemcpy(d_ids.p, lane_ids.data(), nt * 64 * 4, hipMemcpyHostToDevice));
-    ISO_HIP_CHECK(hipMemcpy(d_k.p, lane_k.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+    ISO_HIP_CHECK(copy_h2d(d_ts.p, tile_shared.data(), nt * 4));
+    ISO_HIP_CHECK(copy_h2d(d_ids.p, lane_ids.data(), nt * 64 * 4));
+    ISO_HIP_CHECK(copy_h2d(d_k.p, lane_k.data(), nt * 64 * 4));
     tm.start();
     hipLaunchKernelGGL(k_ed_band_tiles<W>, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, 0, S, d_ts.as<uint32_t>(),
                        d_ids.as<uint32_t>(), d_k.as<int32_t>(), d_out.as<int32_t>(), (uint32_t)nt);
     ISO_HIP_CHECK(hipGetLastError());
     tm.stop();
-    ISO_HIP_CHECK(hipMemcpy(out.data(), d_out.p, nt * 64 * 4, hipMemcpyDeviceToHost));
+    ISO_HIP_CHECK(copy_d2h(out.data(), d_out.p, nt * 64 * 4));
     return ISOCON_OK;
 }
 
@@ -273,9 +324,9 @@ int run_full(isocon_store *st, const std::vector<uint32_t> &a, const std::vector
     DevBuf d_a(&st->pool, SLOT_FULL_A), d_b(&st->pool, SLOT_FULL_B), d_k(&st->pool, SLOT_FULL_K), d_out(&st->pool, SLOT_FULL_OUT);
     int rc;
     if ((rc = d_a.alloc(np * 4)) || (rc = d_b.alloc(np * 4)) || (rc = d_k.alloc(np * 4)) || (rc = d_out.alloc(np * 4))) return rc;
-    ISO_HIP_CHECK(hipMemcpy(d_a.p, a.data(), np * 4, hipMemcpyHostToDevice));
-    ISO_HIP_CHECK(hipMemcpy(d_b.p, b.data(), np * 4, hipMemcpyHostToDevice));
-    ISO_HIP_CHECK(hipMemcpy(d_k.p, k.data(), np * 4, hipMemcpyHostToDevice));
+    ISO_HIP_CHECK(copy_h2d(d_a.p, a.data(), np * 4));
+    ISO_HIP_CHECK(copy_h2d(d_b.p, b.data(), np * 4));
+    ISO_HIP_CHECK(copy_h2d(d_k.p, k.data(), np * 4));
     bool multipass = false;
     int32_t maxtext = 0;
     for (size_t p = 0; p < np; ++p) {
@@ -292,7 +343,7 @@ int run_full(isocon_store *st, const std::vector<uint32_t> &a, const std::vector
                        d_k.as<int32_t>(), d_out.as<int32_t>(), (uint32_t)np);
     ISO_HIP_CHECK(hipGetLastError());
     tm.stop();
-    ISO_HIP_CHECK(hipMemcpy(out.data(), d_out.p, np * 4, hipMemcpyDeviceToHost));
+    ISO_HIP_CHECK(copy_d2h(out.data(), d_out.p, np * 4));
     return ISOCON_OK;
 }
 

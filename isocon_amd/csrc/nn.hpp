@@ -183,6 +183,33 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParam
     nn_flush_acc(P, acc);
 }
 
+// Keeps the hits that can still matter: distance == best[endpoint] at the end of the launch (best only decreases), and
+// the -2 markers.  In place is not possible (unordered appends), so the survivors go to a second list.
+__global__ __launch_bounds__(256) void k_filter_hits(const int32_t *__restrict__ hits, unsigned long long n_hits, const int32_t *__restrict__ best,
+                                                      int32_t *__restrict__ out, unsigned long long *out_count)
+{
+    const int lane = threadIdx.x & 63;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * 256; base < n_hits; base += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long i = base + threadIdx.x;
+        int32_t e = 0, o = 0, d = -1;
+        bool keep = false;
+        if (i < n_hits) {
+            e = hits[i * 3]; o = hits[i * 3 + 1]; d = hits[i * 3 + 2];
+            keep = d == -2 || d == best[e];
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (!mask) continue;
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned long long at = 0;
+        if (lane == leader) at = atomicAdd(out_count, (unsigned long long)__popcll(mask));
+        at = __shfl(at, leader, 64);
+        if (keep) {
+            int32_t *h = out + (at + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull))) * 3;
+            h[0] = e; h[1] = o; h[2] = d;
+        }
+    }
+}
+
 // planes2[chunk][newpos] = planes[chunk][perm[newpos]]  (16 B per element; used to group similar sequences of equal length)
 // Main pass with LANE REFILL.  One workgroup per entry q with q's match masks tabulated in LDS, and the 64 lanes of a
 // wave as independent pair processors: every lane carries its own neighbour, band origin, column position and table
