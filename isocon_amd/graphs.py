@@ -1,0 +1,54 @@
+"""Nearest-neighbour graph construction on top of the MI355X NN search.
+
+Mirror of /root/reference/modules/graphs.py:29-82 (`construct_exact_nearest_neighbor_graph`): same signature, same
+node/edge attributes (`degree`, `edit_distance`), same "already converged" handling.  The all-pairs alignment behind it
+runs on the GPU through isocon_amd.nearest_neighbor_graph; everything else is bookkeeping on the host, as in the
+reference.  The graph container is networkx.DiGraph, which the reference's callers expect (requirements.txt:3).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+
+from . import nearest_neighbor_graph
+
+
+def _nx():
+    try:
+        import networkx as nx
+    except ImportError as e:      # the reference depends on it as well
+        raise ImportError("isocon_amd.graphs needs networkx (the reference's graph container)") from e
+    return nx
+
+
+def construct_exact_nearest_neighbor_graph(S, params):
+    """graphs.py:29-82.  S: {acc: seq} (not necessarily unique).  Returns (G, converged): a node per unique sequence
+    with weight `degree` = multiplicity; an edge s1 -> s2 (attribute `edit_distance`) for every nearest neighbour s2 of
+    a sequence s1 of multiplicity 1."""
+    nx = _nx()
+    predicted_seq_to_acc = defaultdict(list)
+    for acc, seq in S.items():
+        predicted_seq_to_acc[seq].append(acc)
+
+    converged = True
+    G = nx.DiGraph()
+    has_converged = set()
+    for seq, list_acc in predicted_seq_to_acc.items():
+        deg = len(list_acc)
+        G.add_node(seq, degree=deg)
+        if deg > 1:
+            has_converged.add(seq)
+        if deg == 1:
+            converged = False
+    if converged:
+        return G, converged
+
+    unique_strings = {seq: acc for acc, seq in S.items()}          # last accession of a sequence wins (graphs.py:56)
+    S_prime = {acc: seq for seq, acc in unique_strings.items()}
+    edges, _isolated = nearest_neighbor_graph.compute_nearest_neighbor_graph(S_prime, has_converged, params)
+    for s1_acc in edges:
+        s1 = S[s1_acc]
+        if G.nodes[s1]["degree"] > 1:
+            continue
+        for s2_acc, ed in edges[s1_acc].items():
+            G.add_edge(s1, S[s2_acc], edit_distance=ed)
+    return G, converged

@@ -1,0 +1,118 @@
+"""Partition of the nearest-neighbour graph into consensus-centre neighbourhoods.
+
+Mirror of /root/reference/modules/partitions.py:301-413 (`get_partitions_no_copy`) and :416-593 (`partition_strings`).
+The reference walks Python sets of strings, so its visiting order depends on PYTHONHASHSEED; its RESULT is
+order-independent except when two different reachable sets tie in weight.  This restatement works on integer ids and
+is deterministic: candidates are ranked by (weight of the reachable set, number of direct in-neighbours, sequence) and
+all members of a strongly connected top set compete as its representative.  tests/golden/g7_partitions.json holds
+outputs of the reference itself (eight hash seeds, all agreeing) that this module must reproduce.
+"""
+from __future__ import annotations
+
+from . import graphs
+
+
+def _reach(start, succ, alive):
+    """Nodes reachable from `start` along `succ` inside `alive` (iterative DFS), start included."""
+    seen = {start}
+    stack = [start]
+    while stack:
+        v = stack.pop()
+        for w in succ[v]:
+            if w in alive and w not in seen:
+                seen.add(w)
+                stack.append(w)
+    return seen
+
+
+def partition_ids(n, degree, edges, names):
+    """Core of get_partitions_no_copy on integer ids.
+
+    n nodes, degree[i] = multiplicity, edges = [(a, b)]: a's nearest neighbour is b (an edge of G*; the search runs on
+    the transpose, b -> a), names[i] = the sequence (only used to break ties the way the reference does, `m < centre`).
+    Returns [(centre, weight, members)] in the reference's extraction order (components by size, largest first)."""
+    rank = [0] * n                       # position of the sequence in sorted order: compares like the strings, in O(1)
+    for r, v in enumerate(sorted(range(n), key=lambda v: names[v])):
+        rank[v] = r
+    succ_t = [[] for _ in range(n)]      # transpose: b -> a   (who points at me)
+    succ_g = [[] for _ in range(n)]      # G*: a -> b
+    for a, b in edges:
+        succ_t[b].append(a)
+        succ_g[a].append(b)
+
+    # weakly connected components in first-node order, then by size (stable), partitions.py:306-307
+    comp_of = [-1] * n
+    comps = []
+    for s in range(n):
+        if comp_of[s] >= 0:
+            continue
+        cid = len(comps)
+        comp_of[s] = cid
+        members = [s]
+        stack = [s]
+        while stack:
+            v = stack.pop()
+            for w in succ_t[v] + succ_g[v]:
+                if comp_of[w] < 0:
+                    comp_of[w] = cid
+                    members.append(w)
+                    stack.append(w)
+        comps.append(members)
+    comps.sort(key=len, reverse=True)
+
+    out = []
+    for members in comps:
+        alive = set(members)
+        while alive:
+            order = sorted(alive, key=rank.__getitem__)
+            processed = set()
+            best = None            # (weight, nbrs, name, node, reach)
+            for m in order:
+                if m in processed:
+                    continue       # reachable from an earlier start: its own reachable set is a subset of that one
+                reach = _reach(m, succ_t, alive)
+                processed |= reach
+                weight = sum(degree[v] for v in reach)
+                # every node that reaches the same set (the strongly connected top of it) may stand for it
+                top = reach & _reach(m, succ_g, alive)
+                rep = min(top, key=lambda v: (-sum(1 for w in succ_t[v] if w in alive), rank[v]))
+                key = (-weight, -sum(1 for w in succ_t[rep] if w in alive), rank[rep])
+                if best is None or key < best[0]:
+                    best = (key, reach, weight)
+            _, reach, weight = best
+            # the centre: largest direct weight (own multiplicity + direct in-neighbours), then smallest sequence
+            centre = min(reach, key=lambda v: (-(degree[v] + sum(1 for w in succ_t[v] if w in alive)), rank[v]))
+            out.append((centre, weight, reach - {centre}))
+            alive -= reach
+    return out
+
+
+def get_partitions_no_copy(G_transpose):
+    """partitions.py:301-413.  G_transpose: networkx.DiGraph (edge centre -> follower), node attribute `degree`.
+    Returns (M, partition): M[centre] = total weight, partition[centre] = set of the other sequences.  Unlike the
+    reference the input graph is left untouched."""
+    names = list(G_transpose.nodes())
+    idx = {s: i for i, s in enumerate(names)}
+    degree = [G_transpose.nodes[s]["degree"] for s in names]
+    edges = [(idx[b], idx[a]) for a, b in G_transpose.edges()]      # transpose edge a -> b  <=>  G* edge b -> a
+    M, partition = {}, {}
+    for centre, weight, members in partition_ids(len(names), degree, edges, names):
+        M[names[centre]] = weight
+        partition[names[centre]] = set(names[v] for v in members)
+    return M, partition
+
+
+def partition_strings(S, params):
+    """partitions.py:416-593.  Returns (G_star, partition, M, converged)."""
+    import networkx as nx
+    G_star, converged = graphs.construct_exact_nearest_neighbor_graph(S, params)
+    unique_start_strings = set(G_star.nodes())
+    G_transpose = nx.reverse(G_star)
+    M, partition = get_partitions_no_copy(G_transpose)
+    partition_sequences = set()
+    for m in partition:
+        partition_sequences.add(m)
+        partition_sequences.update(partition[m])
+    assert unique_start_strings == partition_sequences
+    assert sum(len(partition[p]) + 1 for p in partition) == len(unique_start_strings)
+    return G_star, partition, M, converged

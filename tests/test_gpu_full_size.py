@@ -79,3 +79,32 @@ def test_c3_alignments_roundtrip(c3):
         x = sum(1 for x, y in zip(a1, a2) if x != y and x != "-" and y != "-")
         assert (m, x, len(a1) - m - x) == tuple(res[p, 3:6])
         assert x + (len(a1) - m - x) >= best[q[p]]          # an alignment cannot beat the edit distance
+
+
+def test_c3_partitions_cover_and_follow_the_graph(c3):
+    """partition_strings at full size (config C3 asks for the partitions): every unique string in exactly one
+    partition, weights add up, partitions are connected pieces of the nearest-neighbour graph, deterministic."""
+    from isocon_amd import partitions
+
+    class P(object):
+        nr_cores = 1; neighbor_search_depth = 2 ** 32; verbose = False; develop_logfile = None
+
+    seqs = c3[0]
+    S = {"read_%d" % i: s for i, s in enumerate(seqs[::5])}          # 10 k reads keep the Python dict work short
+    S.update({"dup_%d" % i: s for i, s in enumerate(seqs[::500])})  # some multiplicity-2 ("converged") strings
+    G, partition, M, converged = partitions.partition_strings(S, P())
+    assert not converged
+    members = [m for c in partition for m in partition[c]] + list(partition)
+    assert len(members) == len(set(members)) == len(set(S.values()))
+    assert sum(M.values()) == len(S)
+    for c in list(partition)[:50]:            # a partition is one connected piece of the nearest-neighbour graph
+        comp = set(partition[c]) | {c}
+        seen, stack = {c}, [c]
+        while stack:
+            v = stack.pop()
+            for w in list(G.successors(v)) + list(G.predecessors(v)):
+                if w in comp and w not in seen:
+                    seen.add(w); stack.append(w)
+        assert seen == comp
+    G2, partition2, M2, _ = partitions.partition_strings(dict(reversed(list(S.items()))), P())
+    assert partition2 == partition and M2 == M
