@@ -1,0 +1,34 @@
+"""Emulates the N-rank sharded NN search on ONE GPU: the ranks' phases are run one after the other and the min-reductions
+are done on the host.  Prints, per world size, the summed lane-columns (work inflation from the staler thresholds) and
+the largest per-rank kernel time of each phase (what an N-GPU step would wait for)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from isocon_amd import synth, _lib
+from isocon_amd.store import SeqStore, nn_finalize
+accs, seqs, _ = synth.make_reads(50000, 2500, 10, 30001)
+seqs = sorted(dict.fromkeys(seqs), key=len)
+st = SeqStore(seqs)
+n = st.n
+b0, rp0, c0, s0 = st.nn_graph()
+print("single: kernel %.1f ms lane-cols %.3g pairs %.4g" % (s0["kernel_ms"], s0["cells_columns"], s0["pairs_evaluated"]))
+for world in (2, 4, 8):
+    best = np.full(n, _lib.NN_INF, dtype=np.int32)
+    tot_cols = 0; tot_pairs = 0; crit = 0.0; walls = []
+    hits_all = []
+    for phase in (0, 1, 2):
+        bests = []; kms = []
+        for r in range(world):
+            b = best.copy()
+            t = time.time(); hits, stats = st.nn_partial(r, n, phase, b, q_stride=world); walls.append(time.time() - t)
+            bests.append(b); kms.append(stats["kernel_ms"]); tot_cols += stats["cells_columns"]; tot_pairs += stats["pairs_evaluated"]
+            hits_all.append(hits)
+        best = np.minimum.reduce(bests)
+        crit += max(kms)
+        print("  world %d phase %d: per-rank kernel ms max %.2f mean %.2f; call wall max %.2f ms" % (world, phase, max(kms), np.mean(kms), 1e3 * max(walls[-world:])))
+    hits = np.concatenate(hits_all)
+    keep = (hits[:, 2] >= 0) & (hits[:, 2] == best[hits[:, 0]])
+    out = nn_finalize(n, best, hits[keep])
+    ok = (out[0] == b0).all() and (out[1] == rp0).all() and (out[2] == c0).all()
+    print("world %d: graph identical %s; sum lane-cols %.3g (x%.3f of single), pairs %.4g; critical-path kernel time %.1f ms" %
+          (world, ok, tot_cols, tot_cols / s0["cells_columns"], tot_pairs, crit))

@@ -136,3 +136,17 @@ def test_empty_store_and_single_entry():
     st1 = SeqStore(["ACGTACGT"])
     best, rp, cols, _ = st1.nn_graph()
     assert best.tolist() == [-1] and rp.tolist() == [0, 0]
+
+
+def test_tile_synchronous_main_pass_still_matches(monkeypatch):
+    """ISOCON_NN_TILES=1 selects the tile-synchronous LDS kernel (+ equal-length regrouping): the fallback for reads too
+    long for the lane-refill kernel's LDS layout must stay exact."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    monkeypatch.setenv("ISOCON_NN_TILES", "1")
+    accs, seqs, _ = synth.make_reads(700, 900, 4, seed=21)
+    S = dict(zip(accs, seqs))
+    g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
