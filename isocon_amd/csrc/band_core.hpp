@@ -113,30 +113,42 @@ ISO_HD void band_init(BandLane<W> &L, int32_t nv /* = -a0 */, int32_t bstar)
 template <int W>
 ISO_HD void band_step_eq(BandLane<W> &L, const uint64_t (&EQ)[W])
 {
-    uint64_t D0[W], HP[W], HN[W];
-    uint64_t carry = 0;
+    // Words are processed in order, and word i-1 is finished as soon as word i's D0 is known (its bit 0 is the bit
+    // shifted into word i-1): only one word's D0 / HP / HN is live at a time, whatever W is.
+    uint64_t carry = 0, d0p = 0, hpp = 0, hnp = 0;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
         const uint64_t eq = EQ[i];
         const uint64_t vp = L.VP[i], vn = L.VN[i];
         const uint64_t x = eq & vp;
         uint64_t s = x + vp;
-        uint64_t c = s < x;
-        if (W > 1) { const uint64_t s2 = s + carry; c |= (s2 < s); s = s2; carry = c; }
-        D0[i] = (s ^ vp) | eq | vn;
-        HP[i] = or_nor(vn, D0[i], vp);
-        HN[i] = D0[i] & vp;
-    }
-    L.ztop += (uint32_t)D0[0] & 1u;
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-        uint64_t d0s = (D0[i] >> 1) | ((i + 1 < W) ? (D0[(i + 1 < W) ? i + 1 : i] << 63) : 0);
+        if (W > 1) {
+            uint64_t c = s < x;
+            const uint64_t s2 = s + carry;
+            c |= (s2 < s);
+            s = s2;
+            carry = c;
+        }
+        const uint64_t d0 = (s ^ vp) | eq | vn;
+        if (i == 0) L.ztop += (uint32_t)d0 & 1u;
+        if (i > 0) {
+            uint64_t d0s = (d0p >> 1) | (d0 << 63);
 #if defined(__HIP_DEVICE_COMPILE__)
-        asm("" : "+v"(d0s));             // one 64-bit shift feeding both uses (else the halves get re-derived)
+            asm("" : "+v"(d0s));             // one 64-bit shift feeding both uses (else the halves get re-derived)
 #endif
-        L.VP[i] = or_nor(HN[i], d0s, HP[i]);
-        L.VN[i] = d0s & HP[i];
+            L.VP[i - 1] = or_nor(hnp, d0s, hpp);
+            L.VN[i - 1] = d0s & hpp;
+        }
+        hpp = or_nor(vn, d0, vp);
+        hnp = d0 & vp;
+        d0p = d0;
     }
+    uint64_t d0s = d0p >> 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(d0s));
+#endif
+    L.VP[W - 1] = or_nor(hnp, d0s, hpp);
+    L.VN[W - 1] = d0s & hpp;
 }
 
 // One text column.  NL/NH = ~pattern bit-planes of the current window (wave-uniform), VM = valid-row mask

@@ -48,7 +48,7 @@ struct ScratchPool {
 
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
-    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2,
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB, SLOT_COUNT
 };
 static_assert(SLOT_COUNT <= 48, "ScratchPool::slots too small");

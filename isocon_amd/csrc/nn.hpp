@@ -443,6 +443,254 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     nn_flush_acc(P, acc);
 }
 
+// The same lane-refill search with a 64*W-row band (W = 2, 4, 8; thresholds up to 127 / 255 / 511): the wide-band phase
+// for entries whose nearest neighbour is further than 63 edits (ONT-like error rates).  Differences from the 64-row
+// kernel: a column's match vector is 2W dwords of the base's plane (entries e', e'+32, ..., W ds_read2_b32), the band
+// state is W words with a carry chain (band_step_eq<W>), the final-diagonal mask is rebuilt from its bit index at the
+// 32-column checks instead of living in 2W registers, and the column loop is unrolled by text dword (8 columns) to
+// keep the code inside the instruction cache.  Bank-phase alignment, virtual columns, nibble texts, neighbour queue:
+// exactly as above.  LDS: 4 planes x (m + 192 W) dwords + (128 W + 32) dwords of ones.
+template <int W>
+__device__ __forceinline__ int32_t diag_value_w(const BandLane<W> &L, int32_t nv, int32_t cols, int32_t bstar)
+{
+    int32_t v = nv + cols - (int32_t)L.ztop;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const int32_t b = bstar - 64 * i;
+        const uint64_t lm = b <= 0 ? 0 : (b >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << b) - 1));
+        v += popc64(L.VP[i] & lm) - popc64(L.VN[i] & lm);
+    }
+    return v;
+}
+
+template <int NWAVES, int W>
+__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill_wide(DevStore S, NNParams P, const uint32_t *__restrict__ text, uint32_t text_stride,
+                                                                      uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t tile_begin)
+{
+    static_assert(W == 2 || W == 4 || W == 8, "wide-band kernel");
+    constexpr int ROWS = 64 * W;
+    extern __shared__ uint32_t tw[];
+    __shared__ uint32_t s_next;
+    __shared__ uint32_t s_ring[NWAVES][NN_RING][2];
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+    const int32_t wave = threadIdx.x >> 6;
+    const int32_t lane = threadIdx.x & 63;
+    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)blockIdx.x * q_stride;
+    if (q64 >= (uint64_t)q_end) return;
+    const uint32_t q = (uint32_t)q64;
+    const int32_t m = S.lens[q];
+    const int64_t pbase = (int64_t)q + 1 + (int64_t)tile_begin * 64;
+    if (pbase >= (int64_t)S.n || pbase - (int64_t)q > (int64_t)P.depth || S.lens[pbase] - m > P.kcap) return;   // uniform
+    const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
+    if (!q_isq && !q_ist) return;
+    const int32_t E = (m + 192 * W + 31) & ~31;          // plane length in dwords
+    {
+        const uint64_t *planes = S.planes;
+        const uint32_t nseq = S.n;
+        const int32_t nchunks = (int32_t)S.nchunks;
+        auto chunk_lo = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2] : 0; };
+        auto chunk_hi = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2 + 1] : 0; };
+        for (int32_t e = threadIdx.x; e < E; e += NWAVES * 64) {
+            const int32_t o = e - (ROWS + 31);           // entry 32 + (ROWS - 1) <-> bit offset 0
+            const uint32_t lo = (uint32_t)stream64(chunk_lo, o), hi = (uint32_t)stream64(chunk_hi, o);
+            const int32_t r0 = o < 0 ? -o : 0, r1 = (m - o) < 32 ? (m - o) : 32;       // valid rows [r0, r1)
+            uint32_t v = 0;
+            if (r1 > r0) v = (r1 >= 32 ? 0xffffffffu : ((1u << r1) - 1u)) & ~(r0 >= 32 ? 0xffffffffu : ((1u << r0) - 1u));
+            tw[e] = ~lo & ~hi & v;
+            tw[E + e] = lo & ~hi & v;
+            tw[2 * E + e] = ~lo & hi & v;
+            tw[3 * E + e] = lo & hi & v;
+        }
+        for (int32_t e = threadIdx.x; e < 128 * W + 32; e += NWAVES * 64) tw[4 * E + e] = 0xffffffffu;
+        if (threadIdx.x == 0) s_next = 0;
+    }
+    __syncthreads();
+    const uint32_t tbase0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)tw;
+    const uint32_t idle_blk = tbase0 + (uint32_t)(lane & 31) * 4u;
+    uint32_t plane_bytes;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(plane_bytes) : "s"((uint32_t)E * 4u));
+    uint32_t(*ring)[2] = s_ring[wave];
+    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
+
+    bool run = false, upd_s = false, upd_l = false;
+    uint32_t tid = q, blk = idle_blk, nsh = 0;
+    int32_t n_t = 0, k_eff = -1, nv = 0, col = 0, bstar = 0;
+    uint32_t cur[5] = {0, 0, 0, 0, 0};
+    const uint32_t *tp = text;
+    BandLane<W> L;
+#pragma unroll
+    for (int i = 0; i < W; ++i) { L.VP[i] = ~(uint64_t)0; L.VN[i] = 0; }
+    L.ztop = 0;
+    uint32_t qhead = 0, qcount = 0;
+    bool exhausted = false;
+    uint32_t n_pairs = 0, n_batches = 0, n_blocks = 0, n_live = 0;
+
+    auto load5 = [](const uint32_t *p, uint32_t (&d)[5]) {
+        const TextQuad t4 = *reinterpret_cast<const TextQuad *>(p);
+        d[0] = t4.x; d[1] = t4.y; d[2] = t4.z; d[3] = t4.w; d[4] = p[4];
+    };
+    // the 2W dwords of one column: plane address a (entries e', e'+32, ..) -- second base register beyond 255 dwords
+    auto fetch = [](uint32_t a, int off, uint64_t (&EQ)[W]) {
+        lds_u32 *p0 = (lds_u32 *)(uintptr_t)a;
+        lds_u32 *p1 = (lds_u32 *)(uintptr_t)(a + 1024u);
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            lds_u32 *pp = i < 4 ? p0 : p1;
+            const int o = off + 64 * (i & 3);
+            EQ[i] = ((uint64_t)pp[o + 32] << 32) | pp[o];
+        }
+    };
+
+    for (;;) {
+        const uint64_t freemask = __ballot(!run);
+        const uint32_t nfree = (uint32_t)__popcll(freemask);
+        while (!exhausted && qcount < nfree && qcount + 64 <= (uint32_t)NN_RING) {
+            uint32_t c0 = 0;
+            if (lane == 0) c0 = atomicAdd(&s_next, 64u);
+            c0 = (uint32_t)uniform_i32((int32_t)c0);
+            const int64_t p = pbase + (int64_t)c0 + lane;
+            const bool inr = p < (int64_t)S.n && p - (int64_t)q <= (int64_t)P.depth;
+            const uint32_t pid = inr ? (uint32_t)p : q;
+            const int32_t np = S.lens[pid];
+            const bool within = inr && np - m <= P.kcap;
+            if (__ballot(within) != ~(uint64_t)0) exhausted = true;
+            const bool us = within && q_isq && P.tflag[pid];
+            const bool ul = within && q_ist && P.qflag[pid];
+            int32_t bs = NN_INF;
+            if (q_isq) bs = uniform_i32(load_relaxed_agent(P.best + q));
+            int32_t ks = -1, kl = -1;
+            if (us) ks = bs < m ? bs : m;
+            if (ul) { const int32_t bl = load_relaxed_agent(P.best + pid); kl = bl < np ? bl : np; }
+            int32_t k = ks > kl ? ks : kl;
+            if (k > P.kcap) k = P.kcap;
+            const int32_t d = m - np, ad = d < 0 ? -d : d;
+            bool accept = within && k >= 0 && ad <= k;
+            const bool triv = accept && (m == 0 || np == 0);
+            if (__ballot(triv) != 0) {
+                bool hs = false, hl = false;
+                if (triv && ad >= P.min_d) {
+                    if (us && ad <= m) { const int32_t old = atomicMin(P.best + q, ad); hs = ad <= old; }
+                    if (ul && ad <= np) { const int32_t old = atomicMin(P.best + pid, ad); hl = ad <= old; }
+                }
+                nn_append(P, hs, (int32_t)q, (int32_t)pid, ad);
+                nn_append(P, hl, (int32_t)pid, (int32_t)q, ad);
+                accept = accept && !triv;
+            }
+            const uint64_t am = __ballot(accept);
+            if (accept) {
+                const uint32_t slot = (qhead + qcount + (uint32_t)__popcll(am & lt_mask)) % (uint32_t)NN_RING;
+                int32_t a0 = lane_emin(d, k);
+                if (a0 < -(ROWS - 1)) a0 = -(ROWS - 1);
+                ring[slot][0] = pid | (us ? 0x40000000u : 0u) | (ul ? 0x80000000u : 0u);
+                ring[slot][1] = (uint32_t)np | ((uint32_t)k << 14) | ((uint32_t)(-a0) << 23);      // 14 + 9 + 9 bits
+            }
+            qcount += (uint32_t)__popcll(am);
+            n_pairs += (uint32_t)__popcll(am);
+            n_batches += 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (nfree && qcount) {
+            const uint32_t rank = (uint32_t)__popcll(freemask & lt_mask);
+            if (!run && rank < qcount) {
+                const uint32_t slot = (qhead + rank) % (uint32_t)NN_RING;
+                const uint32_t e0w = ring[slot][0], e1w = ring[slot][1];
+                tid = e0w & 0x3fffffffu;
+                upd_s = (e0w >> 30) & 1u;
+                upd_l = (e0w >> 31) & 1u;
+                n_t = (int32_t)(e1w & 0x3fffu);
+                k_eff = (int32_t)((e1w >> 14) & 511u);
+                nv = (int32_t)(e1w >> 23);
+                bstar = m - n_t + nv;                        // in [0, ROWS - 1]
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const int32_t lo = nv - 64 * i;
+                    const uint64_t vp = lo <= 0 ? ~(uint64_t)0 : (lo >= 64 ? 0 : (~(uint64_t)0 << lo));
+                    L.VP[i] = vp;
+                    L.VN[i] = ~vp;
+                }
+                const uint32_t e0 = (uint32_t)(ROWS - 1 - nv);
+                const uint32_t phi = (e0 - (uint32_t)lane) & 31u;
+                L.ztop = 0u - phi;
+                col = -(int32_t)phi;
+                blk = tbase0 + (32u + e0 - phi) * 4u;
+                nsh = 4u * ((32u - phi) & 7u);
+                tp = text + (size_t)tid * text_stride + ((32u - phi) >> 3);
+                load5(tp, cur);
+                run = true;
+            }
+            const uint32_t taken = nfree < qcount ? nfree : qcount;
+            qhead = (qhead + taken) % (uint32_t)NN_RING;
+            qcount -= taken;
+        }
+        const uint64_t runmask = __ballot(run);
+        if (runmask == 0) {
+            if (exhausted && qcount == 0) break;
+            continue;
+        }
+        uint32_t w0 = __builtin_amdgcn_alignbit(cur[1], cur[0], nsh), w1 = __builtin_amdgcn_alignbit(cur[2], cur[1], nsh),
+                 w2 = __builtin_amdgcn_alignbit(cur[3], cur[2], nsh), w3 = __builtin_amdgcn_alignbit(cur[4], cur[3], nsh);
+        if (run && col + 32 < n_t) load5(tp + 4, cur);
+        if (__ballot(run && col + 32 > n_t) == 0) {
+            uint32_t a_blk = blk;
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {
+                // 8 columns of one text dword; W = 8 keeps this a real loop (unrolled, its 16 dwords of Eq per column
+                // in flight for several columns push the kernel over 128 VGPRs and into scratch)
+#pragma unroll(W == 8 ? 1 : 8)
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(w0, 4 * u, 3);
+                    uint64_t EQ[W];
+                    if (W == 8) fetch(__umul24(code, plane_bytes) + a_blk + (uint32_t)u * 4u, 0, EQ);
+                    else fetch(__umul24(code, plane_bytes) + a_blk, u, EQ);
+                    band_step_eq<W>(L, EQ);
+                }
+                w0 = w1; w1 = w2; w2 = w3;
+                a_blk += 32u;
+            }
+        } else {
+            uint32_t a_blk = blk;
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll 1
+                for (int u = 0; u < 8; ++u) {
+                    if (run && col + g * 8 + u < n_t) {
+                        const uint32_t code = (w0 >> (4 * u)) & 7u;
+                        uint64_t EQ[W];
+                        fetch(code * plane_bytes + a_blk + (uint32_t)u * 4u, 0, EQ);
+                        band_step_eq<W>(L, EQ);
+                    }
+                }
+                w0 = w1; w1 = w2; w2 = w3;
+                a_blk += 32u;
+            }
+        }
+        n_blocks += 1;
+        n_live += (uint32_t)__popcll(runmask);
+        col += 32;
+        const bool fin = run && col >= n_t;
+        const int32_t dv = diag_value_w<W>(L, nv, fin ? n_t : col, bstar);
+        int32_t r = -1;
+        if (fin) { r = dv <= k_eff ? dv : -1; run = false; }
+        else if (run && dv > k_eff) run = false;
+        if (__ballot(fin && r >= P.min_d) != 0) {
+            bool hs = false, hl = false;
+            if (fin && r >= P.min_d) {
+                if (upd_s && r <= m) { const int32_t old = atomicMin(P.best + q, r); hs = r <= old; }
+                if (upd_l && r <= n_t) { const int32_t old = atomicMin(P.best + tid, r); hl = r <= old; }
+            }
+            nn_append(P, hs, (int32_t)q, (int32_t)tid, r);
+            nn_append(P, hl, (int32_t)tid, (int32_t)q, r);
+        }
+        blk += 128u;
+        tp += 4;
+        if (!run) blk = idle_blk;
+    }
+    WaveAcc acc;
+    acc.pairs = n_pairs; acc.tiles = n_batches; acc.cols = (unsigned long long)n_blocks * 2048ull; acc.live = (unsigned long long)n_live * 32ull;
+    nn_flush_acc(P, acc);
+}
+
 // Nibble store for k_nn_scan_refill: row i = [4 dwords of code 4][ceil(len_i / 8) dwords, base j at bits 4(j%8)..][zeros].
 __global__ __launch_bounds__(256) void k_build_nibble_text(DevStore S, uint32_t *__restrict__ text, uint32_t text_stride)
 {

@@ -13,3 +13,4 @@ st = SeqStore(seqs)
 t = time.time(); best, rp, cols, stats = st.nn_graph(); dt = time.time() - t
 print("nn_graph wall %.2f s" % dt, stats)
 print("best: median %.0f  max %d  rows empty %d" % (np.median(best[best >= 0]), best.max(), (best < 0).sum()))
+print("checksum best %d edges %d cols-sum %d" % (int(best.astype(np.int64).sum()), len(cols), int(cols.astype(np.int64).sum())))
