@@ -150,3 +150,20 @@ def test_tile_synchronous_main_pass_still_matches(monkeypatch):
     g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
     g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
     assert ordered(g_gpu) == ordered(g_cpu)
+
+
+@pytest.mark.parametrize("length,rate,lo,hi", [(650, 0.08, 64, 127), (1300, 0.08, 128, 255), (2600, 0.08, 256, 511)])
+def test_wide_band_refill_kernels(length, rate, lo, hi):
+    """NN distances in (63, 127], (127, 255], (255, 511]: the 128-, 256- and 512-row lane-refill kernels vs the oracle."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    prof = dict(synth.ONT_PROFILE, rate=rate)
+    accs, seqs, _ = synth.make_reads(160, length, 2, seed=length, profile=prof)
+    S = dict(zip(accs, seqs))
+    g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
+    d = sorted(v for nb in g_cpu.values() for v in nb.values())
+    assert lo <= d[len(d) // 2] <= hi, d[len(d) // 2]          # the case really sits in the intended band
+    assert NNG.LAST_STATS["fallback_queries"] > 0
