@@ -469,6 +469,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill_wide(DevStore S,
 {
     static_assert(W == 2 || W == 4 || W == 8, "wide-band kernel");
     constexpr int ROWS = 64 * W;
+    constexpr int UNROLL_COLS = W == 8 ? 1 : 8;
     extern __shared__ uint32_t tw[];
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_ring[NWAVES][NN_RING][2];
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill_wide(DevStore S,
             for (int g = 0; g < 4; ++g) {
                 // 8 columns of one text dword; W = 8 keeps this a real loop (unrolled, its 16 dwords of Eq per column
                 // in flight for several columns push the kernel over 128 VGPRs and into scratch)
-#pragma unroll(W == 8 ? 1 : 8)
+#pragma unroll UNROLL_COLS
                 for (int u = 0; u < 8; ++u) {
                     const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(w0, 4 * u, 3);
                     uint64_t EQ[W];

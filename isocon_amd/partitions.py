@@ -87,14 +87,14 @@ def partition_ids(n, degree, edges, names):
     return out
 
 
-def get_partitions_no_copy(G_transpose):
-    """partitions.py:301-413.  G_transpose: networkx.DiGraph (edge centre -> follower), node attribute `degree`.
-    Returns (M, partition): M[centre] = total weight, partition[centre] = set of the other sequences.  Unlike the
-    reference the input graph is left untouched."""
-    names = list(G_transpose.nodes())
+def _partition_graph(G, transposed):
+    names = list(G.nodes())
     idx = {s: i for i, s in enumerate(names)}
-    degree = [G_transpose.nodes[s]["degree"] for s in names]
-    edges = [(idx[b], idx[a]) for a, b in G_transpose.edges()]      # transpose edge a -> b  <=>  G* edge b -> a
+    degree = [G.nodes[s]["degree"] for s in names]
+    if transposed:
+        edges = [(idx[b], idx[a]) for a, b in G.edges()]      # transpose edge a -> b  <=>  G* edge b -> a
+    else:
+        edges = [(idx[a], idx[b]) for a, b in G.edges()]
     M, partition = {}, {}
     for centre, weight, members in partition_ids(len(names), degree, edges, names):
         M[names[centre]] = weight
@@ -102,13 +102,18 @@ def get_partitions_no_copy(G_transpose):
     return M, partition
 
 
+def get_partitions_no_copy(G_transpose):
+    """partitions.py:301-413.  G_transpose: networkx.DiGraph (edge centre -> follower), node attribute `degree`.
+    Returns (M, partition): M[centre] = total weight, partition[centre] = set of the other sequences.  Unlike the
+    reference the input graph is left untouched."""
+    return _partition_graph(G_transpose, True)
+
+
 def partition_strings(S, params):
     """partitions.py:416-593.  Returns (G_star, partition, M, converged)."""
-    import networkx as nx
     G_star, converged = graphs.construct_exact_nearest_neighbor_graph(S, params)
     unique_start_strings = set(G_star.nodes())
-    G_transpose = nx.reverse(G_star)
-    M, partition = get_partitions_no_copy(G_transpose)
+    M, partition = _partition_graph(G_star, False)      # same result as on nx.reverse(G_star), without the deep copy
     partition_sequences = set()
     for m in partition:
         partition_sequences.add(m)

@@ -123,7 +123,8 @@ class SeqStore(object):
         mm = np.ascontiguousarray(np.broadcast_to(np.asarray(mismatch, dtype=np.int8), (n,)))
         res = np.zeros((max(n, 1), 6), dtype=np.int32)
         ops_ptr = np.zeros(n + 1, dtype=np.uint64)
-        cap = max(64 * n, 1024)
+        tot = int((self.lens[a].astype(np.int64) + self.lens[b]).sum()) if n else 0
+        cap = max(64 * n + tot // 4, 1024)     # generous: a too-small buffer means running the batch again
         needed = ctypes.c_uint64(0)
         ms = ctypes.c_float(0)
         while True:
@@ -148,8 +149,10 @@ def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ret
     res = np.zeros((max(n, 1), 6), dtype=np.int32)
     ops_ptr = np.zeros(n + 1, dtype=np.uint64)
     aln_ptr = np.zeros(n + 1, dtype=np.uint64)
-    ops_cap = max(64 * n, 1024)
-    aln_cap = int((self.lens[a] + self.lens[b]).sum() // 2 + 64 * n + 1024) if n else 1024
+    # generous first guesses (untouched pages of np.empty cost nothing): a too-small buffer means running the batch again
+    tot = int((self.lens[a].astype(np.int64) + self.lens[b]).sum()) if n else 0
+    ops_cap = max(64 * n + tot // 4, 1024)
+    aln_cap = tot + 1024                      # an alignment is never longer than both sequences together
     need_ops, need_aln = ctypes.c_uint64(0), ctypes.c_uint64(0)
     while True:
         ops = np.empty(ops_cap, dtype=np.uint32)
