@@ -52,3 +52,16 @@ def construct_exact_nearest_neighbor_graph(S, params):
         for s2_acc, ed in edges[s1_acc].items():
             G.add_edge(s1, S[s2_acc], edit_distance=ed)
     return G, converged
+
+
+def construct_exact_2set_nearest_neighbor_bipartite_graph(X, C, X_file, C_file, params):
+    """graphs.py:150-160.  X: {read_acc: seq}, C: {cand_acc: seq} (X_file / C_file are unused by the reference as well).
+    Returns the bipartite DiGraph read -> nearest candidate(s): node attribute `bipartite` = 0 (reads, every read, also
+    those without a candidate in reach) / 1 (candidates that are somebody's nearest neighbour)."""
+    nx = _nx()
+    best_exact_matches = nearest_neighbor_graph.compute_2set_nearest_neighbor_graph(X, C, params)
+    G = nx.DiGraph()
+    G.add_nodes_from(best_exact_matches.keys(), bipartite=0)
+    G.add_nodes_from(set(c for x in best_exact_matches for c in best_exact_matches[x]), bipartite=1)
+    G.add_edges_from((x, c) for x in best_exact_matches for c in best_exact_matches[x])
+    return G

@@ -121,3 +121,26 @@ def partition_strings(S, params):
     assert unique_start_strings == partition_sequences
     assert sum(len(partition[p]) + 1 for p in partition) == len(unique_start_strings)
     return G_star, partition, M, converged
+
+
+def partition_strings_2set(X, C, X_file, C_file, params):
+    """partitions.py:595-647: greedy assignment of reads to candidates on the bipartite NN graph -- the candidate with
+    the most supporting reads takes all of them (ties: the smallest accession, `max(sorted(...))` in the reference),
+    they leave the graph, repeat until no candidate is left.  Reads with no candidate in reach end up in no partition.
+    Returns (G_star, partition) with partition[cand_acc] = set(read_acc); G_star is left untouched."""
+    G_star = graphs.construct_exact_2set_nearest_neighbor_bipartite_graph(X, C, X_file, C_file, params)
+    support = {}                       # candidate -> set of reads still pointing at it
+    of_read = {}
+    for x, c in G_star.edges():
+        support.setdefault(c, set()).add(x)
+        of_read.setdefault(x, set()).add(c)
+    partition = {}
+    while support:
+        m = min(support, key=lambda c: (-len(support[c]), c))
+        reads = support.pop(m)
+        partition[m] = set(reads)
+        for x in reads:                # the reads leave the graph: they no longer support their other candidates
+            for c in of_read[x]:
+                if c != m and c in support:
+                    support[c].discard(x)
+    return G_star, partition

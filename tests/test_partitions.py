@@ -92,3 +92,28 @@ def test_gpu_partition_strings(case):
     S = dict(case["S"])
     G, partition, M, converged = partitions.partition_strings(S, Params())
     assert canon(unique_ids(S), partition, M, converged, G) == case["expect"]
+
+
+G9 = json.load(open(os.path.join(HERE, "golden", "g9_partitions_2set.json")))
+
+
+def canon2(G, partition):
+    return {"partition": sorted([c, sorted(m)] for c, m in partition.items()), "edges": sorted([a, b] for a, b in G.edges()),
+            "nodes": sorted(G.nodes())}
+
+
+@pytest.mark.parametrize("case", G9["cases"], ids=[c["name"] for c in G9["cases"]])
+def test_partition_strings_2set_with_the_oracle_search(case, monkeypatch):
+    from isocon_amd import graphs, partitions
+    from oracle import oracle as O
+    monkeypatch.setattr(graphs, "nearest_neighbor_graph", O)
+    G, partition = partitions.partition_strings_2set(dict(case["X"]), dict(case["C"]), None, None, Params())
+    assert canon2(G, partition) == case["expect"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G9["cases"], ids=[c["name"] for c in G9["cases"]])
+def test_gpu_partition_strings_2set(case):
+    from isocon_amd import partitions
+    G, partition = partitions.partition_strings_2set(dict(case["X"]), dict(case["C"]), None, None, Params())
+    assert canon2(G, partition) == case["expect"]
