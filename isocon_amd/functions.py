@@ -74,3 +74,164 @@ def filter_exon_differences(pairwise_alignments, min_exon_diff, ignore_ends_len)
             del pairwise_alignments[s1][s2]
             filtered.add(s2)
     return filtered
+
+
+# ---- multi-alignment of a partition around its centre -----------------------------------------
+# Mirror of /root/reference/modules/functions.py:526-799 (create_position_frequency_matrix, create_multialignment_matrix,
+# position_query_to_alignment, get_best_solution, create_multialignment_format_NEW, min_ed).  Same column layout as the
+# reference: for every centre base one column, and in front of / behind every base one insertion slot that is 1 column
+# wide unless some read inserts >= 2 bases there, in which case it is len(longest insertion) + 2 columns wide and every
+# other insertion is placed inside it by get_best_solution.  The matrix is built as a numpy uint8 array (the reference
+# builds dicts of character lists); `create_multialignment_matrix` converts it to the reference's shape.
+
+def nw_path_cigar(query, target):
+    """Extended CIGAR of one optimal global unit-cost alignment -- stands where the reference calls
+    edlib.align(query, target, task="path", mode="NW") (functions.py:772).  Which optimum edlib reports is pinned by
+    nothing in the reference ("parity unpinned"); backtracking from the end this prefers a query-only step ('I'), then
+    a target-only step ('D'), then the diagonal -- the same rule as the stand-in the golden fixtures were made with."""
+    n, m = len(query), len(target)
+    D = [[0] * (m + 1) for _ in range(n + 1)]
+    for i in range(1, n + 1):
+        D[i][0] = i
+    for j in range(1, m + 1):
+        D[0][j] = j
+    for i in range(1, n + 1):
+        qi, Di, Dp = query[i - 1], D[i], D[i - 1]
+        for j in range(1, m + 1):
+            best = Dp[j - 1] + (qi != target[j - 1])
+            if Dp[j] + 1 < best:
+                best = Dp[j] + 1
+            if Di[j - 1] + 1 < best:
+                best = Di[j - 1] + 1
+            Di[j] = best
+    ops = []
+    i, j = n, m
+    while i > 0 or j > 0:
+        if i > 0 and D[i - 1][j] + 1 == D[i][j]:
+            ops.append("I"); i -= 1
+        elif j > 0 and D[i][j - 1] + 1 == D[i][j]:
+            ops.append("D"); j -= 1
+        else:
+            ops.append("=" if query[i - 1] == target[j - 1] else "X"); i -= 1; j -= 1
+    ops.reverse()
+    return ops
+
+
+def min_ed(max_insertion, q_ins):
+    """functions.py:771-799: thread q_ins into max_insertion along an optimal alignment that deletes nothing from
+    max_insertion; "" if the reported optimum needs such a deletion."""
+    ops = nw_path_cigar(max_insertion, q_ins)
+    if "D" in ops:
+        return ""
+    out, k = [], 0
+    for op in ops:
+        if op == "I":
+            out.append("-")
+        else:
+            out.append(q_ins[k]); k += 1
+    return "".join(out)
+
+
+def get_best_solution(max_insertion, q_ins):
+    """functions.py:635-676: the columns of q_ins inside the (padded) longest insertion of its slot."""
+    L = len(max_insertion)
+    if q_ins == "-":
+        return ["-"] * L
+    pos = max_insertion.find(q_ins)
+    if pos >= 0:
+        return list("-" * pos + max_insertion[pos:pos + len(q_ins)] + "-" * (L - pos - len(q_ins)))
+    threaded = min_ed(max_insertion, q_ins)
+    if threaded:
+        return list(threaded)
+    max_p, max_matches = 0, 0
+    for p in range(0, L - len(q_ins) + 1):
+        nr = sum(1 for c1, c2 in zip(q_ins, max_insertion[p:p + len(q_ins)]) if c1 == c2)
+        if nr > max_matches:
+            max_p, max_matches = p, nr
+    if max_p > 0:
+        return list("-" * max_p + q_ins + "-" * (L - max_p - len(q_ins)))
+    return [q_ins[p] if p < len(q_ins) else "-" for p in range(L)]
+
+
+def position_query_to_alignment(query_aligned, target_aligned, target_alignment_start_position):
+    """functions.py:598-631: (list of 2*len(target)+1 entries: insertion string or '-' on even, aligned character on odd
+    positions; first vector position; last vector position)."""
+    out, ins, t = [], [], target_alignment_start_position
+    for qc, tc in zip(query_aligned, target_aligned):
+        if tc == "-":
+            ins.append(qc)
+        else:
+            out.append("".join(ins) if ins else "-")
+            ins = []
+            out.append(qc)
+            t += 1
+    out.append("".join(ins) if ins else "-")
+    return out, 2 * target_alignment_start_position, 2 * (t - 1) + 2
+
+
+def msa_matrix(m, partition):
+    """(keys, M): keys = list(partition) and M = uint8 [len(keys), columns] multi-alignment matrix (ASCII, '-' = 45)
+    with the reference's column layout (see above)."""
+    keys = list(partition)
+    nr, Lm = len(keys), len(m)
+    A = np.empty((nr, Lm), dtype=np.uint8)                # character aligned to every centre base
+    slot_ins = {}                                         # slot t (before centre base t; Lm = after the last) -> {row: insertion}
+    for r, s in enumerate(keys):
+        _, m_aln, s_aln, _ = partition[s]
+        a = np.frombuffer(m_aln.encode(), dtype=np.uint8)
+        b = np.frombuffer(s_aln.encode(), dtype=np.uint8)
+        tmask = a != 45
+        if int(tmask.sum()) != Lm:
+            raise ValueError("alignment does not spell the centre")
+        A[r] = b[tmask]
+        ins_cols = np.flatnonzero(~tmask)
+        if len(ins_cols):
+            slots = np.cumsum(tmask)[ins_cols]            # centre bases in front of the inserted character
+            first = np.flatnonzero(np.diff(slots, prepend=-1))          # a run of inserted characters shares its slot
+            c0 = ins_cols[first].tolist()
+            c1 = (ins_cols[np.append(first[1:] - 1, len(ins_cols) - 1)] + 1).tolist()
+            for t, a0, a1 in zip(slots[first].tolist(), c0, c1):
+                slot_ins.setdefault(t, {})[r] = s_aln[a0:a1]
+    width = np.ones(Lm + 1, dtype=np.int64)
+    max_ins = {}
+    for t, rows in slot_ins.items():
+        longest = max(len(x) for x in rows.values())
+        if longest > 1:
+            max_ins[t] = "-" + sorted(x for x in rows.values() if len(x) == longest)[0] + "-"
+            width[t] = longest + 2
+    col_slot = np.zeros(Lm + 1, dtype=np.int64)           # first column of slot t; the base column of t follows the slot
+    col_slot[1:] = np.cumsum(width[:-1] + 1)
+    ncols = int(width.sum()) + Lm
+    M = np.full((nr, ncols), 45, dtype=np.uint8)
+    M[:, col_slot[:Lm] + width[:Lm]] = A
+    cache = {}
+    for t, rows in slot_ins.items():
+        c0 = int(col_slot[t])
+        if t in max_ins:
+            mx = max_ins[t]
+            for r, ins in rows.items():
+                sol = cache.get((mx, ins))
+                if sol is None:
+                    sol = cache[(mx, ins)] = np.frombuffer("".join(get_best_solution(mx, ins)).encode(), dtype=np.uint8)
+                M[r, c0:c0 + len(mx)] = sol
+        else:
+            for r, ins in rows.items():
+                M[r, c0] = ord(ins)
+    return keys, M
+
+
+def create_multialignment_matrix(m, partition):
+    """functions.py:543-588: {sequence: [column characters]} for the partition {s: (ed, m_alignment, s_alignment, degree)}."""
+    keys, M = msa_matrix(m, partition)
+    return {s: list(M[r].tobytes().decode()) for r, s in enumerate(keys)}
+
+
+def create_position_frequency_matrix(alignment_matrix, partition):
+    """functions.py:526-536: per column {'A','C','G','T','-'} -> summed degrees."""
+    nr_columns = len(alignment_matrix[next(iter(alignment_matrix))])
+    PFM = [{"A": 0, "C": 0, "G": 0, "T": 0, "-": 0} for _ in range(nr_columns)]
+    for s, row in alignment_matrix.items():
+        deg = partition[s][3]
+        for j, nucl in enumerate(row):
+            PFM[j][nucl] += deg
+    return PFM

@@ -18,3 +18,11 @@ if len(sys.argv) > 2:
     pr = cProfile.Profile(); pr.enable()
     G, part, M, conv = partitions.partition_strings(S, P()); ex = set(); pa = IGC.get_partition_alignments(part, M, G, ex, P())
     pr.disable(); pstats.Stats(pr).sort_stats("cumtime").print_stats(25)
+from isocon_amd import correction_module as COR
+seq_to_acc = IGC.get_unique_seq_accessions(S)
+t0 = time.time(); S_prime, _ = COR.correct_strings(pa, seq_to_acc, {}, 1); t1 = time.time()
+changed = sum(1 for a, s in S_prime.items() if S[a] != s)
+print("correct_strings %.2f s (%d accessions returned, %d changed)" % (t1 - t0, len(S_prime), changed))
+if len(sys.argv) > 3:
+    pr = cProfile.Profile(); pr.enable(); COR.correct_strings(pa, seq_to_acc, {}, 1); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)

@@ -1,0 +1,79 @@
+"""Consensus correction against outputs of the reference's own correction_module / functions
+(tests/golden/g11_correction.json): multi-alignment matrices (width + digest) and corrected sequences (digests)."""
+import hashlib
+import json
+import os
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G7 = {c["name"]: c for c in json.load(open(os.path.join(HERE, "golden", "g7_partitions.json")))["cases"]}
+G11 = json.load(open(os.path.join(HERE, "golden", "g11_correction.json")))["cases"]
+
+
+class Params(object):
+    nr_cores = 1
+    neighbor_search_depth = 2 ** 32
+    verbose = False
+    develop_logfile = None
+    min_exon_diff = 20
+    ignore_ends_len = 15
+
+
+def sha(s):
+    return hashlib.sha1(s.encode()).hexdigest()[:16]
+
+
+def run_chain(S):
+    from isocon_amd import correction_module as COR
+    from isocon_amd import functions as FUN
+    from isocon_amd import isocon_get_candidates as IGC
+    from isocon_amd import partitions
+    G, partition, M, converged = partitions.partition_strings(S, Params())
+    pa = IGC.get_partition_alignments(partition, M, G, set(), Params())
+    seq_to_acc = IGC.get_unique_seq_accessions(S)
+    S_prime, qual = COR.correct_strings(pa, seq_to_acc, {}, 1, nr_cores=1, verbose=False)
+    assert qual == {}
+    uid = {}
+    for seq in S.values():
+        uid.setdefault(seq, len(uid))
+    msa = []
+    for m in sorted(pa, key=lambda x: uid[x]):
+        if len(pa[m]) > 1:
+            am = FUN.create_multialignment_matrix(m, pa[m])
+            msa.append([uid[m], len(am[m]), sha("".join("".join(am[s]) for s in sorted(am, key=lambda x: uid[x])))])
+    return {"S_prime": sorted([acc, sha(s), len(s)] for acc, s in S_prime.items()), "msa": msa}
+
+
+def test_insertion_placement_rules():
+    from isocon_amd import functions as FUN
+    assert FUN.get_best_solution("-GACG-", "-") == list("------")
+    assert FUN.get_best_solution("-GACG-", "AC") == list("--AC--")            # substring: placed where it occurs
+    assert FUN.get_best_solution("-GACG-", "AG") == list("--A-G-")            # threaded along an alignment without deletions
+    assert FUN.min_ed("-GA-", "C") == "C---"
+    vec, a, b = FUN.position_query_to_alignment("AC-GTT", "A-CG-T", 0)
+    assert vec == ["-", "A", "C", "-", "-", "G", "T", "T", "-"] and (a, b) == (0, 8)
+
+
+def test_pfm_counts_degrees():
+    from isocon_amd import functions as FUN
+    am = {"x": list("AC-"), "y": list("AG-")}
+    pfm = FUN.create_position_frequency_matrix(am, {"x": (0, "", "", 3), "y": (1, "", "", 1)})
+    assert pfm[0]["A"] == 4 and pfm[1] == {"A": 0, "C": 3, "G": 1, "T": 0, "-": 0} and pfm[2]["-"] == 4
+
+
+@pytest.mark.parametrize("case", [c for c in G11 if c["name"] != "synth_300x600_4iso_dups"], ids=[c["name"] for c in G11 if c["name"] != "synth_300x600_4iso_dups"])
+def test_correction_with_the_oracle_kernels(case, monkeypatch):
+    from isocon_amd import graphs
+    from isocon_amd import isocon_get_candidates as IGC
+    from oracle import oracle as O
+    monkeypatch.setattr(graphs, "nearest_neighbor_graph", O)
+    monkeypatch.setattr(IGC, "edlib_align_sequences", O.edlib_align_sequences)
+    monkeypatch.setattr(IGC, "sw_align_sequences", O.sw_align_sequences)
+    assert run_chain(dict(G7[case["name"]]["S"])) == case["expect"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G11, ids=[c["name"] for c in G11])
+def test_gpu_correction_chain(case):
+    assert run_chain(dict(G7[case["name"]]["S"])) == case["expect"]
