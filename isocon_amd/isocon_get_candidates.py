@@ -38,3 +38,109 @@ def get_partition_alignments(graph_partition, M, G_star, exon_filtered, params):
             aln_m, aln_s, (matches, mismatches, indels) = exact_alignments[m][s]
             partition_alignments[m][s] = (mismatches + indels, aln_m, aln_s, 1)
     return partition_alignments
+
+
+def _log(message, logfile):
+    if logfile is not None:
+        logfile.write(message + "\n")
+
+
+def find_candidate_transcripts(read_file, params):
+    """isocon_get_candidates.py:85-312: the candidate-inference phase -- read the reads, then partition / align / correct
+    until the reads have converged, name the resulting candidates, and align every read to its candidate.
+
+    params: .is_fastq .nr_cores .neighbor_search_depth .min_exon_diff .ignore_ends_len .min_candidate_support .outfolder
+    .verbose (.logfile / .develop_logfile optional).  Writes candidates_step_<k>.fa, candidates_converged.fa and an empty
+    not_converged.fa into params.outfolder like the reference and returns (candidates_file_name, read_partition,
+    to_realign).  Not provided: the collapse of candidates that differ only in their ends (end_invariant_functions, an
+    edlib HW-mode path outside SURVEY 8's scope) -- params.ignore_ends_len must be 0 here; and the CCS quality variant
+    the reference has switched off."""
+    import os
+
+    from . import correction_module, partitions
+    from .SW_alignment_module import sw_align_sequences_keeping_accession
+    from .edlib_alignment_module import edlib_align_sequences_keeping_accession
+    from .input_output import fasta_parser, fastq_parser
+
+    if params.ignore_ends_len > 0:
+        raise NotImplementedError("collapse_candidates_under_ends_invariant is outside this build: run with ignore_ends_len = 0")
+
+    def read_all():
+        with open(read_file, "r") as fh:
+            if params.is_fastq:
+                return {acc: seq for (acc, seq, qual) in fastq_parser.readfq(fh)}
+            return {acc: seq for (acc, seq) in fasta_parser.read_fasta(fh)}
+
+    S = read_all()
+    logfile = getattr(params, "logfile", None)
+    step = 1
+    exon_filtered = set()
+    seq_to_acc = get_unique_seq_accessions(S)
+    G_star, graph_partition, M, converged = partitions.partition_strings(S, params)
+    partition_alignments = get_partition_alignments(graph_partition, M, G_star, exon_filtered, params)
+    _log("nearest_neighbors and partition, step 1 done", logfile)
+
+    two_steps_ago = [2 ** 28, 2 ** 28, 2 ** 28]          # guards against 2-cycles
+    previous = [2 ** 28]
+    while not converged:
+        edit_distances = sorted(t[0] for inner in partition_alignments.values() for t in inner.values())
+        if two_steps_ago == edit_distances:              # reads alternating between two equally good centres
+            break
+        if sum(edit_distances) > sum(previous) and max(edit_distances) > max(previous):
+            break                                        # getting worse: corrected and re-corrected reads
+        if all(ed == 0 for ed in edit_distances):
+            break                                        # nothing left to correct (isolated nodes remain)
+        S_prime, _ = correction_module.correct_strings(partition_alignments, seq_to_acc, {}, step, nr_cores=params.nr_cores,
+                                                       verbose=params.verbose)
+        for acc, s_prime in S_prime.items():
+            S[acc] = s_prime
+        seq_to_acc = get_unique_seq_accessions(S)
+        step += 1
+        S_to_align = {acc: seq for acc, seq in S.items() if seq not in exon_filtered}
+        G_star, graph_partition, M, converged = partitions.partition_strings(S_to_align, params)
+        partition_alignments = get_partition_alignments(graph_partition, M, G_star, exon_filtered, params)
+        with open(os.path.join(params.outfolder, "candidates_step_" + str(step) + ".fa"), "w") as out_file:
+            for i, m in enumerate(partition_alignments):
+                N_t = sum(t[3] for t in partition_alignments[m].values())
+                out_file.write(">{0}\n{1}\n".format("read" + str(i) + "_support_" + str(N_t), m))
+        two_steps_ago = previous
+        previous = edit_distances
+        _log("correction, nearest_neighbors and partition, step {0} done".format(step), logfile)
+
+    # candidates = the distinct corrected sequences, supported by the reads that became identical to them
+    c_seq_to_read_acc = {}
+    for read_acc, seq in S.items():
+        c_seq_to_read_acc.setdefault(seq, []).append(read_acc)
+    c_acc_to_seq, c_acc_to_support = {}, {}
+    for i, m in enumerate(sorted(c_seq_to_read_acc)):
+        N_t = partition_alignments[m][m][3] if m in partition_alignments else 1
+        c_acc = "transcript_" + str(i) + "_support_" + str(N_t)
+        c_acc_to_seq[c_acc] = m
+        c_acc_to_support[c_acc] = N_t
+
+    original_reads = read_all()
+    assert len(S) == len(original_reads)
+    for c_acc in list(c_acc_to_seq.keys()):
+        if c_acc_to_support[c_acc] < params.min_candidate_support:
+            del c_seq_to_read_acc[c_acc_to_seq[c_acc]]
+            del c_acc_to_seq[c_acc]
+            del c_acc_to_support[c_acc]
+    assigned = set(read_acc for c_seq in c_seq_to_read_acc for read_acc in c_seq_to_read_acc[c_seq])
+    to_realign = {read_acc: original_reads[read_acc] for read_acc in set(original_reads.keys()) - assigned}
+
+    candidates_file_name = os.path.join(params.outfolder, "candidates_converged.fa")
+    with open(candidates_file_name, "w") as fh:
+        for c_acc, c_seq in sorted(c_acc_to_seq.items()):
+            fh.write(">{0}\n{1}\n".format(c_acc, c_seq))
+    open(os.path.join(params.outfolder, "not_converged.fa"), "w").close()
+    assert len(to_realign) + len(assigned) == len(original_reads)
+
+    c_to_reads = {}
+    for c_acc, c_seq in c_acc_to_seq.items():
+        c_to_reads[c_acc] = {read_acc: (c_seq, original_reads[read_acc]) for read_acc in c_seq_to_read_acc[c_seq]}
+    c_to_reads_edit_distances = edlib_align_sequences_keeping_accession(c_to_reads, nr_cores=params.nr_cores)
+    read_partition = sw_align_sequences_keeping_accession(c_to_reads_edit_distances, nr_cores=params.nr_cores)
+    filtered_reads = functions.filter_exon_differences(read_partition, params.min_exon_diff, params.ignore_ends_len)
+    for read_acc in filtered_reads:
+        to_realign[read_acc] = original_reads[read_acc]
+    return candidates_file_name, read_partition, to_realign

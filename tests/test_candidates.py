@@ -1,0 +1,76 @@
+"""The candidate-inference phase end to end (BASELINE config[0]: the reference's test data through the pipeline's first
+phase) against what the reference's own find_candidate_transcripts produces (tests/golden/g12_candidates.json,
+ignore_ends_len = 0): converged candidates, read -> candidate alignments, reads to realign, number of steps."""
+import glob
+import hashlib
+import json
+import os
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G12 = json.load(open(os.path.join(HERE, "golden", "g12_candidates.json")))["cases"]
+
+
+def sha(s):
+    return hashlib.sha1(s.encode()).hexdigest()[:16]
+
+
+def run(case, tmp_path):
+    from isocon_amd import isocon_get_candidates as IGC
+    read_file = tmp_path / "reads.fa"
+    read_file.write_text("".join(">%s\n%s\n" % (a, s) for a, s in case["S"]))
+
+    class Params(object):
+        nr_cores = 1
+        neighbor_search_depth = 2 ** 32
+        verbose = False
+        develop_logfile = None
+        logfile = None
+        min_exon_diff = 20
+        ignore_ends_len = 0
+        min_candidate_support = 2
+        is_fastq = False
+        ccs = None
+        outfolder = str(tmp_path)
+
+    cand_file, read_partition, to_realign = IGC.find_candidate_transcripts(str(read_file), Params())
+    cands, acc = [], None
+    for line in open(cand_file):
+        if line.startswith(">"):
+            acc = line[1:].strip()
+        else:
+            cands.append([acc, sha(line.strip()), len(line.strip())])
+    steps = 1 + len(glob.glob(os.path.join(str(tmp_path), "candidates_step_*.fa")))
+    rp = sorted([c, r, sha(t[0]), sha(t[1]), list(t[2])] for c in read_partition for r, t in read_partition[c].items())
+    return {"candidates": cands, "read_partition": rp, "to_realign": sorted(to_realign), "steps": steps}
+
+
+def test_end_invariant_collapse_is_refused(tmp_path):
+    from isocon_amd import isocon_get_candidates as IGC
+
+    class P(object):
+        ignore_ends_len = 15
+    with pytest.raises(NotImplementedError):
+        IGC.find_candidate_transcripts(str(tmp_path / "x.fa"), P())
+
+
+@pytest.mark.parametrize("case", [c for c in G12 if c["name"].startswith("synth")], ids=[c["name"] for c in G12 if c["name"].startswith("synth")])
+def test_candidate_inference_with_the_oracle_kernels(case, tmp_path, monkeypatch):
+    import isocon_amd.SW_alignment_module as SWM
+    import isocon_amd.edlib_alignment_module as EAM
+    from isocon_amd import graphs
+    from isocon_amd import isocon_get_candidates as IGC
+    from oracle import oracle as O
+    monkeypatch.setattr(graphs, "nearest_neighbor_graph", O)
+    monkeypatch.setattr(IGC, "edlib_align_sequences", O.edlib_align_sequences)
+    monkeypatch.setattr(IGC, "sw_align_sequences", O.sw_align_sequences)
+    monkeypatch.setattr(EAM, "edlib_align_sequences_keeping_accession", O.edlib_align_sequences_keeping_accession)
+    monkeypatch.setattr(SWM, "sw_align_sequences_keeping_accession", O.sw_align_sequences_keeping_accession)
+    assert run(case, tmp_path) == case["expect"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G12, ids=[c["name"] for c in G12])
+def test_gpu_candidate_inference(case, tmp_path):
+    assert run(case, tmp_path) == case["expect"]
