@@ -171,52 +171,68 @@ def position_query_to_alignment(query_aligned, target_aligned, target_alignment_
 
 def msa_matrix(m, partition):
     """(keys, M): keys = list(partition) and M = uint8 [len(keys), columns] multi-alignment matrix (ASCII, '-' = 45)
-    with the reference's column layout (see above)."""
+    with the reference's column layout (see above).  All rows are processed at once: the gapped strings are joined
+    into two byte arrays, the centre's non-gap columns give the aligned characters of every read by one boolean
+    index, and only the inserted characters (a percent of the cells) are looked at individually."""
     keys = list(partition)
     nr, Lm = len(keys), len(m)
-    A = np.empty((nr, Lm), dtype=np.uint8)                # character aligned to every centre base
-    slot_ins = {}                                         # slot t (before centre base t; Lm = after the last) -> {row: insertion}
-    for r, s in enumerate(keys):
-        _, m_aln, s_aln, _ = partition[s]
-        a = np.frombuffer(m_aln.encode(), dtype=np.uint8)
-        b = np.frombuffer(s_aln.encode(), dtype=np.uint8)
-        tmask = a != 45
-        if int(tmask.sum()) != Lm:
-            raise ValueError("alignment does not spell the centre")
-        A[r] = b[tmask]
-        ins_cols = np.flatnonzero(~tmask)
-        if len(ins_cols):
-            slots = np.cumsum(tmask)[ins_cols]            # centre bases in front of the inserted character
-            first = np.flatnonzero(np.diff(slots, prepend=-1))          # a run of inserted characters shares its slot
-            c0 = ins_cols[first].tolist()
-            c1 = (ins_cols[np.append(first[1:] - 1, len(ins_cols) - 1)] + 1).tolist()
-            for t, a0, a1 in zip(slots[first].tolist(), c0, c1):
-                slot_ins.setdefault(t, {})[r] = s_aln[a0:a1]
+    m_all = np.frombuffer("".join(partition[s][1] for s in keys).encode(), dtype=np.uint8)
+    s_all = np.frombuffer("".join(partition[s][2] for s in keys).encode(), dtype=np.uint8)
+    aln_len = np.fromiter((len(partition[s][1]) for s in keys), dtype=np.int64, count=nr)
+    if len(m_all) != len(s_all) or int(aln_len.sum()) != len(m_all):
+        raise ValueError("gapped strings of a pair differ in length")
+    tmask = m_all != 45
+    A = s_all[tmask]
+    if len(A) != nr * Lm:
+        raise ValueError("alignment does not spell the centre")
+    A = A.reshape(nr, Lm)                                  # character aligned to every centre base
+    # inserted characters: position in the joined array, row, slot (= centre bases of the row in front of it)
+    ins_pos = np.flatnonzero(~tmask)
+    row_start = np.zeros(nr + 1, dtype=np.int64)
+    np.cumsum(aln_len, out=row_start[1:])
+    ins_row = np.searchsorted(row_start, ins_pos, side="right") - 1
+    ins_slot = np.cumsum(tmask)[ins_pos] - ins_row * Lm
+    # runs of inserted characters = one insertion string each (same row, same slot, consecutive positions)
+    if len(ins_pos):
+        new_run = np.ones(len(ins_pos), dtype=bool)
+        new_run[1:] = (np.diff(ins_pos) != 1) | (np.diff(ins_row) != 0) | (np.diff(ins_slot) != 0)
+        first = np.flatnonzero(new_run)
+        run_len = np.diff(np.append(first, len(ins_pos)))
+        run_row, run_slot, run_pos = ins_row[first], ins_slot[first], ins_pos[first]
+    else:
+        run_len = run_row = run_slot = run_pos = np.zeros(0, dtype=np.int64)
+    # slot widths: 1, or longest + 2 where some read inserts >= 2 characters (functions.py:722-731)
     width = np.ones(Lm + 1, dtype=np.int64)
-    max_ins = {}
-    for t, rows in slot_ins.items():
-        longest = max(len(x) for x in rows.values())
-        if longest > 1:
-            max_ins[t] = "-" + sorted(x for x in rows.values() if len(x) == longest)[0] + "-"
-            width[t] = longest + 2
+    longest = np.zeros(Lm + 1, dtype=np.int64)
+    np.maximum.at(longest, run_slot, run_len)
+    wide_slots = np.flatnonzero(longest > 1)
+    width[wide_slots] = longest[wide_slots] + 2
     col_slot = np.zeros(Lm + 1, dtype=np.int64)           # first column of slot t; the base column of t follows the slot
     col_slot[1:] = np.cumsum(width[:-1] + 1)
     ncols = int(width.sum()) + Lm
     M = np.full((nr, ncols), 45, dtype=np.uint8)
     M[:, col_slot[:Lm] + width[:Lm]] = A
-    cache = {}
-    for t, rows in slot_ins.items():
-        c0 = int(col_slot[t])
-        if t in max_ins:
-            mx = max_ins[t]
-            for r, ins in rows.items():
-                sol = cache.get((mx, ins))
-                if sol is None:
-                    sol = cache[(mx, ins)] = np.frombuffer("".join(get_best_solution(mx, ins)).encode(), dtype=np.uint8)
-                M[r, c0:c0 + len(mx)] = sol
-        else:
-            for r, ins in rows.items():
-                M[r, c0] = ord(ins)
+    if len(run_len):
+        in_wide = longest[run_slot] > 1
+        # single characters in 1-column slots: one scatter
+        one = ~in_wide
+        M[run_row[one], col_slot[run_slot[one]]] = s_all[run_pos[one]]
+        # slots with a multi-character insertion: place every insertion inside the padded longest one
+        if in_wide.any():
+            s_bytes = s_all.tobytes()
+            by_slot = {}
+            for r, t, p0, ln in zip(run_row[in_wide].tolist(), run_slot[in_wide].tolist(), run_pos[in_wide].tolist(), run_len[in_wide].tolist()):
+                by_slot.setdefault(t, []).append((r, s_bytes[p0:p0 + ln].decode()))
+            cache = {}
+            for t, items in by_slot.items():
+                lg = int(longest[t])
+                mx = "-" + sorted(x for _, x in items if len(x) == lg)[0] + "-"
+                c0 = int(col_slot[t])
+                for r, ins in items:
+                    sol = cache.get((mx, ins))
+                    if sol is None:
+                        sol = cache[(mx, ins)] = np.frombuffer("".join(get_best_solution(mx, ins)).encode(), dtype=np.uint8)
+                    M[r, c0:c0 + len(mx)] = sol
     return keys, M
 
 
