@@ -167,3 +167,23 @@ def test_wide_band_refill_kernels(length, rate, lo, hi):
     d = sorted(v for nb in g_cpu.values() for v in nb.values())
     assert lo <= d[len(d) // 2] <= hi, d[len(d) // 2]          # the case really sits in the intended band
     assert NNG.LAST_STATS["fallback_queries"] > 0
+
+
+def test_hit_list_overflow_reruns_with_the_bounds_kept(monkeypatch):
+    """A hit list that is too small makes the phase run again (larger list, bounds kept): same graph."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    monkeypatch.setenv("ISOCON_HITS_CAP", "64")
+    accs, seqs, _ = synth.make_reads(500, 700, 3, seed=33)
+    S = dict(zip(accs, seqs))
+    g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert NNG.LAST_STATS["scan_launches"] >= 2
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
+    prof = dict(synth.ONT_PROFILE, rate=0.08)          # the same in the wide-band phase
+    accs, seqs, _ = synth.make_reads(120, 1300, 2, seed=34, profile=prof)
+    S = dict(zip(accs, seqs))
+    g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
