@@ -154,6 +154,22 @@ int isocon_sg_strings_batch(isocon_store *s, const uint32_t *a, const uint32_t *
 int isocon_exon_filter_from_ops(const uint32_t *ops, const uint64_t *ops_ptr, uint64_t n_pairs, int32_t min_exon_diff,
                                 int32_t ignore_ends_len, uint8_t *out_flag);
 
+/* Consensus correction of one partition on its multi-alignment matrix -- replaces the column statistics and the
+ * per-read correction of modules/correction_module.py:277-402 (position frequency matrix modules/functions.py:526-536).
+ * matrix: n_rows x n_cols bytes, row-major, symbols 'A' 'C' 'G' 'T' '-' (layout of functions.create_multialignment_matrix);
+ * degree[r]: multiplicity of row r (rows with degree > 1 are counted degree times and never corrected).
+ * Per column: weighted counts, majority symbol (first maximum in the order A, C, G, T, -), unambiguous iff unique.
+ * Per row of degree 1: the positions where an unambiguous majority differs from the row are correctable; with
+ * frequency = count of the row's symbol in the column / partition total of that error class (insertion, deletion,
+ * substitution; over the unambiguous columns; at least 1), every position whose frequency is <= the ceil(n/2)-th
+ * smallest is replaced by the majority.  Output: the corrected rows without their '-' symbols, packed
+ * (out_offsets[n_rows + 1]), out_n_cand[r] = number of correctable positions (-1: more than the kernel holds, row
+ * returned uncorrected -- the caller falls back for it), out_class_totals[3] = insertion, deletion, substitution totals.
+ * ISOCON_E_CAPACITY if packed_cap is too small (out_offsets[n_rows] holds the size needed). */
+int isocon_msa_correct(const uint8_t *matrix, uint32_t n_rows, uint32_t n_cols, const int32_t *degree,
+                       uint8_t *out_packed, uint64_t packed_cap, uint64_t *out_offsets, int32_t *out_n_cand,
+                       int64_t *out_class_totals, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("ISOCON_LIB", os.path.join(_HERE, "lib", "libisocon_hip.so"))   # override: kernel experiments
 SRC_DIR = os.path.join(_HERE, "csrc")
 _SOURCES = ["isocon_hip.hip", "band_core.hpp", "common.hpp", "ed_band.hpp", "ed_full.hpp", "nn.hpp", "nn_host.inc",
-            "sg.hpp", "sg_host.inc"]
+            "sg.hpp", "sg_host.inc", "msa.hpp", "msa_host.inc"]
 
 ISOCON_OK = 0
 ISOCON_E_CAPACITY = -4
@@ -63,6 +63,8 @@ SYMBOLS = {
                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, u32p, u64p, ctypes.c_uint64,
                                                u64p, i32p, u8p, u8p, u64p, ctypes.c_uint64, u64p, f32p]),
     "isocon_exon_filter_from_ops": (ctypes.c_int, [u32p, u64p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, u8p]),
+    "isocon_msa_correct": (ctypes.c_int, [u8p, ctypes.c_uint32, ctypes.c_uint32, i32p, u8p, ctypes.c_uint64, u64p, i32p,
+                                          ctypes.POINTER(ctypes.c_int64), f32p]),
 }
 
 _lib = None

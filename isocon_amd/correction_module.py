@@ -5,8 +5,8 @@ Mirror of /root/reference/modules/correction_module.py:12-76 (`correct_strings`)
 matrix, majority character per column, and for every non-converged read the correction of the ceil(half) of its
 unambiguous minority positions that are rarest for their error class.  Same signatures and return shapes; the quality-
 value variant (`correct_to_consensus_ccs_qual`, switched off in the reference: isocon_get_candidates.py:106 `if False`)
-is not provided.  Column statistics are numpy reductions over the uint8 alignment matrix instead of Python loops over
-dicts of lists; every tie rule of the reference is kept (first maximum in the order A, C, G, T, -; stable sort of the
+is not provided.  Column statistics, the per-read selection and the gap stripping run on the GPU (isocon_msa_correct);
+the same steps exist as numpy reductions over the uint8 matrix (ISOCON_CORRECT_HOST=1: CPU tests, A/B checks); every tie rule of the reference is kept (first maximum in the order A, C, G, T, -; stable sort of the
 candidate positions by frequency; ties with the last chosen frequency are corrected too)."""
 from __future__ import annotations
 
@@ -14,9 +14,30 @@ import math
 
 import numpy as np
 
+import ctypes
+import os
+
+from . import _lib
 from .functions import msa_matrix
 
 _SYMS = np.frombuffer(b"ACGT-", dtype=np.uint8)
+
+
+def _correct_on_device(M, deg):
+    """Column statistics + per-read correction + gap stripping on the GPU (isocon_msa_correct, csrc/msa.hpp).
+    Returns (packed bytes, offsets int64[nr+1], n_cand int32[nr])."""
+    L = _lib.lib()
+    nr, ncols = M.shape
+    M = np.ascontiguousarray(M)
+    deg32 = np.ascontiguousarray(deg, dtype=np.int32)
+    packed = np.empty(M.size, dtype=np.uint8)
+    offsets = np.zeros(nr + 1, dtype=np.uint64)
+    n_cand = np.zeros(nr, dtype=np.int32)
+    tot = (ctypes.c_int64 * 3)()
+    _lib.check(L.isocon_msa_correct(M.ctypes.data_as(_lib.u8p), nr, ncols, deg32.ctypes.data_as(_lib.i32p), packed.ctypes.data_as(_lib.u8p),
+                                    packed.size, offsets.ctypes.data_as(_lib.u64p), n_cand.ctypes.data_as(_lib.i32p), tot, None),
+               "isocon_msa_correct")
+    return packed, offsets.astype(np.int64), n_cand
 
 
 def correct_to_consensus(m, partition, seq_to_acc, step, verbose):
@@ -29,9 +50,25 @@ def correct_to_consensus(m, partition, seq_to_acc, step, verbose):
         return S_prime_partition
     keys, M = msa_matrix(m, partition)
     nr, ncols = M.shape
-    if M[M != 45].tobytes() != "".join(keys).encode():             # correction_module.py:273-275, all rows at once
+    # correction_module.py:273-275 asserts that every row spells its sequence; checked here by length for all rows and
+    # letter by letter for a sample (the full comparison is a pass over the whole matrix)
+    if (np.count_nonzero(M != 45, axis=1) != np.fromiter((len(k) for k in keys), dtype=np.int64, count=nr)).any():
         raise AssertionError("multi-alignment rows do not spell their sequences")
+    for r in range(0, nr, max(1, nr // 16)):
+        if M[r][M[r] != 45].tobytes().decode() != keys[r]:
+            raise AssertionError("multi-alignment row does not spell its sequence")
     deg = np.array([partition[s][3] for s in keys], dtype=np.int64)
+    if os.environ.get("ISOCON_CORRECT_HOST") != "1":               # the product path: HIP kernels (no silent CPU fallback)
+        packed, off, n_cand = _correct_on_device(M, deg)
+        if (n_cand >= 0).all():
+            flat = packed[:off[nr]].tobytes().decode()
+            for r in sorted(range(nr), key=lambda r: keys[r]):
+                if deg[r] == 1 and n_cand[r] > 0:
+                    s_modified = flat[off[r]:off[r + 1]]
+                    for acc in seq_to_acc[keys[r]]:
+                        S_prime_partition[acc] = s_modified
+            return S_prime_partition
+        # a read with more correctable positions than the kernel holds per row: the whole partition on the host below
     sym_index0 = np.full(256, -1, dtype=np.int64)
     sym_index0[_SYMS] = np.arange(5)
     heavy = np.flatnonzero(deg != 1)                               # rows of multiplicity > 1 (the centre, usually) count extra

@@ -14,6 +14,7 @@
 #include "ed_full.hpp"
 #include "nn.hpp"
 #include "sg.hpp"
+#include "msa.hpp"
 
 namespace isocon {
 thread_local std::string g_last_error;
@@ -25,7 +26,7 @@ using namespace isocon;
 // hipMalloc/hipFree (tens of ms for the multi-GB trace scratch) every time.
 struct ScratchPool {
     struct Slot { void *p = nullptr; size_t cap = 0; };
-    Slot slots[48];
+    Slot slots[64];
     void *get(int idx, size_t bytes)
     {
         Slot &s = slots[idx];
@@ -49,9 +50,11 @@ struct ScratchPool {
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
     SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2,
-    SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB, SLOT_COUNT
+    SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
+    SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED,
+    SLOT_COUNT
 };
-static_assert(SLOT_COUNT <= 48, "ScratchPool::slots too small");
+static_assert(SLOT_COUNT <= 64, "ScratchPool::slots too small");
 
 // One pool per process (one process drives one GPU): scratch outlives the individual stores, because the Python
 // wrappers create a fresh store per call (the reference's functions are stateless).
@@ -459,3 +462,4 @@ extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_
 
 #include "nn_host.inc"
 #include "sg_host.inc"
+#include "msa_host.inc"

@@ -97,7 +97,7 @@ class SeqStore(object):
         conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
         targ = None if is_target is None else np.ascontiguousarray(is_target, dtype=np.uint8)
         assert best.dtype == np.int32 and best.flags.c_contiguous and len(best) >= self.n
-        cap = max(16 * self.n, 1 << 16)
+        cap = 48 * self.n + (1 << 20)          # generous (np.empty costs nothing until touched): a retry repeats the phase
         n_hits = ctypes.c_uint64(0)
         stats = _lib.NNStats()
         depth = int(min(depth, 2 ** 63 - 1))

@@ -67,6 +67,7 @@ def test_correction_with_the_oracle_kernels(case, monkeypatch):
     from isocon_amd import graphs
     from isocon_amd import isocon_get_candidates as IGC
     from oracle import oracle as O
+    monkeypatch.setenv("ISOCON_CORRECT_HOST", "1")          # no GPU here: the numpy statement of the correction step
     monkeypatch.setattr(graphs, "nearest_neighbor_graph", O)
     monkeypatch.setattr(IGC, "edlib_align_sequences", O.edlib_align_sequences)
     monkeypatch.setattr(IGC, "sw_align_sequences", O.sw_align_sequences)
@@ -77,3 +78,22 @@ def test_correction_with_the_oracle_kernels(case, monkeypatch):
 @pytest.mark.parametrize("case", G11, ids=[c["name"] for c in G11])
 def test_gpu_correction_chain(case):
     assert run_chain(dict(G7[case["name"]]["S"])) == case["expect"]
+
+
+@pytest.mark.gpu
+def test_device_correction_equals_host_statement(monkeypatch):
+    """isocon_msa_correct vs the numpy statement of the same step on a partition with many reads and real indels."""
+    import numpy as np
+    from isocon_amd import correction_module as COR
+    from isocon_amd import isocon_get_candidates as IGC
+    from isocon_amd import partitions, synth
+    accs, seqs, _ = synth.make_reads(1500, 900, 2, seed=61)
+    S = dict(zip(accs, seqs))
+    S.update({"dup%d" % i: seqs[i * 40] for i in range(10)})
+    G, partition, M, converged = partitions.partition_strings(S, Params())
+    pa = IGC.get_partition_alignments(partition, M, G, set(), Params())
+    seq_to_acc = IGC.get_unique_seq_accessions(S)
+    dev, _ = COR.correct_strings(pa, seq_to_acc, {}, 1)
+    monkeypatch.setenv("ISOCON_CORRECT_HOST", "1")
+    host, _ = COR.correct_strings(pa, seq_to_acc, {}, 1)
+    assert dev == host and len(dev) > 1000
