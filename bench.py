@@ -282,12 +282,18 @@ def main():
             store.sg_trace(t[:64], q[:64], mm[:64])
             t0 = time.perf_counter(); ops, ptr, res, sw_ms = store.sg_trace(t, q, mm, return_ms=True); sw_wall = time.perf_counter() - t0
             cells = float((lens[t] * lens[q]).sum())
+            # the same batch with the pairs' edit distances as band hints (what sw_align_sequences passes down)
+            store.sg_trace(t[:64], q[:64], mm[:64], ed_upper=ed[:64])
+            t0 = time.perf_counter(); ops_b, ptr_b, res_b, swb_ms = store.sg_trace(t, q, mm, return_ms=True, ed_upper=ed); swb_wall = time.perf_counter() - t0
+            same = bool((res_b == res).all() and len(ops_b) == len(ops) and (ops_b == ops).all())
             result["other_kernels"] = {
                 "pairs": int(len(q)),
                 "ed_pairs_per_s_kernel": len(q) / (ed_ms / 1e3) if ed_ms > 0 else None, "ed_pairs_wall_ms": ed_wall * 1e3,
                 "sw_pairs_per_s_kernel": len(q) / (sw_ms / 1e3) if sw_ms > 0 else None, "sw_wall_ms": sw_wall * 1e3,
                 "sw_cell_updates_per_s": cells / (sw_ms / 1e3) if sw_ms > 0 else None,
-                "sw_trace_hbm_write_GBps": (cells / 2) / (sw_ms / 1e3) / 1e9 if sw_ms > 0 else None}
+                "sw_trace_hbm_write_GBps": (cells / 2) / (sw_ms / 1e3) / 1e9 if sw_ms > 0 else None,
+                "sw_banded_pairs_per_s_kernel": len(q) / (swb_ms / 1e3) if swb_ms > 0 else None, "sw_banded_wall_ms": swb_wall * 1e3,
+                "sw_banded_equals_full": same}
     except Exception as e:  # the headline line must still be printed
         result["other_kernels"] = {"error": repr(e)}
     if cpu is not None:

@@ -127,11 +127,15 @@ int isocon_nn_finalize(uint32_t n, const int32_t *best, const int32_t *hits, uin
  * bucket, :102-109).  tie_policy 0 = parasail's behaviour as restated in oracle/isocon_oracle.c.
  * Outputs: CIGAR ops as (len << 4 | code), code 0 '=', 1 'X', 2 'I' (consumes a), 3 'D' (consumes b);
  * out_ops_ptr[n_pairs+1]; out_res[6*p..] = score, end_query, end_ref, matches, mismatches, indels.
+ * ed_upper (may be NULL; entries < 0 = unknown): an upper bound of the pair's edit distance -- the reference's
+ * sw_align_sequences receives exactly that in its input dict (modules/SW_alignment_module.py:89-101).  It only
+ * narrows the part of the DP matrix that is computed; the result is always the full-matrix result: a banded alignment
+ * is accepted only if its score proves that nothing outside the band can reach it, otherwise the pair is redone in full.
  */
 int isocon_sg_trace_batch(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t match,
                           const int8_t *mismatch_per_pair, int32_t open, int32_t ext, int32_t tie_policy,
                           uint32_t *out_ops, uint64_t *out_ops_ptr, uint64_t ops_cap, uint64_t *n_ops_needed,
-                          int32_t *out_res, float *kernel_ms);
+                          int32_t *out_res, float *kernel_ms, const int32_t *ed_upper);
 
 /*
  * Same as isocon_sg_trace_batch plus the two gapped strings per pair (what cigar_to_seq builds from the CIGAR in the
@@ -143,7 +147,7 @@ int isocon_sg_strings_batch(isocon_store *s, const uint32_t *a, const uint32_t *
                             const int8_t *mismatch_per_pair, int32_t open, int32_t ext, int32_t tie_policy,
                             uint32_t *out_ops, uint64_t *out_ops_ptr, uint64_t ops_cap, uint64_t *n_ops_needed,
                             int32_t *out_res, uint8_t *out_aln_a, uint8_t *out_aln_b, uint64_t *out_aln_ptr,
-                            uint64_t aln_cap, uint64_t *n_aln_needed, float *kernel_ms);
+                            uint64_t aln_cap, uint64_t *n_aln_needed, float *kernel_ms, const int32_t *ed_upper);
 
 /*
  * Exon-difference filter on CIGAR ops (host-only helper, no GPU): out_flag[p] = 1 iff filter_exon_differences

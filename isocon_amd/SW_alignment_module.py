@@ -68,8 +68,10 @@ def ops_to_cigar(ops):
     return "".join("%d%s" % (op >> 4, _OPS[op & 15]) for op in ops)
 
 
-def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0):
-    """[(s1, s2)], per-pair mismatch penalties -> [(s1_aln, s2_aln, (matches, mismatches, indels))]."""
+def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0, ed_upper=None):
+    """[(s1, s2)], per-pair mismatch penalties -> [(s1_aln, s2_aln, (matches, mismatches, indels))].
+    ed_upper: the pairs' edit distances where the caller has them (they only narrow the computed part of the matrix;
+    the device re-aligns in full whatever it cannot certify, see include/isocon_hip.h)."""
     if not pairs:
         return []
     if any(len(s1) == 0 or len(s2) == 0 for s1, s2 in pairs):
@@ -78,7 +80,7 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0):
     try:
         aln_a, aln_b, ptr, res, ops, ops_ptr = st.sg_strings(a, b, np.asarray(mismatch, dtype=np.int8), match=match_score,
                                                              open_=opening_penalty, ext=gap_ext, tie_policy=TIE_POLICY,
-                                                             return_ops=True)
+                                                             return_ops=True, ed_upper=ed_upper)
     finally:
         if owned:
             st.close()
@@ -118,12 +120,22 @@ def _penalty(ed, s1, s2):
     return -4
 
 
+def _ed_hint(ed):
+    """The input edit distance as a band hint (-1 = none).  It is only a hint: the device certifies or redoes."""
+    try:
+        ed = int(ed)
+    except (TypeError, ValueError):
+        return -1
+    return ed if 0 <= ed < 2 ** 30 else -1
+
+
 def sw_align_sequences(matches, nr_cores=1, mismatch_penalty=-1):
     """SWM:89-164.  {s1: {s2: ed}} -> {s1: {s2: (s1_aln, s2_aln, (matches, mismatches, indels))}}."""
     pairs = [(s1, s2) for s1 in matches for s2 in matches[s1]]
     pens = [_penalty(matches[s1][s2], s1, s2) for s1, s2 in pairs]
+    eds = [_ed_hint(matches[s1][s2]) for s1, s2 in pairs]
     exact_matches = {}
-    for (s1, s2), stats in zip(pairs, _align_pairs(pairs, pens)):
+    for (s1, s2), stats in zip(pairs, _align_pairs(pairs, pens, ed_upper=eds)):
         if stats:
             exact_matches.setdefault(s1, {})[s2] = stats
     return exact_matches
@@ -134,8 +146,9 @@ def sw_align_sequences_keeping_accession(matches, nr_cores=1):
     keys = [(a1, a2) for a1 in matches for a2 in matches[a1]]
     pairs = [(matches[a1][a2][0], matches[a1][a2][1]) for a1, a2 in keys]
     pens = [_penalty(matches[a1][a2][2], matches[a1][a2][0], matches[a1][a2][1]) for a1, a2 in keys]
+    eds = [_ed_hint(matches[a1][a2][2]) for a1, a2 in keys]
     exact_matches = {}
-    for (a1, a2), stats in zip(keys, _align_pairs(pairs, pens)):
+    for (a1, a2), stats in zip(keys, _align_pairs(pairs, pens, ed_upper=eds)):
         if stats:
             exact_matches.setdefault(a1, {})[a2] = stats
     return exact_matches

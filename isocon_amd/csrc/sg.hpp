@@ -37,11 +37,24 @@ struct SgParams {
 struct SgPair {            // per pair of the batch
     uint32_t a, b;         // query (rows), ref (columns)
     int32_t mismatch;
-    uint32_t pad;
+    int32_t dlo;           // band of diagonals j - i that is computed: [dlo, dhi]  (full matrix: dlo <= -m, dhi >= n)
     uint64_t trace_off;    // byte offset of this pair's trace in the scratch buffer
     uint64_t ops_off;      // first slot of this pair's ops region (capacity m + n + 2)
     uint64_t bound_off;    // first int2 of this pair's pass-boundary row (capacity n)
+    int32_t dhi;
+    int32_t steps;         // steps per pass (window columns + 63), the same for every pass of the pair
 };
+
+// Column window of one pass (64*R query rows starting at prow0) for the band [dlo, dhi]: every cell of the band lies
+// inside, the window starts on a multiple of 64 (text chunks) at least one column left of the band.  Cells of the
+// window outside the band are simply computed too; what lies outside the window counts as -infinity.
+__host__ __device__ __forceinline__ void sg_window(int32_t prow0, int32_t rows, int32_t dlo, int32_t dhi, int32_t n, int32_t &jlo, int32_t &jhi)
+{
+    const int64_t lo = (int64_t)prow0 + dlo - 1;
+    jlo = lo <= 0 ? 0 : (int32_t)(lo & ~(int64_t)63);
+    const int64_t hi = (int64_t)prow0 + rows - 1 + dhi + 1;
+    jhi = hi > (int64_t)n - 1 ? n - 1 : (int32_t)hi;
+}
 
 // 64 consecutive bits of a bit-plane starting at bit `off` (per-lane address).
 __device__ __forceinline__ uint64_t plane_bits64(const uint64_t *planes, uint32_t nseq, int32_t nchunks, uint32_t id, int plane, int32_t off)
@@ -91,8 +104,10 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
     const int32_t nchunks = (int32_t)S.nchunks;
     int2 *bound = bound_all + pr.bound_off;
     uint8_t *tbase = trace + pr.trace_off;
-    const int32_t steps = n + 63;
+    const int32_t steps = uniform_i32(pr.steps);
+    const int32_t dlo = uniform_i32(pr.dlo), dhi = uniform_i32(pr.dhi);
     const int32_t passes = (m + 64 * R - 1) / (64 * R);
+    int32_t jhi_prev = -1;          // last column the previous pass left a boundary row for
 
     const int32_t last_i = m - 1;
     const int32_t pstar = last_i / (64 * R), lstar = (last_i % (64 * R)) / R, rstar = last_i % R;
@@ -102,20 +117,25 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
 #pragma unroll 1
     for (int32_t pass = 0; pass < passes; ++pass) {
         const int32_t row0 = pass * 64 * R + lane * R;
+        int32_t jlo, jhi;
+        sg_window(pass * 64 * R, 64 * R, dlo, dhi, n, jlo, jhi);
+        const int32_t psteps = jhi >= jlo ? jhi - jlo + 1 + 63 : 0;
+        const int32_t left0 = jlo == 0 ? 0 : SG_NEG;       // H[.][jlo - 1]: the free leading gap, or outside the window
         const uint64_t qlo = plane_bits64(planes, nseq, nchunks, ia, 0, row0);
         const uint64_t qhi = plane_bits64(planes, nseq, nchunks, ia, 1, row0);
         int32_t Hp[R], Ep[R];   // H[i][j-1], E[i][j-1]
 #pragma unroll
-        for (int r = 0; r < R; ++r) { Hp[r] = 0; Ep[r] = SG_NEG; }
-        int32_t diag_in = 0;     // H[row0-1][j-1]
+        for (int r = 0; r < R; ++r) { Hp[r] = left0; Ep[r] = SG_NEG; }
+        int32_t diag_in = left0;     // H[row0-1][j-1]
         int32_t sendH = 0, sendFC = SG_NEG * 4;
         uint64_t tlo = 0, thi = 0;
         int32_t bndH = 0, bndF = SG_NEG;   // lane l: boundary (H, F) of column 64*(s/64) + l
         const bool lane_has_rows = row0 < m;
 #pragma unroll 1
-        for (int32_t s = 0; s < steps; ++s) {
+        for (int32_t s = 0; s < psteps; ++s) {
+            const int32_t col0 = jlo + s;     // lane 0's column (jlo is a multiple of 64)
             if ((s & 63) == 0) {   // wave-uniform: next 64 ref bases
-                const int32_t tc = s >> 6;
+                const int32_t tc = col0 >> 6;
                 uint64_t a = 0, b = 0;
                 if (tc < nchunks) { a = planes[((size_t)tc * nseq + ib) * 2]; b = planes[((size_t)tc * nseq + ib) * 2 + 1]; }
                 // into SGPRs right here: a vector load whose result is first read many steps later would otherwise
@@ -126,12 +146,12 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
             if (pass > 0 && (s & 63) == 0) {
                 // bottom row of the previous pass for the next 64 columns: one coalesced, L1-bypassing load per lane
                 // (the values were written by lane 63 of this very wave); lane 0 picks its column by readlane below
-                const int32_t col = s + lane;
-                if (col < n) {
+                const int32_t col = col0 + lane;
+                if (col <= jhi_prev) {           // (columns right of the previous pass' window: outside the band)
                     const int32_t *bp = reinterpret_cast<const int32_t *>(bound + col);
                     bndH = __hip_atomic_load(bp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bndF = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else { bndH = 0; bndF = SG_NEG; }
+                } else { bndH = SG_NEG; bndF = SG_NEG; }
                 // consume the loads HERE: otherwise the compiler parks an `s_waitcnt vmcnt(0)` in front of the
                 // readlanes of EVERY step, which also waits for the trace stores in flight (vmcnt counts stores) and
                 // serialises each step on the HBM write latency.
@@ -143,19 +163,19 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
             const int32_t b_h = __builtin_amdgcn_readlane(bndH, s & 63), b_f = __builtin_amdgcn_readlane(bndF, s & 63);
             if (lane == 0) {
                 ch = (int32_t)(((tlo >> (s & 63)) & 1) | (((thi >> (s & 63)) & 1) << 1));
-                if (pass == 0 || s >= n) { Hup = 0; Fup = SG_NEG; }
+                if (pass == 0) { Hup = 0; Fup = SG_NEG; }
                 else { Hup = b_h; Fup = b_f; }
             } else {
                 Fup = FC >> 2;
                 ch = FC & 3;
             }
-            const int32_t j = s - lane;
-            const bool act = j >= 0 && j < n && lane_has_rows;
+            const int32_t j = col0 - lane;
+            const bool act = j >= jlo && j <= jhi && lane_has_rows;
             const int32_t diag_next = Hup;
             if (act) {
                 const uint64_t slo = (ch & 1) ? ~(uint64_t)0 : 0, shi = (ch & 2) ? ~(uint64_t)0 : 0;
                 const uint32_t eq = (uint32_t)(~(qlo ^ slo) & ~(qhi ^ shi));
-                int32_t diag = (j == 0) ? 0 : diag_in;   // left boundary column: H[.][-1] = 0
+                int32_t diag = (j == jlo) ? left0 : diag_in;   // left boundary column: H[.][-1] = 0 / outside the window
                 uint32_t tw = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
                         else if (hv == rowbest) rowj_last = j;
                     }
                 }
-                if (s >= n - 1) {                         // only then can some lane sit on the last ref column
+                if (col0 >= n - 1) {                      // only then can some lane sit on the last ref column
                     if (j == n - 1) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
@@ -226,6 +246,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
             sendH = Hup;
             sendFC = (int32_t)(((uint32_t)(Fup < SG_NEG ? SG_NEG : Fup) << 2) | (uint32_t)ch);
         }
+        jhi_prev = jhi;
         if (pass + 1 < passes) __threadfence();
     }
     // reduce the last-column candidates over lanes: maximum; smallest (first) / largest (last) row on ties
@@ -273,8 +294,9 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     const int32_t m = S.lens[pr.a], n = S.lens[pr.b];
     const int32_t R = Rs[p];
     const uint8_t *tb = trace + pr.trace_off;
-    const int32_t steps = n + 63;
+    const int32_t steps = pr.steps;
     const int32_t score = endinfo[(size_t)p * 4], eq = endinfo[(size_t)p * 4 + 1], er = endinfo[(size_t)p * 4 + 2];
+    bool left_window = false;       // the path stepped on a cell that was never computed (cannot happen inside a certified band)
     const uint64_t cap = (uint64_t)m + n + 2;
     uint32_t *region = ops + pr.ops_off;
     uint64_t pos = cap;
@@ -293,7 +315,10 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     while (i >= 0 && j >= 0) {
         const int32_t pass = i / (64 * R), ip = i - pass * 64 * R;
         const int32_t l = ip / R, r = ip - l * R;
-        const uint32_t word = *reinterpret_cast<const uint32_t *>(tb + (((size_t)pass * steps + (size_t)(j + l)) * 64 + l) * (size_t)(R / 2));
+        int32_t jlo, jhi;
+        sg_window(pass * 64 * R, 64 * R, pr.dlo, pr.dhi, n, jlo, jhi);
+        if (j < jlo || j > jhi) { left_window = true; break; }
+        const uint32_t word = *reinterpret_cast<const uint32_t *>(tb + (((size_t)pass * steps + (size_t)(j - jlo + l)) * 64 + l) * (size_t)(R / 2));
         const uint32_t tr = (word >> (28 - 4 * r)) & 15u;
         if (where == 0) {
             if (!(tr & SG_BIT_GAP)) {
@@ -315,7 +340,7 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     if (run_len) region[--pos] = (run_len << 4) | run_code;
     opcount[p] = (uint32_t)(cap - pos);
     int32_t *o = res + (size_t)p * 6;
-    o[0] = score; o[1] = eq; o[2] = er; o[3] = nmatch; o[4] = nmis; o[5] = (int32_t)(alen - nmatch - nmis);
+    o[0] = left_window ? SG_NEG : score; o[1] = eq; o[2] = er; o[3] = nmatch; o[4] = nmis; o[5] = (int32_t)(alen - nmatch - nmis);
 }
 
 // Gapped strings (what cigar_to_seq builds in the reference, SW_alignment_module.py:15-56): one block per pair, one op

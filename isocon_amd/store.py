@@ -115,7 +115,7 @@ class SeqStore(object):
             return hits[:int(n_hits.value)], stats.as_dict()
 
     # ---- semi-global affine alignment with traceback ----------------------------------------------------------
-    def sg_trace(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ms=False):
+    def sg_trace(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ms=False, ed_upper=None):
         """Returns (ops uint32[], ops_ptr int64[n+1], res int32[n,6]) -- see include/isocon_hip.h."""
         a = np.ascontiguousarray(a, dtype=np.uint32)
         b = np.ascontiguousarray(b, dtype=np.uint32)
@@ -125,13 +125,14 @@ class SeqStore(object):
         ops_ptr = np.zeros(n + 1, dtype=np.uint64)
         tot = int((self.lens[a].astype(np.int64) + self.lens[b]).sum()) if n else 0
         cap = max(64 * n + tot // 4, 1024)     # generous: a too-small buffer means running the batch again
+        edu = None if ed_upper is None else np.ascontiguousarray(np.broadcast_to(np.asarray(ed_upper, dtype=np.int32), (n,)))
         needed = ctypes.c_uint64(0)
         ms = ctypes.c_float(0)
         while True:
             ops = np.empty(cap, dtype=np.uint32)
             rc = self._L.isocon_sg_trace_batch(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), n, match, _ptr(mm, _lib.i8p),
                                                open_, ext, tie_policy, _ptr(ops, _lib.u32p), _ptr(ops_ptr, _lib.u64p), cap,
-                                               ctypes.byref(needed), _ptr(res, _lib.i32p), ctypes.byref(ms))
+                                               ctypes.byref(needed), _ptr(res, _lib.i32p), ctypes.byref(ms), _ptr(edu, _lib.i32p))
             if rc == _lib.ISOCON_E_CAPACITY:
                 cap = int(needed.value) + 16
                 continue
@@ -140,7 +141,7 @@ class SeqStore(object):
             return out + (ms.value,) if return_ms else out
 
 
-def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ops=False):
+def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ops=False, ed_upper=None):
     """Gapped strings straight from the device: returns (aln_a bytes, aln_b bytes, aln_ptr int64[n+1], res int32[n,6])."""
     a = np.ascontiguousarray(a, dtype=np.uint32)
     b = np.ascontiguousarray(b, dtype=np.uint32)
@@ -153,6 +154,7 @@ def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ret
     tot = int((self.lens[a].astype(np.int64) + self.lens[b]).sum()) if n else 0
     ops_cap = max(64 * n + tot // 4, 1024)
     aln_cap = tot + 1024                      # an alignment is never longer than both sequences together
+    edu = None if ed_upper is None else np.ascontiguousarray(np.broadcast_to(np.asarray(ed_upper, dtype=np.int32), (n,)))
     need_ops, need_aln = ctypes.c_uint64(0), ctypes.c_uint64(0)
     while True:
         ops = np.empty(ops_cap, dtype=np.uint32)
@@ -161,7 +163,7 @@ def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ret
         rc = self._L.isocon_sg_strings_batch(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), n, match, _ptr(mm, _lib.i8p), open_, ext,
                                              tie_policy, _ptr(ops, _lib.u32p), _ptr(ops_ptr, _lib.u64p), ops_cap, ctypes.byref(need_ops),
                                              _ptr(res, _lib.i32p), _ptr(aln_a, _lib.u8p), _ptr(aln_b, _lib.u8p), _ptr(aln_ptr, _lib.u64p),
-                                             aln_cap, ctypes.byref(need_aln), None)
+                                             aln_cap, ctypes.byref(need_aln), None, _ptr(edu, _lib.i32p))
         if rc == _lib.ISOCON_E_CAPACITY:
             ops_cap = max(ops_cap, int(need_ops.value) + 16)
             aln_cap = max(aln_cap, int(need_aln.value) + 16)

@@ -1,23 +1,19 @@
-"""Times isocon_ed_pairs + isocon_sg_trace_batch on the (query, first NN) pairs of a synthetic set (kernel experiments)."""
+"""SW batch timing at C3 scale: 8192 (centre, read) pairs of ~2.5 kb, with and without the edit-distance band hint."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from isocon_amd import synth
+from isocon_amd.edlib_alignment_module import _intern
 from isocon_amd.store import SeqStore
-n, L, iso, seed = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (50000, 2500, 10, 30001)))
-npairs = int(sys.argv[5]) if len(sys.argv) > 5 else 8192
-accs, seqs, _ = synth.make_reads(n, L, iso, seed)
-seqs = sorted(dict.fromkeys(seqs), key=len)
-st = SeqStore(seqs)
-best, rp, cols, stats = st.nn_graph()
-has = np.nonzero(rp[1:] > rp[:-1])[0][:npairs]
-a = cols[rp[has]].astype(np.uint32)       # centre-like: the neighbour
-b = has.astype(np.uint32)
-t = time.time(); ed, ms = st.ed_pairs(a, b, None, return_ms=True); dt = time.time() - t
-print("ed_pairs %d pairs: wall %.1f ms kernel %.2f ms  mean ed %.1f" % (len(a), dt * 1e3, ms, ed.mean()))
-mm = np.where(ed / np.minimum(st.lens[a], st.lens[b]) <= 0.01, -1, np.where(ed / np.minimum(st.lens[a], st.lens[b]) <= 0.09, -2, -4)).astype(np.int8)
-for rep in range(2):
-    t = time.time(); ops, ptr, res, ms = st.sg_trace(a, b, mm, return_ms=True); dt = time.time() - t
-    cells = float((st.lens[a] * st.lens[b]).sum())
-    print("sg_trace %d pairs: wall %.1f ms kernel %.1f ms  %.3g cells/s (kernel)  %.1f pairs/ms  mean ops %.1f  trace bytes %.3g" % (
-        len(a), dt * 1e3, ms, cells / (ms * 1e-3), len(a) / ms, len(ops) / len(a), cells / 2))
+accs, seqs, iso = synth.make_reads(8192, 2500, 10, 30001)
+pairs = [(iso[int(a.split("_")[-1])], s) for a, s in zip(accs, seqs)]
+sq, a, b = _intern(pairs)
+st = SeqStore(sq)
+ed = st.ed_pairs(a, b, None)
+mm = np.full(len(pairs), -2, np.int8)
+cells = float((st.lens[a].astype(np.int64) * st.lens[b]).sum())
+for name, hint in (("full", None), ("banded", ed)):
+    st.sg_trace(a[:64], b[:64], mm[:64], ed_upper=None if hint is None else hint[:64])
+    t = time.time(); ops, ptr, res, ms = st.sg_trace(a, b, mm, return_ms=True, ed_upper=hint); dt = time.time() - t
+    print("%-6s kernels %.1f ms, wall %.1f ms, %.3g matrix cells/s (kernel), median ed %d, checksum %d" %
+          (name, ms, dt * 1e3, cells / (ms / 1e3), int(np.median(ed)), int(res[:, 0].astype(np.int64).sum() + ops.astype(np.int64).sum())))
