@@ -1,0 +1,119 @@
+"""Collapse of candidates that are identical up to their ends (the step between the correction loop and
+the read-to-candidate alignment of find_candidate_transcripts).
+
+Mirror of /root/reference/modules/end_invariant_functions.py:884-918 (`is_overlap`), :920-951
+(`get_invariants_under_ignored_edge_ends_speed`), :405-533 (`partition_highest_reachable_with_edge_degrees`) and
+:975-1065 (`collapse_candidates_under_ends_invariant`).  Pure string work on the (few thousand) candidates -- exact
+substring / suffix-prefix tests, no alignment -- so it stays on the host, like in the reference.  The alignment-based
+variants of that module (`get_all_NN`, edlib HW mode) are dead code in v0.3.3 and not provided."""
+from __future__ import annotations
+
+from . import partitions
+
+
+def is_overlap(text1, text2, ignore_ends_threshold):
+    """end_invariant_functions.py:884-918: does a suffix of text1 equal a prefix of text2 such that at most
+    ignore_ends_threshold characters of either ORIGINAL string are left uncovered?  Like the reference: 0 for an empty
+    string, the common length (truthy) if the truncated strings are identical, else True / False."""
+    len1, len2 = len(text1), len(text2)
+    if len1 == 0 or len2 == 0:
+        return 0
+    if len1 > len2:
+        text1 = text1[-len2:]
+    elif len1 < len2:
+        text2 = text2[:len1]
+    if text1 == text2:
+        return min(len1, len2)
+    # The reference searches the LONGEST suffix-prefix overlap `best` and accepts iff len1 - best and len2 - best are
+    # within the threshold: equivalent to "some overlap of at least max(len1, len2) - threshold characters exists".
+    n = len(text1)
+    need = max(len1, len2) - ignore_ends_threshold
+    if need <= 0:
+        return True          # (best >= 0 always satisfies both offsets)
+    if need >= 16:
+        # an overlap of L >= need characters starts at position n - L <= n - need of text1 and begins with text2[:16]:
+        # let str.find look for that probe in the admissible start range (one C call instead of a Python loop)
+        probe, last_start = text2[:16], n - need
+        pos = text1.find(probe, 0, last_start + 16)
+        while pos != -1:
+            if text1[pos:] == text2[:n - pos]:
+                return True
+            pos = text1.find(probe, pos + 1, last_start + 16)
+        return False
+    for L in range(n, need - 1, -1):
+        if text1[n - L:] == text2[:L]:
+            return True
+    return False
+
+
+def _pair_is_invariant(seq1, seq2, thr):
+    """The reference's test for one ordered pair (len(seq1) - 2 thr <= len(seq2) <= len(seq1)), :933-946."""
+    if seq2 in seq1:
+        start_offset = seq1.find(seq2)
+        end_offset = len(seq1) - (start_offset + len(seq2))
+        return start_offset <= thr and end_offset <= thr
+    return bool(is_overlap(seq1, seq2, thr) or is_overlap(seq2, seq1, thr))
+
+
+def get_invariants_under_ignored_edge_ends_speed(candidate_transcripts, candidate_support, params):
+    """:920-951.  DiGraph on candidate accessions (node attribute `degree` = support) with edges in both directions
+    between candidates of which one is contained in the other, or which overlap suffix-to-prefix, leaving at most
+    params.ignore_ends_len characters at either end.
+
+    The reference tests every pair inside the length window (quadratic in the candidates).  Here pairs are proposed by an
+    anchor index first: whichever of the three relations holds, the 24-mer at offset thr of one string occurs in the
+    other at an offset in [thr, 2 thr] (the strings coincide up to a shift of at most thr), so only pairs sharing such a
+    k-mer are tested -- with the reference's own test.  Sets with a very short candidate take the quadratic route."""
+    import bisect
+
+    import networkx as nx
+    thr = params.ignore_ends_len
+    K = 24
+    G = nx.DiGraph()
+    for acc in candidate_transcripts:
+        G.add_node(acc, degree=candidate_support[acc])
+    by_len = sorted(candidate_transcripts.items(), key=lambda x: len(x[1]))
+    lens = [len(s) for _, s in by_len]
+    pos_of = {acc: i for i, (acc, _) in enumerate(by_len)}
+    indexed = bool(by_len) and lens[0] >= 3 * thr + K + 1
+    if indexed:
+        anchor_owner = {}                  # 24-mer at offset thr -> candidates having it there
+        window_owner = {}                  # 24-mer at an offset in [thr, 2 thr] -> candidates
+        for acc, seq in by_len:
+            anchor_owner.setdefault(seq[thr:thr + K], []).append(acc)
+            for o in range(thr, 2 * thr + 1):
+                window_owner.setdefault(seq[o:o + K], set()).add(acc)
+    for i1, (acc1, seq1) in enumerate(by_len):
+        lo = bisect.bisect_left(lens, len(seq1) - 2 * thr)          # shorter candidates cannot be merged
+        hi = bisect.bisect_right(lens, len(seq1))                   # the reference stops at the first longer one
+        if indexed:
+            partners = set(window_owner.get(seq1[thr:thr + K], ()))                 # my anchor inside their window
+            for o in range(thr, 2 * thr + 1):
+                partners.update(anchor_owner.get(seq1[o:o + K], ()))                # their anchor inside my window
+            todo = sorted((pos_of[a] for a in partners if lo <= pos_of[a] < hi and a != acc1))
+            todo = [by_len[k] for k in todo]
+        else:
+            todo = [x for x in by_len[lo:hi] if x[0] != acc1]
+        for acc2, seq2 in todo:
+            if _pair_is_invariant(seq1, seq2, thr):
+                G.add_edge(acc2, acc1)
+                G.add_edge(acc1, acc2)
+    return G
+
+
+def partition_highest_reachable_with_edge_degrees(G_star, params):
+    """:405-533.  Same greedy extraction as partitions.get_partitions_no_copy, ties between equally heavy reachable sets
+    decided by the accession only.  Returns (G_star, partition, M)."""
+    M, partition = partitions._partition_graph(G_star, False, nbr_tiebreak=False)
+    members = set(partition)
+    for m in partition:
+        members.update(partition[m])
+    assert members == set(G_star.nodes())
+    return G_star, partition, M
+
+
+def collapse_candidates_under_ends_invariant(candidate_transcripts, candidate_support, params):
+    """:975-1065.  {kept candidate accession: set(accessions merged into it)}."""
+    G = get_invariants_under_ignored_edge_ends_speed(candidate_transcripts, candidate_support, params)
+    _, partition, _ = partition_highest_reachable_with_edge_degrees(G, params)
+    return partition

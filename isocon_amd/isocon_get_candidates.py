@@ -52,18 +52,13 @@ def find_candidate_transcripts(read_file, params):
     params: .is_fastq .nr_cores .neighbor_search_depth .min_exon_diff .ignore_ends_len .min_candidate_support .outfolder
     .verbose (.logfile / .develop_logfile optional).  Writes candidates_step_<k>.fa, candidates_converged.fa and an empty
     not_converged.fa into params.outfolder like the reference and returns (candidates_file_name, read_partition,
-    to_realign).  Not provided: the collapse of candidates that differ only in their ends (end_invariant_functions, an
-    edlib HW-mode path outside SURVEY 8's scope) -- params.ignore_ends_len must be 0 here; and the CCS quality variant
-    the reference has switched off."""
+    to_realign).  Not provided: the CCS quality variant the reference has switched off."""
     import os
 
     from . import correction_module, partitions
     from .SW_alignment_module import sw_align_sequences_keeping_accession
     from .edlib_alignment_module import edlib_align_sequences_keeping_accession
     from .input_output import fasta_parser, fastq_parser
-
-    if params.ignore_ends_len > 0:
-        raise NotImplementedError("collapse_candidates_under_ends_invariant is outside this build: run with ignore_ends_len = 0")
 
     def read_all():
         with open(read_file, "r") as fh:
@@ -117,6 +112,18 @@ def find_candidate_transcripts(read_file, params):
         c_acc = "transcript_" + str(i) + "_support_" + str(N_t)
         c_acc_to_seq[c_acc] = m
         c_acc_to_support[c_acc] = N_t
+
+    if params.ignore_ends_len > 0:          # candidates that differ only in their ends are merged into the best supported one
+        from . import end_invariant_functions
+        remaining = end_invariant_functions.collapse_candidates_under_ends_invariant(c_acc_to_seq, c_acc_to_support, params)
+        for c_acc in remaining:
+            c_seq = c_acc_to_seq[c_acc]
+            for removed_c_acc in remaining[c_acc]:
+                removed_c_seq = c_acc_to_seq[removed_c_acc]
+                c_seq_to_read_acc[c_seq].extend(c_seq_to_read_acc[removed_c_seq])
+                del c_acc_to_seq[removed_c_acc]
+                del c_acc_to_support[removed_c_acc]
+                del c_seq_to_read_acc[removed_c_seq]
 
     original_reads = read_all()
     assert len(S) == len(original_reads)

@@ -25,11 +25,13 @@ def _reach(start, succ, alive):
     return seen
 
 
-def partition_ids(n, degree, edges, names):
+def partition_ids(n, degree, edges, names, nbr_tiebreak=True):
     """Core of get_partitions_no_copy on integer ids.
 
     n nodes, degree[i] = multiplicity, edges = [(a, b)]: a's nearest neighbour is b (an edge of G*; the search runs on
     the transpose, b -> a), names[i] = the sequence (only used to break ties the way the reference does, `m < centre`).
+    nbr_tiebreak: between start nodes of equal reachable weight prefer the one with more direct in-neighbours
+    (partitions.py:346-361); False = only the name decides (end_invariant_functions.py:461-470).
     Returns [(centre, weight, members)] in the reference's extraction order (components by size, largest first)."""
     rank = [0] * n                       # position of the sequence in sorted order: compares like the strings, in O(1)
     for r, v in enumerate(sorted(range(n), key=lambda v: names[v])):
@@ -75,8 +77,12 @@ def partition_ids(n, degree, edges, names):
                 weight = sum(degree[v] for v in reach)
                 # every node that reaches the same set (the strongly connected top of it) may stand for it
                 top = reach & _reach(m, succ_g, alive)
-                rep = min(top, key=lambda v: (-sum(1 for w in succ_t[v] if w in alive), rank[v]))
-                key = (-weight, -sum(1 for w in succ_t[rep] if w in alive), rank[rep])
+                if nbr_tiebreak:
+                    rep = min(top, key=lambda v: (-sum(1 for w in succ_t[v] if w in alive), rank[v]))
+                    key = (-weight, -sum(1 for w in succ_t[rep] if w in alive), rank[rep])
+                else:
+                    rep = min(top, key=rank.__getitem__)
+                    key = (-weight, 0, rank[rep])
                 if best is None or key < best[0]:
                     best = (key, reach, weight)
             _, reach, weight = best
@@ -87,7 +93,7 @@ def partition_ids(n, degree, edges, names):
     return out
 
 
-def _partition_graph(G, transposed):
+def _partition_graph(G, transposed, nbr_tiebreak=True):
     names = list(G.nodes())
     idx = {s: i for i, s in enumerate(names)}
     degree = [G.nodes[s]["degree"] for s in names]
@@ -96,7 +102,7 @@ def _partition_graph(G, transposed):
     else:
         edges = [(idx[a], idx[b]) for a, b in G.edges()]
     M, partition = {}, {}
-    for centre, weight, members in partition_ids(len(names), degree, edges, names):
+    for centre, weight, members in partition_ids(len(names), degree, edges, names, nbr_tiebreak):
         M[names[centre]] = weight
         partition[names[centre]] = set(names[v] for v in members)
     return M, partition

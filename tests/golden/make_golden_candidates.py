@@ -2,7 +2,7 @@
 """Golden fixture tests/golden/g12_candidates.json: the reference's own
 modules/isocon_get_candidates.py::find_candidate_transcripts (the whole candidate-inference phase: partition / align /
 correct until convergence, candidate naming, read-to-candidate alignment) on its public test FASTA (n = 200) and on a
-synthetic read set, with ignore_ends_len = 0 (the end-invariant collapse is outside this build's scope), under
+synthetic read set, with ignore_ends_len = 0 and 15 (the default; adds the end-invariant collapse of candidates), under
 PYTHONHASHSEED 0..2 (kept if all agree).  edlib / parasail are absent: tests/golden/shims forward to the CPU oracle
 (alignment tie-breaks "parity unpinned").  Stored: the converged candidates (accession, digest, length), the
 read -> candidate assignment with alignment digests, the reads left to realign, the number of correction steps.
@@ -38,7 +38,7 @@ def inputs():
     return [("test_data_n200", fa), ("synth_150x500_3iso", dict(zip(accs, seqs)))]
 
 
-def child(ci):
+def child(ci, ends=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(HERE, "shims"))
     sys.path.insert(0, REF)
@@ -61,7 +61,7 @@ def child(ci):
             develop_logfile = None
             logfile = open(os.path.join(tmp, "log.txt"), "w")
             min_exon_diff = 20
-            ignore_ends_len = 0
+            ignore_ends_len = ends
             min_candidate_support = 2
             is_fastq = False
             ccs = None
@@ -82,24 +82,25 @@ def child(ci):
 
 
 def main():
-    if len(sys.argv) == 3 and sys.argv[1] == "--child":
-        return child(int(sys.argv[2]))
+    if len(sys.argv) == 4 and sys.argv[1] == "--child":
+        return child(int(sys.argv[2]), int(sys.argv[3]))
     kept, dropped = [], []
     for ci, (name, S) in enumerate(inputs()):
+      for ends in (0, 15):
         outs = []
         for seed in range(3):
             env = dict(os.environ, PYTHONHASHSEED=str(seed))
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(ci)], env=env, capture_output=True, text=True, check=True)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(ci), str(ends)], env=env, capture_output=True, text=True, check=True)
             outs.append(r.stdout)
         agree = all(o == outs[0] for o in outs)
         e = json.loads(outs[0])
         if agree:
-            kept.append({"name": name, "S": [[a, s] for a, s in S.items()], "expect": e})
+            kept.append({"name": "%s_ends%d" % (name, ends), "ignore_ends_len": ends, "S": [[a, s] for a, s in S.items()], "expect": e})
         else:
-            dropped.append(name)
-        print(name, "agree" if agree else "HASH-ORDER DEPENDENT", len(S), "reads ->", len(e["candidates"]), "candidates,", e["steps"], "steps,",
+            dropped.append("%s_ends%d" % (name, ends))
+        print(name, "ends", ends, "agree" if agree else "HASH-ORDER DEPENDENT", len(S), "reads ->", len(e["candidates"]), "candidates,", e["steps"], "steps,",
               len(e["read_partition"]), "assigned,", len(e["to_realign"]), "to realign")
-    json.dump({"generator": "tests/golden/make_golden_candidates.py", "params": {"ignore_ends_len": 0, "min_exon_diff": 20, "min_candidate_support": 2},
+    json.dump({"generator": "tests/golden/make_golden_candidates.py", "params": {"ignore_ends_len": "0 and 15 (per case)", "min_exon_diff": 20, "min_candidate_support": 2},
                "hash_order_dependent_cases_dropped": dropped, "cases": kept}, open(os.path.join(HERE, "g12_candidates.json"), "w"), indent=0)
 
 

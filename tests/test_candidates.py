@@ -1,6 +1,6 @@
 """The candidate-inference phase end to end (BASELINE config[0]: the reference's test data through the pipeline's first
 phase) against what the reference's own find_candidate_transcripts produces (tests/golden/g12_candidates.json,
-ignore_ends_len = 0): converged candidates, read -> candidate alignments, reads to realign, number of steps."""
+ignore_ends_len = 0 and the default 15): converged candidates, read -> candidate alignments, reads to realign, number of steps."""
 import glob
 import hashlib
 import json
@@ -28,7 +28,7 @@ def run(case, tmp_path):
         develop_logfile = None
         logfile = None
         min_exon_diff = 20
-        ignore_ends_len = 0
+        ignore_ends_len = case.get("ignore_ends_len", 0)
         min_candidate_support = 2
         is_fastq = False
         ccs = None
@@ -44,15 +44,6 @@ def run(case, tmp_path):
     steps = 1 + len(glob.glob(os.path.join(str(tmp_path), "candidates_step_*.fa")))
     rp = sorted([c, r, sha(t[0]), sha(t[1]), list(t[2])] for c in read_partition for r, t in read_partition[c].items())
     return {"candidates": cands, "read_partition": rp, "to_realign": sorted(to_realign), "steps": steps}
-
-
-def test_end_invariant_collapse_is_refused(tmp_path):
-    from isocon_amd import isocon_get_candidates as IGC
-
-    class P(object):
-        ignore_ends_len = 15
-    with pytest.raises(NotImplementedError):
-        IGC.find_candidate_transcripts(str(tmp_path / "x.fa"), P())
 
 
 @pytest.mark.parametrize("case", [c for c in G12 if c["name"].startswith("synth")], ids=[c["name"] for c in G12 if c["name"].startswith("synth")])
