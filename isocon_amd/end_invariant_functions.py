@@ -55,6 +55,23 @@ def _pair_is_invariant(seq1, seq2, thr):
     return bool(is_overlap(seq1, seq2, thr) or is_overlap(seq2, seq1, thr))
 
 
+def _shift_consistent(A, B, thr, K=24):
+    """Necessary condition for "B[d + t] == A[t] on the whole overlap, for some 0 <= d <= thr" (every relation of
+    _pair_is_invariant is one of these, in one of the two directions): A's k-mer at offset thr fixes d, and the k-mers
+    in the middle and at the end of the overlap must agree with it.  No copies: str.find / str.startswith with offsets."""
+    probe = A[thr:thr + K]
+    pos = B.find(probe, thr, 2 * thr + K)
+    while pos != -1:
+        d = pos - thr
+        end = min(len(A), len(B) - d)               # overlap = A[0:end] vs B[d:d+end]
+        if end >= thr + K:
+            mid = end // 2
+            if B.startswith(A[mid:mid + K], d + mid) and B.startswith(A[end - K:end], d + end - K):
+                return True
+        pos = B.find(probe, pos + 1, 2 * thr + K)
+    return False
+
+
 def get_invariants_under_ignored_edge_ends_speed(candidate_transcripts, candidate_support, params):
     """:920-951.  DiGraph on candidate accessions (node attribute `degree` = support) with edges in both directions
     between candidates of which one is contained in the other, or which overlap suffix-to-prefix, leaving at most
@@ -95,6 +112,8 @@ def get_invariants_under_ignored_edge_ends_speed(candidate_transcripts, candidat
         else:
             todo = [x for x in by_len[lo:hi] if x[0] != acc1]
         for acc2, seq2 in todo:
+            if indexed and not (_shift_consistent(seq2, seq1, thr, K) or _shift_consistent(seq1, seq2, thr, K)):
+                continue                    # (candidates of one isoform share the anchor but differ inside)
             if _pair_is_invariant(seq1, seq2, thr):
                 G.add_edge(acc2, acc1)
                 G.add_edge(acc1, acc2)

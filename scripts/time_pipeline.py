@@ -12,7 +12,7 @@ with tempfile.TemporaryDirectory() as tmp:
     with open(rf, "w") as fh:
         for a, s in zip(accs, seqs): fh.write(">%s\n%s\n" % (a, s))
     class P: nr_cores = 1; neighbor_search_depth = 2 ** 32; verbose = False; develop_logfile = None; logfile = None; min_exon_diff = 20
-    P.ignore_ends_len = 0; P.min_candidate_support = 2; P.is_fastq = False; P.ccs = None; P.outfolder = tmp
+    P.ignore_ends_len = 15; P.min_candidate_support = 2; P.is_fastq = False; P.ccs = None; P.outfolder = tmp
     t = time.time(); cand_file, rp, to_realign = IGC.find_candidate_transcripts(rf, P); dt = time.time() - t
     cands = [l.strip() for l in open(cand_file) if not l.startswith(">")]
     steps = 1 + len(glob.glob(os.path.join(tmp, "candidates_step_*.fa")))
