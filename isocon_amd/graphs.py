@@ -29,28 +29,19 @@ def construct_exact_nearest_neighbor_graph(S, params):
     for acc, seq in S.items():
         predicted_seq_to_acc[seq].append(acc)
 
-    converged = True
     G = nx.DiGraph()
-    has_converged = set()
-    for seq, list_acc in predicted_seq_to_acc.items():
-        deg = len(list_acc)
-        G.add_node(seq, degree=deg)
-        if deg > 1:
-            has_converged.add(seq)
-        if deg == 1:
-            converged = False
+    G.add_nodes_from((seq, {"degree": len(list_acc)}) for seq, list_acc in predicted_seq_to_acc.items())
+    has_converged = set(seq for seq, list_acc in predicted_seq_to_acc.items() if len(list_acc) > 1)
+    converged = len(has_converged) == len(predicted_seq_to_acc)          # no sequence of multiplicity 1 left
     if converged:
         return G, converged
 
     unique_strings = {seq: acc for acc, seq in S.items()}          # last accession of a sequence wins (graphs.py:56)
     S_prime = {acc: seq for seq, acc in unique_strings.items()}
     edges, _isolated = nearest_neighbor_graph.compute_nearest_neighbor_graph(S_prime, has_converged, params)
-    for s1_acc in edges:
-        s1 = S[s1_acc]
-        if G.nodes[s1]["degree"] > 1:
-            continue
-        for s2_acc, ed in edges[s1_acc].items():
-            G.add_edge(s1, S[s2_acc], edit_distance=ed)
+    G.add_edges_from((S[s1_acc], S[s2_acc], {"edit_distance": ed})
+                     for s1_acc, nbrs in edges.items() if S[s1_acc] not in has_converged
+                     for s2_acc, ed in nbrs.items())
     return G, converged
 
 
