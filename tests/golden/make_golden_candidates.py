@@ -84,7 +84,7 @@ def child(ci, ends=0):
 def main():
     if len(sys.argv) == 4 and sys.argv[1] == "--child":
         return child(int(sys.argv[2]), int(sys.argv[3]))
-    kept, dropped = [], []
+    kept, dropped, stored_inputs = [], [], {}
     for ci, (name, S) in enumerate(inputs()):
       for ends in (0, 15):
         outs = []
@@ -95,13 +95,14 @@ def main():
         agree = all(o == outs[0] for o in outs)
         e = json.loads(outs[0])
         if agree:
-            kept.append({"name": "%s_ends%d" % (name, ends), "ignore_ends_len": ends, "S": [[a, s] for a, s in S.items()], "expect": e})
+            kept.append({"name": "%s_ends%d" % (name, ends), "ignore_ends_len": ends, "input": name, "expect": e})
+            stored_inputs[name] = [[a, s] for a, s in S.items()]
         else:
             dropped.append("%s_ends%d" % (name, ends))
         print(name, "ends", ends, "agree" if agree else "HASH-ORDER DEPENDENT", len(S), "reads ->", len(e["candidates"]), "candidates,", e["steps"], "steps,",
               len(e["read_partition"]), "assigned,", len(e["to_realign"]), "to realign")
     json.dump({"generator": "tests/golden/make_golden_candidates.py", "params": {"ignore_ends_len": "0 and 15 (per case)", "min_exon_diff": 20, "min_candidate_support": 2},
-               "hash_order_dependent_cases_dropped": dropped, "cases": kept}, open(os.path.join(HERE, "g12_candidates.json"), "w"), indent=0)
+               "hash_order_dependent_cases_dropped": dropped, "cases": kept, "inputs": stored_inputs}, open(os.path.join(HERE, "g12_candidates.json"), "w"), indent=0)
 
 
 if __name__ == "__main__":

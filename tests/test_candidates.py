@@ -9,7 +9,8 @@ import os
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-G12 = json.load(open(os.path.join(HERE, "golden", "g12_candidates.json")))["cases"]
+_G12 = json.load(open(os.path.join(HERE, "golden", "g12_candidates.json")))
+G12 = [dict(c, S=_G12["inputs"][c["input"]]) for c in _G12["cases"]]
 
 
 def sha(s):
