@@ -210,15 +210,14 @@ __global__ __launch_bounds__(256) void k_filter_hits(const int32_t *__restrict__
     }
 }
 
-// planes2[chunk][newpos] = planes[chunk][perm[newpos]]  (16 B per element; used to group similar sequences of equal length)
 // Main pass with LANE REFILL.  One workgroup per entry q with q's match masks tabulated in LDS, and the 64 lanes of a
 // wave as independent pair processors: every lane carries its own neighbour, band origin, column position and table
 // address, and a lane whose pair is decided (final-diagonal value above its threshold, or text exhausted) takes the
 // next admissible neighbour from the wave's queue at the next 32-column boundary.  No lane waits for the slowest pair
 // of a tile, no tile is half empty, and -- the band origin being per lane -- no pair ever needs a second run.
 //
-// LDS layout (dwords): four planes tw[b * E + e'] = 32-row match mask of base b at bit offset o = e' - 95 of q
-// (rows outside [0, m) read 0), then 160 dwords of 0xffffffff (the "virtual column" plane, code 4).  A lane reads
+// LDS layout (dwords): four planes tw[b * E + e'] = 32-row match mask of base b at bit offset o = e' - (64 W + 31) of q
+// (rows outside [0, m) read 0), then 128 W + 32 dwords of 0xffffffff (the "virtual column" plane, code 4).  A lane reads
 // (e', code) and (e' + 32, code) with ONE ds_read2_b32.  ds_read_b32 banks are (address / 4) mod 32 per 32-lane half,
 // so lanes at unrelated table positions would collide (measured: 17 LDS cycles per read instead of 4).  Therefore every
 // lane keeps e' = lane (mod 32) at step 0 of every block: a new pair starts phi = (e0 - lane) mod 32 steps "early",
@@ -236,220 +235,13 @@ static constexpr int NN_TEXT_PAD_FRONT = 4, NN_TEXT_PAD_BACK = 6;     // dwords 
 
 struct __attribute__((packed, aligned(4))) TextQuad { uint32_t x, y, z, w; };
 
-template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNParams P, const uint32_t *__restrict__ text, uint32_t text_stride,
-                                                                 uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t tile_begin)
-{
-    extern __shared__ uint32_t tw[];
-    __shared__ uint32_t s_next;
-    __shared__ uint32_t s_ring[NWAVES][NN_RING][2];
-    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-    const int32_t wave = threadIdx.x >> 6;
-    const int32_t lane = threadIdx.x & 63;
-    const uint32_t bid = blockIdx.x;
-    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)bid * q_stride;
-    if (q64 >= (uint64_t)q_end) return;
-    const uint32_t q = (uint32_t)q64;
-    const int32_t m = S.lens[q];
-    const int64_t pbase = (int64_t)q + 1 + (int64_t)tile_begin * 64;
-    if (pbase >= (int64_t)S.n || pbase - (int64_t)q > (int64_t)P.depth || S.lens[pbase] - m > P.kcap) return;   // uniform
-    const int32_t E = (m + 190 + 31) & ~31;          // plane length in dwords
-    {
-        const uint64_t *planes = S.planes;
-        const uint32_t nseq = S.n;
-        const int32_t nchunks = (int32_t)S.nchunks;
-        auto chunk_lo = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2] : 0; };
-        auto chunk_hi = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2 + 1] : 0; };
-        for (int32_t e = threadIdx.x; e < E; e += NWAVES * 64) {
-            const int32_t o = e - 95;
-            const uint32_t lo = (uint32_t)stream64(chunk_lo, o), hi = (uint32_t)stream64(chunk_hi, o);
-            const int32_t r0 = o < 0 ? -o : 0, r1 = (m - o) < 32 ? (m - o) : 32;       // valid rows [r0, r1)
-            uint32_t v = 0;
-            if (r1 > r0) v = (r1 >= 32 ? 0xffffffffu : ((1u << r1) - 1u)) & ~(r0 >= 32 ? 0xffffffffu : ((1u << r0) - 1u));
-            tw[e] = ~lo & ~hi & v;
-            tw[E + e] = lo & ~hi & v;
-            tw[2 * E + e] = ~lo & hi & v;
-            tw[3 * E + e] = lo & hi & v;
-        }
-        for (int32_t e = threadIdx.x; e < 160; e += NWAVES * 64) tw[4 * E + e] = 0xffffffffu;
-        if (threadIdx.x == 0) s_next = 0;
-    }
-    __syncthreads();
-    const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
-    const uint32_t tbase0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)tw;
-    const uint32_t idle_blk = tbase0 + (uint32_t)(lane & 31) * 4u;
-    uint32_t plane_bytes;      // in a VGPR: SGPR operands cost VALU issue cycles
-    asm volatile("v_mov_b32 %0, %1" : "=v"(plane_bytes) : "s"((uint32_t)E * 4u));
-    uint32_t(*ring)[2] = s_ring[wave];
-    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
-
-    // lane state
-    bool run = false, upd_s = false, upd_l = false;
-    uint32_t tid = q, blk = idle_blk, nsh = 0;
-    int32_t n_t = 0, k_eff = -1, nv = 0, col = 0;
-    uint32_t cur[5] = {0, 0, 0, 0, 0};       // the 5 text dwords the lane's next block is cut from
-    const uint32_t *tp = text;          // first dword of the lane's current block in the nibble store
-    BandLane<1> L;
-    band_init<1>(L, 0, 0);
-    // wave state (uniform)
-    uint32_t qhead = 0, qcount = 0;
-    bool exhausted = false;
-    uint32_t n_pairs = 0, n_batches = 0, n_blocks = 0, n_live = 0;
-
-    auto load5 = [](const uint32_t *p, uint32_t (&d)[5]) {
-        const TextQuad t4 = *reinterpret_cast<const TextQuad *>(p);
-        d[0] = t4.x; d[1] = t4.y; d[2] = t4.z; d[3] = t4.w; d[4] = p[4];
-    };
-
-    for (;;) {
-        const uint64_t freemask = __ballot(!run);
-        const uint32_t nfree = (uint32_t)__popcll(freemask);
-        // top up the wave's queue
-        while (!exhausted && qcount < nfree && qcount + 64 <= (uint32_t)NN_RING) {
-            uint32_t c0 = 0;
-            if (lane == 0) c0 = atomicAdd(&s_next, 64u);
-            c0 = (uint32_t)uniform_i32((int32_t)c0);
-            const int64_t p = pbase + (int64_t)c0 + lane;
-            const bool inr = p < (int64_t)S.n && p - (int64_t)q <= (int64_t)P.depth;
-            const uint32_t pid = inr ? (uint32_t)p : q;
-            const int32_t np = S.lens[pid];
-            const bool within = inr && np - m <= P.kcap;
-            if (__ballot(within) != ~(uint64_t)0) exhausted = true;      // lengths ascend: nothing admissible further up
-            const bool us = within && q_isq && P.tflag[pid];
-            const bool ul = within && q_ist && P.qflag[pid];
-            int32_t bs = NN_INF;
-            if (q_isq) bs = uniform_i32(load_relaxed_agent(P.best + q));
-            int32_t ks = -1, kl = -1;
-            if (us) ks = bs < m ? bs : m;
-            if (ul) { const int32_t bl = load_relaxed_agent(P.best + pid); kl = bl < np ? bl : np; }
-            int32_t k = ks > kl ? ks : kl;
-            if (k > P.kcap) k = P.kcap;
-            const int32_t d = m - np, ad = d < 0 ? -d : d;
-            bool accept = within && k >= 0 && ad <= k;
-            const bool triv = accept && (m == 0 || np == 0);      // an empty sequence: the distance is the other length
-            if (__ballot(triv) != 0) {
-                bool hs = false, hl = false;
-                if (triv && ad >= P.min_d) {
-                    if (us && ad <= m) { const int32_t old = atomicMin(P.best + q, ad); hs = ad <= old; }
-                    if (ul && ad <= np) { const int32_t old = atomicMin(P.best + pid, ad); hl = ad <= old; }
-                }
-                nn_append(P, hs, (int32_t)q, (int32_t)pid, ad);
-                nn_append(P, hl, (int32_t)pid, (int32_t)q, ad);
-                accept = accept && !triv;
-            }
-            const uint64_t am = __ballot(accept);
-            if (accept) {
-                const uint32_t slot = (qhead + qcount + (uint32_t)__popcll(am & lt_mask)) % (uint32_t)NN_RING;
-                int32_t a0 = lane_emin(d, k);            // own band origin: the 64-row window always certifies k <= 63
-                if (a0 < -63) a0 = -63;
-                ring[slot][0] = pid | (us ? 0x40000000u : 0u) | (ul ? 0x80000000u : 0u);
-                ring[slot][1] = (uint32_t)np | ((uint32_t)k << 20) | ((uint32_t)(-a0) << 26);
-            }
-            qcount += (uint32_t)__popcll(am);
-            n_pairs += (uint32_t)__popcll(am);
-            n_batches += 1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // hand queued neighbours to the free lanes
-        if (nfree && qcount) {
-            const uint32_t rank = (uint32_t)__popcll(freemask & lt_mask);
-            if (!run && rank < qcount) {
-                const uint32_t slot = (qhead + rank) % (uint32_t)NN_RING;
-                const uint32_t e0w = ring[slot][0], e1w = ring[slot][1];
-                tid = e0w & 0x3fffffffu;
-                upd_s = (e0w >> 30) & 1u;
-                upd_l = (e0w >> 31) & 1u;
-                n_t = (int32_t)(e1w & 0xfffffu);
-                k_eff = (int32_t)((e1w >> 20) & 63u);
-                nv = (int32_t)(e1w >> 26);
-                const int32_t bstar = m - n_t + nv;          // final diagonal inside the window: d - a0, in [0, 63]
-                L.VP[0] = ~(uint64_t)0 << nv;
-                L.VN[0] = ~L.VP[0];
-                L.LM[0] = ((uint64_t)1 << bstar) - 1;
-                const uint32_t e0 = (uint32_t)(63 - nv);                  // table entry of column 0 (before the apron shift)
-                const uint32_t phi = (e0 - (uint32_t)lane) & 31u;         // virtual columns in front: entry = lane (mod 32)
-                L.ztop = 0u - phi;
-                col = -(int32_t)phi;
-                blk = tbase0 + (32u + e0 - phi) * 4u;
-                nsh = 4u * ((32u - phi) & 7u);
-                tp = text + (size_t)tid * text_stride + ((32u - phi) >> 3);
-                load5(tp, cur);
-                run = true;
-            }
-            const uint32_t taken = nfree < qcount ? nfree : qcount;
-            qhead = (qhead + taken) % (uint32_t)NN_RING;
-            qcount -= taken;
-        }
-        const uint64_t runmask = __ballot(run);
-        if (runmask == 0) {
-            if (exhausted && qcount == 0) break;
-            continue;
-        }
-        // 32 columns for every running lane
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_alignbit(cur[i + 1], cur[i], nsh);
-        if (run && col + 32 < n_t) load5(tp + 4, cur);          // next block's text arrives while this one is computed
-        if (__ballot(run && col + 32 > n_t) == 0) {
-#pragma unroll
-            for (int jj = 0; jj < 32; ++jj) {
-                const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(w[jj >> 3], 4 * (jj & 7), 3);
-                lds_u32 *pe = (lds_u32 *)(uintptr_t)(__umul24(code, plane_bytes) + blk);
-                uint64_t EQ[1];
-                EQ[0] = ((uint64_t)pe[jj + 32] << 32) | pe[jj];
-                band_step_eq<1>(L, EQ);
-            }
-        } else {
-#pragma unroll
-            for (int seg = 0; seg < 4; ++seg) {
-                const uint32_t ws = w[seg];
-#pragma unroll 1
-                for (int u = 0; u < 8; ++u) {
-                    const int jj = seg * 8 + u;
-                    if (run && col + jj < n_t) {
-                        const uint32_t code = (ws >> (4 * u)) & 7u;
-                        lds_u32 *pe = (lds_u32 *)(uintptr_t)(code * plane_bytes + blk + (uint32_t)jj * 4u);
-                        uint64_t EQ[1];
-                        EQ[0] = ((uint64_t)pe[32] << 32) | pe[0];
-                        band_step_eq<1>(L, EQ);
-                    }
-                }
-            }
-        }
-        n_blocks += 1;
-        n_live += (uint32_t)__popcll(runmask);
-        col += 32;
-        const bool fin = run && col >= n_t;
-        const int32_t dv = band_diag_value<1>(L, nv, fin ? n_t : col);
-        int32_t r = -1;
-        if (fin) { r = dv <= k_eff ? dv : -1; run = false; }
-        else if (run && dv > k_eff) run = false;         // the value on the final diagonal never decreases
-        if (__ballot(fin && r >= P.min_d) != 0) {
-            bool hs = false, hl = false;
-            if (fin && r >= P.min_d) {
-                if (upd_s && r <= m) { const int32_t old = atomicMin(P.best + q, r); hs = r <= old; }
-                if (upd_l && r <= n_t) { const int32_t old = atomicMin(P.best + tid, r); hl = r <= old; }
-            }
-            nn_append(P, hs, (int32_t)q, (int32_t)tid, r);
-            nn_append(P, hl, (int32_t)tid, (int32_t)q, r);
-        }
-        blk += 128u;
-        tp += 4;
-        if (!run) blk = idle_blk;
-    }
-    WaveAcc acc;
-    acc.pairs = n_pairs; acc.tiles = n_batches; acc.cols = (unsigned long long)n_blocks * 2048ull; acc.live = (unsigned long long)n_live * 32ull;
-    nn_flush_acc(P, acc);
-}
-
-// The same lane-refill search with a 64*W-row band (W = 2, 4, 8; thresholds up to 127 / 255 / 511): the wide-band phase
-// for entries whose nearest neighbour is further than 63 edits (ONT-like error rates).  Differences from the 64-row
-// kernel: a column's match vector is 2W dwords of the base's plane (entries e', e'+32, ..., W ds_read2_b32), the band
-// state is W words with a carry chain (band_step_eq<W>), the final-diagonal mask is rebuilt from its bit index at the
-// 32-column checks instead of living in 2W registers, and the column loop is unrolled by text dword (8 columns) to
-// keep the code inside the instruction cache.  Bank-phase alignment, virtual columns, nibble texts, neighbour queue:
-// exactly as above.  LDS: 4 planes x (m + 192 W) dwords + (128 W + 32) dwords of ones.
+// One kernel for every band width: W = 1 is the main pass (64 rows, thresholds up to 63), W = 2, 4, 8 the phase for
+// entries whose nearest neighbour is further away (128 / 256 / 512 rows, ONT-like error rates).  A column's match
+// vector is 2W dwords of the base's plane (entries e', e'+32, ..., W ds_read2_b32), the band state is W words with a
+// carry chain (band_step_eq<W>), the final-diagonal mask is rebuilt from its bit index at the 32-column checks, and
+// the column loop is fully unrolled for W = 1 (immediate table offsets) and unrolled by text dword (8 columns) for the
+// wide bands to keep the code inside the instruction cache.  LDS: 4 planes x (m + 192 W) dwords + (128 W + 32) dwords
+// of ones for the virtual columns.
 template <int W>
 __device__ __forceinline__ int32_t diag_value_w(const BandLane<W> &L, int32_t nv, int32_t cols, int32_t bstar)
 {
@@ -464,10 +256,10 @@ __device__ __forceinline__ int32_t diag_value_w(const BandLane<W> &L, int32_t nv
 }
 
 template <int NWAVES, int W>
-__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill_wide(DevStore S, NNParams P, const uint32_t *__restrict__ text, uint32_t text_stride,
+__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNParams P, const uint32_t *__restrict__ text, uint32_t text_stride,
                                                                       uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t tile_begin)
 {
-    static_assert(W == 2 || W == 4 || W == 8, "wide-band kernel");
+    static_assert(W == 1 || W == 2 || W == 4 || W == 8, "band widths");
     constexpr int ROWS = 64 * W;
     constexpr int UNROLL_COLS = W == 8 ? 1 : 8;
     extern __shared__ uint32_t tw[];
@@ -632,7 +424,18 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill_wide(DevStore S,
         uint32_t w0 = __builtin_amdgcn_alignbit(cur[1], cur[0], nsh), w1 = __builtin_amdgcn_alignbit(cur[2], cur[1], nsh),
                  w2 = __builtin_amdgcn_alignbit(cur[3], cur[2], nsh), w3 = __builtin_amdgcn_alignbit(cur[4], cur[3], nsh);
         if (run && col + 32 < n_t) load5(tp + 4, cur);
-        if (__ballot(run && col + 32 > n_t) == 0) {
+        if (W == 1 && __ballot(run && col + 32 > n_t) == 0) {
+            // 64-row band: all 32 columns unrolled, immediate table offsets
+            const uint32_t wq[4] = {w0, w1, w2, w3};
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) {
+                const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(wq[jj >> 3], 4 * (jj & 7), 3);
+                lds_u32 *pe = (lds_u32 *)(uintptr_t)(__umul24(code, plane_bytes) + blk);
+                uint64_t EQ[W];
+                EQ[0] = ((uint64_t)pe[jj + 32] << 32) | pe[jj];
+                band_step_eq<W>(L, EQ);
+            }
+        } else if (__ballot(run && col + 32 > n_t) == 0) {
             uint32_t a_blk = blk;
 #pragma unroll 1
             for (int g = 0; g < 4; ++g) {
@@ -738,6 +541,7 @@ __global__ __launch_bounds__(256) void k_interleave_planes(const ulonglong2 *__r
     }
 }
 
+// planes2[chunk][newpos] = planes[chunk][perm[newpos]]  (16 B per element; used to group similar sequences of equal length)
 __global__ __launch_bounds__(256) void k_permute_planes(const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ dst,
                                                          const uint32_t *__restrict__ perm, uint32_t n, uint32_t nchunks)
 {
