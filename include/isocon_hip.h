@@ -105,7 +105,8 @@ int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t 
  * best_inout[n] is IN/OUT (0x3fffffff = no neighbour known yet).
  *   phase 0: seed pass -- every owned entry against its 64 nearest longer neighbours (64-row band).  Pass best_inout all
  *            0x3fffffff.  (No-op for the 2-set graph.)
- *   phase 1: 64-row band over every remaining admissible pair whose LOWER index (1-set) / whose query (2-set) is owned;
+ *   phase 1: 64-row band over every remaining admissible pair whose LOWER index is owned (1-set and 2-set alike;
+ *            only the long-read fallback of the 2-set search assigns a pair to the rank that owns its read);
  *            best_inout = element-wise MIN over all ranks' phase-0 results (tight thresholds on every rank).
  *   phase 2: 128/256/512-row bands over the pairs whose lower index is owned and that involve an entry still
  *            unresolved in best_inout (= MIN over all ranks' phase-1 results), then the un-banded kernel for the owned

@@ -187,3 +187,17 @@ def test_hit_list_overflow_reruns_with_the_bounds_kept(monkeypatch):
     g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
     g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
     assert ordered(g_gpu) == ordered(g_cpu)
+
+
+def test_2set_with_many_candidates_takes_the_scan_kernel():
+    """More than 512 candidates: the reads-vs-candidates search runs as the generic upward scan with role flags."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    accs, seqs, _ = synth.make_reads(1500, 400, 4, seed=44)
+    X = {a: s for a, s in list(zip(accs, seqs))[:900]}
+    C = {"c_" + a: s for a, s in list(zip(accs, seqs))[900:]}
+    assert len(set(C.values())) > 512
+    g_gpu = NNG.compute_2set_nearest_neighbor_graph(X, C, Params(1))
+    g_cpu = O.compute_2set_nearest_neighbor_graph(X, C, Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
