@@ -78,41 +78,43 @@ def get_invariants_under_ignored_edge_ends_speed(candidate_transcripts, candidat
     params.ignore_ends_len characters at either end.
 
     The reference tests every pair inside the length window (quadratic in the candidates).  Here pairs are proposed by an
-    anchor index first: whichever of the three relations holds, the 24-mer at offset thr of one string occurs in the
-    other at an offset in [thr, 2 thr] (the strings coincide up to a shift of at most thr), so only pairs sharing such a
-    k-mer are tested -- with the reference's own test.  Sets with a very short candidate take the quadratic route."""
+    anchor index first: whichever of the three relations holds, the K-mer at offset thr of one string occurs in the
+    other at an offset in [thr, 2 thr] (the strings coincide up to a shift of at most thr; K = shortest length - 3 thr),
+    so only pairs sharing such a K-mer are tested -- with the reference's own test.  Sets with a very short candidate take the quadratic route."""
     import bisect
 
     import networkx as nx
     thr = params.ignore_ends_len
-    K = 24
     G = nx.DiGraph()
     for acc in candidate_transcripts:
         G.add_node(acc, degree=candidate_support[acc])
     by_len = sorted(candidate_transcripts.items(), key=lambda x: len(x[1]))
     lens = [len(s) for _, s in by_len]
     pos_of = {acc: i for i, (acc, _) in enumerate(by_len)}
-    indexed = bool(by_len) and lens[0] >= 3 * thr + K + 1
+    # anchor length: as long as the shortest candidate allows (related strings are IDENTICAL on their whole overlap, so a
+    # long anchor separates candidates of one isoform that differ by a base somewhere); keyed by hash, verified exactly
+    K = max(24, lens[0] - 3 * thr - 1) if by_len else 24
+    indexed = bool(by_len) and lens[0] >= 3 * thr + 24 + 1
     if indexed:
-        anchor_owner = {}                  # 24-mer at offset thr -> candidates having it there
-        window_owner = {}                  # 24-mer at an offset in [thr, 2 thr] -> candidates
+        anchor_owner = {}                  # hash of the K-mer at offset thr -> candidates having it there
+        window_owner = {}                  # hash of a K-mer at an offset in [thr, 2 thr] -> candidates
         for acc, seq in by_len:
-            anchor_owner.setdefault(seq[thr:thr + K], []).append(acc)
+            anchor_owner.setdefault(hash(seq[thr:thr + K]), []).append(acc)
             for o in range(thr, 2 * thr + 1):
-                window_owner.setdefault(seq[o:o + K], set()).add(acc)
+                window_owner.setdefault(hash(seq[o:o + K]), set()).add(acc)
     for i1, (acc1, seq1) in enumerate(by_len):
         lo = bisect.bisect_left(lens, len(seq1) - 2 * thr)          # shorter candidates cannot be merged
         hi = bisect.bisect_right(lens, len(seq1))                   # the reference stops at the first longer one
         if indexed:
-            partners = set(window_owner.get(seq1[thr:thr + K], ()))                 # my anchor inside their window
+            partners = set(window_owner.get(hash(seq1[thr:thr + K]), ()))           # my anchor inside their window
             for o in range(thr, 2 * thr + 1):
-                partners.update(anchor_owner.get(seq1[o:o + K], ()))                # their anchor inside my window
+                partners.update(anchor_owner.get(hash(seq1[o:o + K]), ()))          # their anchor inside my window
             todo = sorted((pos_of[a] for a in partners if lo <= pos_of[a] < hi and a != acc1))
             todo = [by_len[k] for k in todo]
         else:
             todo = [x for x in by_len[lo:hi] if x[0] != acc1]
         for acc2, seq2 in todo:
-            if indexed and not (_shift_consistent(seq2, seq1, thr, K) or _shift_consistent(seq1, seq2, thr, K)):
+            if indexed and not (_shift_consistent(seq2, seq1, thr) or _shift_consistent(seq1, seq2, thr)):
                 continue                    # (candidates of one isoform share the anchor but differ inside)
             if _pair_is_invariant(seq1, seq2, thr):
                 G.add_edge(acc2, acc1)
