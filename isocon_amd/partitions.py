@@ -63,33 +63,66 @@ def partition_ids(n, degree, edges, names, nbr_tiebreak=True):
     comps.sort(key=len, reverse=True)
 
     out = []
+    live_in = [len(x) for x in succ_t]                    # direct in-neighbours of G* still in the graph (transpose successors)
     for members in comps:
         alive = set(members)
         while alive:
+            # One sweep: reachable set and weight of every start node that is not inside an earlier start's set (its own
+            # set would be a subset of that one).  Keys: (-weight, -direct in-neighbours of the representative, its rank);
+            # every node of the strongly connected top of a set may represent it.
             order = sorted(alive, key=rank.__getitem__)
             processed = set()
-            best = None            # (weight, nbrs, name, node, reach)
+            cands = []
+            best_w = -1
             for m in order:
                 if m in processed:
-                    continue       # reachable from an earlier start: its own reachable set is a subset of that one
-                reach = _reach(m, succ_t, alive)
-                processed |= reach
-                weight = sum(degree[v] for v in reach)
-                # every node that reaches the same set (the strongly connected top of it) may stand for it
+                    continue
+                if live_in[m] == 0:
+                    reach = {m}
+                else:
+                    reach = _reach(m, succ_t, alive)
+                    processed |= reach
+                weight = degree[m] if len(reach) == 1 else sum(degree[v] for v in reach)
+                cands.append((weight, m, reach))
+                if weight > best_w:
+                    best_w = weight
+
+            def full_key(weight, m, reach):
+                if len(reach) == 1:
+                    return (-weight, 0, rank[m])
                 top = reach & _reach(m, succ_g, alive)
                 if nbr_tiebreak:
-                    rep = min(top, key=lambda v: (-sum(1 for w in succ_t[v] if w in alive), rank[v]))
-                    key = (-weight, -sum(1 for w in succ_t[rep] if w in alive), rank[rep])
-                else:
-                    rep = min(top, key=rank.__getitem__)
-                    key = (-weight, 0, rank[rep])
-                if best is None or key < best[0]:
-                    best = (key, reach, weight)
-            _, reach, weight = best
-            # the centre: largest direct weight (own multiplicity + direct in-neighbours), then smallest sequence
-            centre = min(reach, key=lambda v: (-(degree[v] + sum(1 for w in succ_t[v] if w in alive)), rank[v]))
-            out.append((centre, weight, reach - {centre}))
-            alive -= reach
+                    rep = min(top, key=lambda v: (-live_in[v], rank[v]))
+                    return (-weight, -live_in[rep], rank[rep])
+                return (-weight, 0, rank[min(top, key=rank.__getitem__)])
+
+            # Extract in key order for as long as the next set is untouched by what was removed in this sweep: removing
+            # nodes can only shrink other sets, so an untouched set with the best key is what a fresh sweep would pick.
+            cands.sort(key=lambda c: -c[0])
+            removed = set()
+            k = 0
+            while k < len(cands):
+                w = cands[k][0]
+                e = k
+                while e < len(cands) and cands[e][0] == w:
+                    e += 1
+                group = sorted(cands[k:e], key=lambda c: full_key(*c)) if e - k > 1 else cands[k:e]
+                stop = False
+                for weight, m, reach in group:
+                    if removed and not removed.isdisjoint(reach):
+                        stop = True
+                        break
+                    # the centre: largest direct weight (own multiplicity + direct in-neighbours), then smallest sequence
+                    centre = m if len(reach) == 1 else min(reach, key=lambda v: (-(degree[v] + live_in[v]), rank[v]))
+                    out.append((centre, weight, reach - {centre}))
+                    removed |= reach
+                    alive -= reach
+                    for v in reach:                       # their nearest neighbours lose an in-neighbour
+                        for u in succ_g[v]:
+                            live_in[u] -= 1
+                if stop:
+                    break
+                k = e
     return out
 
 
