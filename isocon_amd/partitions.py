@@ -70,7 +70,8 @@ def partition_ids(n, degree, edges, names, nbr_tiebreak=True):
             # One sweep: reachable set and weight of every start node that is not inside an earlier start's set (its own
             # set would be a subset of that one).  Keys: (-weight, -direct in-neighbours of the representative, its rank);
             # every node of the strongly connected top of a set may represent it.
-            order = sorted(alive, key=rank.__getitem__)
+            # (hubs first: most nodes are then inside an earlier start's set and never start a search of their own)
+            order = sorted(alive, key=lambda v: (-live_in[v], rank[v]))
             processed = set()
             cands = []
             best_w = -1
