@@ -67,3 +67,26 @@ def test_candidate_inference_with_the_oracle_kernels(case, tmp_path, monkeypatch
 @pytest.mark.parametrize("case", G12, ids=[c["name"] for c in G12])
 def test_gpu_candidate_inference(case, tmp_path):
     assert run(case, tmp_path) == case["expect"]
+
+
+@pytest.mark.gpu
+def test_fastq_input_gives_the_same_candidates(tmp_path):
+    """is_fastq = True reads the same records through readfq; nothing else may change."""
+    from isocon_amd import isocon_get_candidates as IGC
+    from isocon_amd import synth
+    accs, seqs, _ = synth.make_reads(120, 400, 2, seed=97)
+    (tmp_path / "a").mkdir(); (tmp_path / "q").mkdir()
+    fa, fq = tmp_path / "reads.fa", tmp_path / "reads.fq"
+    fa.write_text("".join(">%s\n%s\n" % (a, s) for a, s in zip(accs, seqs)))
+    fq.write_text("".join("@%s\n%s\n+\n%s\n" % (a, s, "I" * len(s)) for a, s in zip(accs, seqs)))
+
+    def params(is_fastq, out):
+        class P(object):
+            nr_cores = 1; neighbor_search_depth = 2 ** 32; verbose = False; develop_logfile = None; logfile = None
+            min_exon_diff = 20; ignore_ends_len = 15; min_candidate_support = 2; ccs = None
+        P.is_fastq = is_fastq; P.outfolder = str(out)
+        return P
+
+    c1, rp1, tr1 = IGC.find_candidate_transcripts(str(fa), params(False, tmp_path / "a"))
+    c2, rp2, tr2 = IGC.find_candidate_transcripts(str(fq), params(True, tmp_path / "q"))
+    assert open(c1).read() == open(c2).read() and rp1 == rp2 and tr1 == tr2
