@@ -99,3 +99,92 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
     gathered = _all_gather_rows(dist, hits.astype(np.int32), device)    # exchange step 3
     out = nn_finalize(n, best[:n], gathered)
     return out + (stats_all,) if return_stats else out
+
+
+# ---- explicit pair lists (edlib_align_sequences*, sw_align_sequences*): embarrassingly parallel ------------------------
+def _pair_shards(lens_a, lens_b, world):
+    """Round-robin over the pairs sorted by len(a) * len(b) (largest first): every rank gets the same mix of sizes."""
+    cost = np.asarray(lens_a, dtype=np.int64) * np.asarray(lens_b, dtype=np.int64)
+    order = np.argsort(-cost, kind="stable")
+    return [order[r::world] for r in range(world)]
+
+
+def _all_gather_ragged(dist, arr, device):
+    """all_gather of 1-D int32 arrays of different lengths; returns the per-rank arrays."""
+    import torch
+    world = dist.get_world_size()
+    k = torch.tensor([arr.shape[0]], dtype=torch.int64, device=device)
+    ks = [torch.zeros_like(k) for _ in range(world)]
+    dist.all_gather(ks, k)
+    kmax = max(int(x.item()) for x in ks)
+    buf = torch.zeros(max(kmax, 1), dtype=torch.int32, device=device)
+    if arr.shape[0]:
+        buf[:arr.shape[0]] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(device)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return [outs[r][:int(ks[r].item())].cpu().numpy() for r in range(world)]
+
+
+def sharded_ed_pairs(store, a, b, k=None, dist=None, device=None):
+    """Edit distances of the pairs (a[i], b[i]) computed by all ranks (each a round-robin share), gathered everywhere.
+    `store` needs .lens and .ed_pairs(a, b, k).  The reference's counterpart is the Pool of EAM:25-47."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLC0415
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    a = np.asarray(a, dtype=np.uint32); b = np.asarray(b, dtype=np.uint32)
+    lens = np.asarray(store.lens)
+    shards = _pair_shards(lens[a], lens[b], world)
+    mine = shards[rank]
+    kk = None if k is None else np.asarray(k, dtype=np.int32)[mine]
+    ed = np.asarray(store.ed_pairs(a[mine], b[mine], kk), dtype=np.int32) if len(mine) else np.zeros(0, np.int32)
+    parts = _all_gather_ragged(dist, ed, device)
+    out = np.empty(len(a), dtype=np.int32)
+    for r in range(world):
+        out[shards[r]] = parts[r]
+    return out
+
+
+def sharded_sg_trace(store, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ed_upper=None, dist=None, device=None):
+    """Semi-global alignments of the pairs computed by all ranks, gathered everywhere: returns (ops, ops_ptr, res) in the
+    caller's pair order like SeqStore.sg_trace.  CIGAR ops travel as one ragged int32 all_gather (a few hundred bytes per
+    pair); the reference's counterpart is the Pool of SWM:121-162."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLC0415
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    a = np.asarray(a, dtype=np.uint32); b = np.asarray(b, dtype=np.uint32)
+    n = len(a)
+    mm = np.broadcast_to(np.asarray(mismatch, dtype=np.int8), (n,))
+    lens = np.asarray(store.lens)
+    shards = _pair_shards(lens[a], lens[b], world)
+    mine = shards[rank]
+    if len(mine):
+        hint = None if ed_upper is None else np.asarray(ed_upper, dtype=np.int32)[mine]
+        ops, ptr, res = store.sg_trace(a[mine], b[mine], mm[mine], match=match, open_=open_, ext=ext, tie_policy=tie_policy, ed_upper=hint)
+    else:
+        ops, ptr, res = np.zeros(0, np.uint32), np.zeros(1, np.int64), np.zeros((0, 6), np.int32)
+    cnt = np.diff(np.asarray(ptr, dtype=np.int64)).astype(np.int32)
+    g_ops = _all_gather_ragged(dist, ops.view(np.int32) if ops.dtype == np.uint32 else ops.astype(np.int32), device)
+    g_cnt = _all_gather_ragged(dist, cnt, device)
+    g_res = _all_gather_ragged(dist, np.ascontiguousarray(res, dtype=np.int32).reshape(-1), device)
+    counts = np.zeros(n, dtype=np.int64)
+    for r in range(world):
+        counts[shards[r]] = g_cnt[r]
+    out_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=out_ptr[1:])
+    out_ops = np.empty(int(out_ptr[n]), dtype=np.uint32)
+    out_res = np.empty((n, 6), dtype=np.int32)
+    for r in range(world):
+        src_ptr = np.zeros(len(shards[r]) + 1, dtype=np.int64)
+        np.cumsum(g_cnt[r], out=src_ptr[1:])
+        rr = g_res[r].reshape(-1, 6)
+        o = g_ops[r].view(np.uint32)
+        for i, p in enumerate(shards[r].tolist()):
+            out_ops[out_ptr[p]:out_ptr[p + 1]] = o[src_ptr[i]:src_ptr[i + 1]]
+            out_res[p] = rr[i]
+    return out_ops, out_ptr, out_res

@@ -127,3 +127,61 @@ def test_two_rank_sharded_graph_equals_serial_oracle(tmp_path):
     assert r0["cols"].tolist() == cols.tolist()
     exp_best = [int(eds[row_ptr[i]]) if row_ptr[i + 1] > row_ptr[i] else -1 for i in range(n)]
     assert r0["best"].tolist() == exp_best
+
+
+class FakePairStore(object):
+    """SeqStore.ed_pairs / sg_trace contract with the CPU oracle behind it."""
+
+    def __init__(self, seqs):
+        self.seqs = seqs
+        self.lens = np.array([len(s) for s in seqs], dtype=np.int64)
+
+    def ed_pairs(self, a, b, k=None):
+        from oracle import oracle as O
+        return np.array([O.ed_bounded(self.seqs[int(x)], self.seqs[int(y)], -1 if k is None else int(k[i])) for i, (x, y) in enumerate(zip(a, b))], dtype=np.int32)
+
+    def sg_trace(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ed_upper=None):
+        from oracle import oracle as O
+        import re
+        ops, ptr, res = [], [0], []
+        code = {"=": 0, "X": 1, "I": 2, "D": 3}
+        for i, (x, y) in enumerate(zip(a, b)):
+            t = O.sg_trace(self.seqs[int(x)], self.seqs[int(y)], match, int(mismatch[i]), open_, ext, tie_policy)
+            for ln, c in re.findall(r"(\d+)([=XID])", t["cigar"]):
+                ops.append((int(ln) << 4) | code[c])
+            ptr.append(len(ops))
+            res.append([t["score"], t["end_query"], t["end_ref"], t["matches"], t["mismatches"], t["indels"]])
+        return np.array(ops, dtype=np.uint32), np.array(ptr, dtype=np.int64), np.array(res, dtype=np.int32).reshape(-1, 6)
+
+
+def _worker_pairs(rank, world, port, seqs, a, b, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isocon_amd.dist import sharded_ed_pairs, sharded_sg_trace
+    st = FakePairStore(seqs)
+    ed = sharded_ed_pairs(st, a, b, dist=dist, device=torch.device("cpu"))
+    ops, ptr, res = sharded_sg_trace(st, a, b, np.full(len(a), -2, np.int8), dist=dist, device=torch.device("cpu"))
+    np.savez(os.path.join(out_dir, "pairs%d.npz" % rank), ed=ed, ops=ops, ptr=ptr, res=res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_pair_lists_two_ranks(tmp_path):
+    """Pair lists split round-robin by size over two ranks and gathered: same as one rank doing everything."""
+    import random
+    rng = random.Random(3)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(20, 90))) for _ in range(14)]
+    seqs += [s[:10] + "A" + s[10:] for s in seqs[:6]]
+    a = np.array([rng.randrange(len(seqs)) for _ in range(23)], dtype=np.uint32)
+    b = np.array([rng.randrange(len(seqs)) for _ in range(23)], dtype=np.uint32)
+    port = _free_port()
+    mp.spawn(_worker_pairs, args=(2, port, seqs, a, b, str(tmp_path)), nprocs=2, join=True)
+    st = FakePairStore(seqs)
+    ed = st.ed_pairs(a, b)
+    ops, ptr, res = st.sg_trace(a, b, np.full(len(a), -2, np.int8))
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), "pairs%d.npz" % r))
+        assert (z["ed"] == ed).all() and (z["ptr"] == ptr).all() and (z["ops"] == ops).all() and (z["res"] == res).all()
