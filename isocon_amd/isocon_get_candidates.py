@@ -1,8 +1,9 @@
-"""The two helpers of the candidate-inference loop that sit directly on the hot path:
-mirror of /root/reference/modules/isocon_get_candidates.py:22-35 (`get_unique_seq_accessions`) and :37-81
-(`get_partition_alignments`: exact edit distances -> semi-global alignments -> exon-difference filter -> the
-partition_alignments structure consumed by correction_module).  Same signatures, same return shapes; progress prints
-of the reference are not reproduced.  Everything heavy runs on the GPU through the sibling modules; the exon filter
+"""The candidate-inference phase: mirror of
+/root/reference/modules/isocon_get_candidates.py:22-35 (`get_unique_seq_accessions`), :37-81 (`get_partition_alignments`:
+exact edit distances -> semi-global alignments -> exon-difference filter -> the partition_alignments structure consumed
+by correction_module) and :85-312 (`find_candidate_transcripts`: the loop around partitioning, alignment and correction,
+the naming and collapse of the candidates, the read-to-candidate alignments).  Same signatures, same return shapes,
+same files written; progress prints of the reference are not reproduced.  Everything heavy runs on the GPU through the sibling modules; the exon filter
 works on the CIGAR ops the aligner just produced (isocon_amd.functions)."""
 from __future__ import annotations
 
