@@ -5,17 +5,16 @@ Mirror of /root/reference/modules/correction_module.py:12-76 (`correct_strings`)
 matrix, majority character per column, and for every non-converged read the correction of the ceil(half) of its
 unambiguous minority positions that are rarest for their error class.  Same signatures and return shapes; the quality-
 value variant (`correct_to_consensus_ccs_qual`, switched off in the reference: isocon_get_candidates.py:106 `if False`)
-is not provided.  Column statistics, the per-read selection and the gap stripping run on the GPU (isocon_msa_correct);
-the same steps exist as numpy reductions over the uint8 matrix (ISOCON_CORRECT_HOST=1: CPU tests, A/B checks); every tie rule of the reference is kept (first maximum in the order A, C, G, T, -; stable sort of the
-candidate positions by frequency; ties with the last chosen frequency are corrected too)."""
+is not provided.  Column statistics, the per-read selection and the gap stripping run on the GPU (isocon_msa_correct,
+csrc/msa.hpp) -- there is no host path: without the library or a GPU this module raises.  Every tie rule of the
+reference is kept (first maximum in the order A, C, G, T, -; stable sort of the candidate positions by frequency; ties
+with the last chosen frequency are corrected too).  The CPU tests substitute `_correct_on_device` with the numpy
+checker of oracle/correction.py."""
 from __future__ import annotations
-
-import math
 
 import numpy as np
 
 import ctypes
-import os
 
 from . import _lib
 from .functions import msa_matrix
@@ -58,72 +57,16 @@ def correct_to_consensus(m, partition, seq_to_acc, step, verbose):
         if M[r][M[r] != 45].tobytes().decode() != keys[r]:
             raise AssertionError("multi-alignment row does not spell its sequence")
     deg = np.array([partition[s][3] for s in keys], dtype=np.int64)
-    if os.environ.get("ISOCON_CORRECT_HOST") != "1":               # the product path: HIP kernels (no silent CPU fallback)
-        packed, off, n_cand = _correct_on_device(M, deg)
-        if (n_cand >= 0).all():
-            flat = packed[:off[nr]].tobytes().decode()
-            for r in sorted(range(nr), key=lambda r: keys[r]):
-                if deg[r] == 1 and n_cand[r] > 0:
-                    s_modified = flat[off[r]:off[r + 1]]
-                    for acc in seq_to_acc[keys[r]]:
-                        S_prime_partition[acc] = s_modified
-            return S_prime_partition
-        # a read with more correctable positions than the kernel holds per row: the whole partition on the host below
-    sym_index0 = np.full(256, -1, dtype=np.int64)
-    sym_index0[_SYMS] = np.arange(5)
-    heavy = np.flatnonzero(deg != 1)                               # rows of multiplicity > 1 (the centre, usually) count extra
-    counts = np.stack([np.count_nonzero(M == c, axis=0) for c in _SYMS]).astype(np.int64)     # [5, ncols], order A C G T -
-    for r in heavy:
-        counts[sym_index0[M[r]], np.arange(ncols)] += deg[r] - 1
-    maj_idx = counts.argmax(axis=0)                                # first maximum in that order (max() over the dict)
-    maj_cnt = counts.max(axis=0)
-    unambiguous = (counts == maj_cnt[None, :]).sum(axis=0) == 1
-    maj_chr = _SYMS[maj_idx]
-    maj_is_gap = maj_idx == 4
-    # error-type totals over the unambiguous columns (correction_module.py:296-307)
-    tot = counts.sum(axis=0)
-    c_ins = int((tot - maj_cnt)[unambiguous & maj_is_gap].sum())
-    col_ok = unambiguous & ~maj_is_gap
-    c_del = int(counts[4][col_ok].sum())
-    c_subs = int((tot - maj_cnt - counts[4])[col_ok].sum())
-    sym_index = np.full(256, -1, dtype=np.int64)
-    sym_index[_SYMS] = np.arange(5)
-
-    # Per read: the unambiguous columns where it differs from the majority are its correctable positions; ceil(half) of
-    # them are corrected, rarest first (frequency of the read's character in the column relative to the partition's
-    # total of that error class), plus every position tied with the last one chosen (correction_module.py:329-402).
-    # Equivalent set form used here: positions whose frequency is <= the ceil(n/2)-th smallest of the read.
-    single = deg == 1
-    cand = (M != maj_chr[None, :]) & unambiguous[None, :] & single[:, None]
-    rows, cols = np.nonzero(cand)                                   # row-major: ascending row, then ascending column
-    new_M = M
-    n_cand = np.bincount(rows, minlength=nr)
-    if len(rows):
-        v = M[rows, cols]
-        own_cnt = counts[sym_index[v], cols].astype(np.float64)
-        denom = np.where(maj_is_gap[cols], float(max(c_ins, 1)), np.where(v == 45, float(max(c_del, 1)), float(max(c_subs, 1))))
-        freq = own_cnt / denom
-        srt = np.lexsort((freq, rows))                              # by row, then frequency (stable)
-        start = np.zeros(nr + 1, dtype=np.int64)
-        np.cumsum(n_cand, out=start[1:])
-        k = (n_cand + 1) // 2                                       # ceil(n / 2)
-        thr = np.full(nr, -1.0)
-        has = k > 0
-        thr[has] = freq[srt[start[:-1][has] + k[has] - 1]]
-        chosen = freq <= thr[rows]
-        new_M = M.copy()
-        new_M[rows[chosen], cols[chosen]] = maj_chr[cols[chosen]]
-    keep = new_M != 45
-    lens_new = keep.sum(axis=1)
-    flat = new_M[keep].tobytes().decode()
-    off = np.zeros(nr + 1, dtype=np.int64)
-    np.cumsum(lens_new, out=off[1:])
+    # the product path: HIP kernels only (no host restatement here; the numpy checker lives in oracle/correction.py)
+    packed, off, n_cand = _correct_on_device(M, deg)
+    if (n_cand < 0).any():
+        raise RuntimeError("isocon_msa_correct left rows unprocessed")
+    flat = packed[:off[nr]].tobytes().decode()
     for r in sorted(range(nr), key=lambda r: keys[r]):
-        if not single[r] or n_cand[r] == 0:
-            continue
-        s_modified = flat[off[r]:off[r + 1]]
-        for acc in seq_to_acc[keys[r]]:
-            S_prime_partition[acc] = s_modified
+        if deg[r] == 1 and n_cand[r] > 0:
+            s_modified = flat[off[r]:off[r + 1]]
+            for acc in seq_to_acc[keys[r]]:
+                S_prime_partition[acc] = s_modified
     return S_prime_partition
 
 

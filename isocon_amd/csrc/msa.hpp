@@ -15,7 +15,27 @@
 
 namespace isocon {
 
-static constexpr int MSA_MAX_CAND = 2048;      // correctable positions per read held in LDS (more: host path)
+static constexpr int MSA_MAX_CAND = 2048;      // correctable positions per read held in LDS (more: the row is run again with
+                                               // its list in a global scratch row, k_msa_row_correct<true>)
+
+// scratch accessors: LDS directly; global scratch through device-scope atomics (lanes read what other lanes of the wave wrote)
+template <bool GLOBAL> __device__ __forceinline__ void msa_put(double *fq, uint32_t *cl, uint32_t at, double f, uint32_t col)
+{
+    if (GLOBAL) {
+        __hip_atomic_store((unsigned long long *)fq + at, (unsigned long long)__double_as_longlong(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cl + at, col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { fq[at] = f; cl[at] = col; }
+}
+template <bool GLOBAL> __device__ __forceinline__ double msa_freq(const double *fq, uint32_t i)
+{
+    if (GLOBAL) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)fq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return fq[i];
+}
+template <bool GLOBAL> __device__ __forceinline__ uint32_t msa_col(const uint32_t *cl, uint32_t i)
+{
+    if (GLOBAL) return __hip_atomic_load(cl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return cl[i];
+}
 
 __device__ __forceinline__ int msa_sym(uint8_t c)      // A C G T - -> 0..4
 {
@@ -65,18 +85,23 @@ __global__ __launch_bounds__(256) void k_msa_col_stats(const uint8_t *__restrict
     }
 }
 
-// One wavefront per row.  out row = corrected row; n_cand[r] = number of correctable positions (-1: too many for LDS,
-// row left untouched for the host path).
+// One wavefront per row.  out row = corrected row; n_cand[r] = number of correctable positions.  GLOBAL = false: the
+// list lives in LDS, a row with more than MSA_MAX_CAND positions gets n_cand = -1 and is left for the second launch;
+// GLOBAL = true: rows come from `row_list` (n_list of them) and keep their lists in g_freq / g_col (ncols entries per row).
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_msa_row_correct(const uint8_t *__restrict__ M, uint8_t *__restrict__ out, uint32_t nr, uint32_t ncols,
                                                           const int32_t *__restrict__ degree, const int32_t *__restrict__ counts,
                                                           const uint8_t *__restrict__ maj, const uint8_t *__restrict__ flags,
-                                                          const unsigned long long *__restrict__ class_tot, int32_t *__restrict__ n_cand)
+                                                          const unsigned long long *__restrict__ class_tot, int32_t *__restrict__ n_cand,
+                                                          const uint32_t *__restrict__ row_list, uint32_t n_list, double *g_freq, uint32_t *g_col)
 {
-    __shared__ double s_freq[4][MSA_MAX_CAND];
-    __shared__ uint32_t s_col[4][MSA_MAX_CAND];
+    __shared__ double s_freq[GLOBAL ? 1 : 4][GLOBAL ? 1 : MSA_MAX_CAND];
+    __shared__ uint32_t s_col[GLOBAL ? 1 : 4][GLOBAL ? 1 : MSA_MAX_CAND];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t r = blockIdx.x * 4 + wave;
-    if (r >= nr) return;
+    const uint32_t slot = blockIdx.x * 4 + wave;
+    if (slot >= (GLOBAL ? n_list : nr)) return;
+    const uint32_t r = GLOBAL ? row_list[slot] : slot;
+    const uint32_t cap = GLOBAL ? ncols : (uint32_t)MSA_MAX_CAND;
     const uint8_t *row = M + (size_t)r * ncols;
     uint8_t *orow = out + (size_t)r * ncols;
     const char SYM[5] = {'A', 'C', 'G', 'T', '-'};
@@ -84,8 +109,8 @@ __global__ __launch_bounds__(256) void k_msa_row_correct(const uint8_t *__restri
     const double d_del = (double)(class_tot[1] > 0 ? class_tot[1] : 1ull);
     const double d_sub = (double)(class_tot[2] > 0 ? class_tot[2] : 1ull);
     const bool single = degree[r] == 1;
-    double *fq = s_freq[wave];
-    uint32_t *cl = s_col[wave];
+    double *fq = GLOBAL ? g_freq + (size_t)slot * ncols : s_freq[wave];
+    uint32_t *cl = GLOBAL ? g_col + (size_t)slot * ncols : s_col[wave];
     uint32_t n = 0;                 // candidates so far (wave-uniform)
     bool overflow = false;
     for (uint32_t c0 = 0; c0 < ncols; c0 += 64) {
@@ -101,21 +126,21 @@ __global__ __launch_bounds__(256) void k_msa_row_correct(const uint8_t *__restri
         if (mask) {
             const uint32_t at = n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             if (cand) {
-                if (at < (uint32_t)MSA_MAX_CAND) {
+                if (at < cap) {
                     const int mj = maj[col];
                     const double own = (double)counts[(size_t)msa_sym(v) * ncols + col];
-                    fq[at] = own / (mj == 4 ? d_ins : (v == '-' ? d_del : d_sub));
-                    cl[at] = col;
+                    msa_put<GLOBAL>(fq, cl, at, own / (mj == 4 ? d_ins : (v == '-' ? d_del : d_sub)), col);
                 }
             }
             n += (uint32_t)__popcll(mask);
-            if (n > (uint32_t)MSA_MAX_CAND) overflow = true;
+            if (n > cap) overflow = true;
         }
     }
     if (overflow) { if (lane == 0) n_cand[r] = -1; return; }
     if (lane == 0) n_cand[r] = (int32_t)n;
     if (n == 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // threshold = k-th smallest frequency, k = ceil(n / 2): the value f with  #{< f} < k <= #{<= f}
     const uint32_t k = (n + 1) / 2;
@@ -126,9 +151,9 @@ __global__ __launch_bounds__(256) void k_msa_row_correct(const uint8_t *__restri
         bool mine = false;
         double f = 0.0;
         if (i < n) {
-            f = fq[i];
+            f = msa_freq<GLOBAL>(fq, i);
             uint32_t lt = 0, le = 0;
-            for (uint32_t j = 0; j < n; ++j) { const double g = fq[j]; lt += g < f; le += g <= f; }
+            for (uint32_t j = 0; j < n; ++j) { const double g = msa_freq<GLOBAL>(fq, j); lt += g < f; le += g <= f; }
             mine = lt < k && k <= le;
         }
         const unsigned long long m2 = __ballot(mine);
@@ -139,7 +164,7 @@ __global__ __launch_bounds__(256) void k_msa_row_correct(const uint8_t *__restri
         }
     }
     for (uint32_t i = lane; i < n; i += 64)
-        if (fq[i] <= thr) orow[cl[i]] = (uint8_t)SYM[maj[cl[i]]];
+        if (msa_freq<GLOBAL>(fq, i) <= thr) { const uint32_t c = msa_col<GLOBAL>(cl, i); orow[c] = (uint8_t)SYM[maj[c]]; }
 }
 
 __global__ __launch_bounds__(256) void k_msa_row_lengths(const uint8_t *__restrict__ rows, uint32_t nr, uint32_t ncols, uint32_t *__restrict__ len)

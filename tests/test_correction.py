@@ -67,7 +67,9 @@ def test_correction_with_the_oracle_kernels(case, monkeypatch):
     from isocon_amd import graphs
     from isocon_amd import isocon_get_candidates as IGC
     from oracle import oracle as O
-    monkeypatch.setenv("ISOCON_CORRECT_HOST", "1")          # no GPU here: the numpy statement of the correction step
+    from isocon_amd import correction_module as COR
+    from oracle import correction as OC
+    monkeypatch.setattr(COR, "_correct_on_device", OC.correct_rows)     # no GPU here: the numpy checker stands in for the kernels
     monkeypatch.setattr(graphs, "nearest_neighbor_graph", O)
     monkeypatch.setattr(IGC, "edlib_align_sequences", O.edlib_align_sequences)
     monkeypatch.setattr(IGC, "sw_align_sequences", O.sw_align_sequences)
@@ -93,7 +95,30 @@ def test_device_correction_equals_host_statement(monkeypatch):
     G, partition, M, converged = partitions.partition_strings(S, Params())
     pa = IGC.get_partition_alignments(partition, M, G, set(), Params())
     seq_to_acc = IGC.get_unique_seq_accessions(S)
+    from oracle import correction as OC
     dev, _ = COR.correct_strings(pa, seq_to_acc, {}, 1)
-    monkeypatch.setenv("ISOCON_CORRECT_HOST", "1")
+    monkeypatch.setattr(COR, "_correct_on_device", OC.correct_rows)
     host, _ = COR.correct_strings(pa, seq_to_acc, {}, 1)
     assert dev == host and len(dev) > 1000
+
+
+@pytest.mark.gpu
+def test_device_correction_rows_beyond_the_lds_list():
+    """Rows with more than 2048 correctable positions take the second launch (list in HBM): same result as the checker."""
+    import numpy as np
+    from isocon_amd import correction_module as COR
+    from oracle import correction as OC
+    rng = np.random.default_rng(5)
+    nr, ncols = 40, 9000
+    base = rng.integers(0, 4, ncols)
+    M = np.frombuffer(b"ACGT", dtype=np.uint8)[np.tile(base, (nr, 1))].copy()
+    for r in (3, 17, 29):                           # three very noisy rows: ~1/3 of their positions differ from the majority
+        pos = rng.choice(ncols, 3000 + 100 * r, replace=False)
+        M[r, pos] = np.frombuffer(b"ACGT-", dtype=np.uint8)[rng.integers(0, 5, len(pos))]
+    for r in range(nr):                             # and a little noise everywhere (varied frequencies, gaps)
+        pos = rng.choice(ncols, 30, replace=False)
+        M[r, pos] = np.frombuffer(b"ACGT-", dtype=np.uint8)[rng.integers(0, 5, 30)]
+    deg = np.ones(nr, dtype=np.int64); deg[0] = 4
+    p1, o1, n1 = COR._correct_on_device(M, deg)
+    p2, o2, n2 = OC.correct_rows(M, deg)
+    assert n1.max() > 2048 and (n1 == n2).all() and (o1 == o2).all() and (p1[:o1[-1]] == p2).all()
