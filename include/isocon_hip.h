@@ -168,12 +168,26 @@ int isocon_exon_filter_from_ops(const uint32_t *ops, const uint64_t *ops_ptr, ui
  * frequency = count of the row's symbol in the column / partition total of that error class (insertion, deletion,
  * substitution; over the unambiguous columns; at least 1), every position whose frequency is <= the ceil(n/2)-th
  * smallest is replaced by the majority.  Output: the corrected rows without their '-' symbols, packed
- * (out_offsets[n_rows + 1]), out_n_cand[r] = number of correctable positions (-1: more than the kernel holds, row
- * returned uncorrected -- the caller falls back for it), out_class_totals[3] = insertion, deletion, substitution totals.
+ * (out_offsets[n_rows + 1]), out_n_cand[r] = number of correctable positions (rows with more than the 2048 the kernel
+ * keeps in LDS are run again with their list in HBM), out_class_totals[3] = insertion, deletion, substitution totals.
  * ISOCON_E_CAPACITY if packed_cap is too small (out_offsets[n_rows] holds the size needed). */
 int isocon_msa_correct(const uint8_t *matrix, uint32_t n_rows, uint32_t n_cols, const int32_t *degree,
                        uint8_t *out_packed, uint64_t packed_cap, uint64_t *out_offsets, int32_t *out_n_cand,
                        int64_t *out_class_totals, float *kernel_ms);
+
+/*
+ * Batched infix ("HW") edit distance with location and path ends == edlib.align(q, t, mode="HW", task="path", k=k)
+ * as consumed by edlib_traceback (modules/end_invariant_functions.py:593-620) inside get_all_NN (:622-681), the
+ * candidate-vs-candidate graph of the statistical-test phase: the query is aligned globally inside the target, target
+ * prefix and suffix are free.  k[p] >= 0 is required (k = 10 + ignore_ends_len there); the diagonals a path of cost <= k
+ * can visit must fit 256 (max(len(t) - len(q), 0) + 2 k + 1 <= 256), otherwise ISOCON_E_UNSUPPORTED.
+ * out[5 p ..] = editDistance (-1 if > k[p]; then the rest is -1 / 0), locations[0] start, end (0-based, inclusive: the
+ * first optimal end, the smallest start for it), length of the insertion run (query bases without target) the path
+ * starts with, length of the one it ends with (0 = the CIGAR does not start / end with 'I').  Path = global alignment of
+ * q to t[start..end], traced from the end preferring I, then D, then the diagonal (oracle/isocon_oracle.c section 5).
+ */
+int isocon_hw_pairs(isocon_store *s, const uint32_t *q, const uint32_t *t, const int32_t *k, uint64_t n_pairs,
+                    int32_t *out, float *kernel_ms);
 
 #ifdef __cplusplus
 }

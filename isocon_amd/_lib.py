@@ -65,6 +65,7 @@ SYMBOLS = {
     "isocon_exon_filter_from_ops": (ctypes.c_int, [u32p, u64p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, u8p]),
     "isocon_msa_correct": (ctypes.c_int, [u8p, ctypes.c_uint32, ctypes.c_uint32, i32p, u8p, ctypes.c_uint64, u64p, i32p,
                                           ctypes.POINTER(ctypes.c_int64), f32p]),
+    "isocon_hw_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, i32p, ctypes.c_uint64, i32p, f32p]),
 }
 
 _lib = None

@@ -15,6 +15,7 @@
 #include "nn.hpp"
 #include "sg.hpp"
 #include "msa.hpp"
+#include "hw.hpp"
 
 namespace isocon {
 thread_local std::string g_last_error;
@@ -52,6 +53,7 @@ enum {
     SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED,
+    SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR,
     SLOT_COUNT
 };
 static_assert(SLOT_COUNT <= 64, "ScratchPool::slots too small");
@@ -463,3 +465,4 @@ extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_
 #include "nn_host.inc"
 #include "sg_host.inc"
 #include "msa_host.inc"
+#include "hw_host.inc"

@@ -4,11 +4,21 @@ the read-to-candidate alignment of find_candidate_transcripts).
 Mirror of /root/reference/modules/end_invariant_functions.py:884-918 (`is_overlap`), :920-951
 (`get_invariants_under_ignored_edge_ends_speed`), :405-533 (`partition_highest_reachable_with_edge_degrees`) and
 :975-1065 (`collapse_candidates_under_ends_invariant`).  Pure string work on the (few thousand) candidates -- exact
-substring / suffix-prefix tests, no alignment -- so it stays on the host, like in the reference.  The alignment-based
-variants of that module (`get_all_NN`, edlib HW mode) are dead code in v0.3.3 and not provided."""
+substring / suffix-prefix tests, no alignment -- so it stays on the host, like in the reference.
+
+Second part: the candidate-vs-candidate graph of the statistical-test phase --
+`edlib_traceback` (:593-620, edlib HW mode + path), `get_all_NN` (:622-681), `get_all_NN_under_ignored_edge_ends`
+(:687-754) and `get_NN_graph_ignored_ends_edlib` (:757-788): every candidate against all candidates whose length differs
+by at most 10 + 2 * ignore_ends_len, infix edit distance with threshold 10 + ignore_ends_len, target overhangs beyond the
+ignored ends charged, terminal insertion runs forgiven.  All pairs of a call go through one launch of isocon_hw_pairs
+(csrc/hw.hpp); the arithmetic on the five integers it returns per pair is done here as in the reference.  The other
+alignment-based variants of that module (`get_nearest_neighbors*`, the parasail graph) have no live caller in v0.3.3."""
 from __future__ import annotations
 
+import numpy as np
+
 from . import partitions
+from .store import SeqStore
 
 
 def is_overlap(text1, text2, ignore_ends_threshold):
@@ -138,3 +148,121 @@ def collapse_candidates_under_ends_invariant(candidate_transcripts, candidate_su
     G = get_invariants_under_ignored_edge_ends_speed(candidate_transcripts, candidate_support, params)
     _, partition, _ = partition_highest_reachable_with_edge_degrees(G, params)
     return partition
+
+
+# ---- candidate-vs-candidate graph with ignored ends (statistical-test phase) ------------------------------------------
+def _ends_adjusted(res, len_t, end_threshold):
+    """end_invariant_functions.py:597-619 on the kernel's (distance, start, end, leading I run, trailing I run) rows:
+    target bases left of `start` / right of `end` beyond the threshold are added, a terminal insertion run is forgiven up
+    to the threshold.  Rows with distance -1 (above k: edlib returns no cigar) stay -1."""
+    res = np.asarray(res, dtype=np.int64).reshape(-1, 5)
+    ed = res[:, 0].copy()
+    ok = ed >= 0
+    T = int(end_threshold)
+    adj = (np.maximum(0, res[:, 1] - T) + np.maximum(0, np.asarray(len_t, dtype=np.int64) - (res[:, 2] + 1) - T)
+           - np.minimum(res[:, 4], T) - np.minimum(res[:, 3], T))
+    ed[ok] += adj[ok]
+    return ed
+
+
+def edlib_traceback(x, y, mode="HW", task="path", k=1, end_threshold=0):
+    """end_invariant_functions.py:593-620 for one pair (x = query, y = target)."""
+    if mode != "HW" or task != "path":
+        raise NotImplementedError("end_invariant_functions.edlib_traceback: only mode='HW', task='path' (the reference's only use, :661,:668)")
+    res = SeqStore([x, y]).hw_pairs([0], [1], [int(k)])
+    return int(_ends_adjusted(res, [len(y)], end_threshold)[0])
+
+
+def _window_pairs(lens, q_lo, q_hi, window, depth):
+    """Neighbour indices the loop of get_all_NN visits for every query q_lo <= i < q_hi, in its order (offset j = 1, 2, ...:
+    i - j, then i + j; either side stops for good at the first length difference above `window` or at the list's end,
+    :636-655; offsets stop at max(1, depth), :677).  Returns (query index, neighbour index) arrays."""
+    n = len(lens)
+    jmax = max(1, int(min(depth, n)))
+    qs, ts = [], []
+    sorted_ok = bool((np.diff(lens) >= 0).all())
+    idx = np.arange(q_lo, q_hi, dtype=np.int64)
+    if sorted_ok and len(idx):
+        lo = np.maximum(np.searchsorted(lens, lens[idx] - window, side="left"), idx - jmax)
+        hi = np.minimum(np.searchsorted(lens, lens[idx] + window, side="right") - 1, idx + jmax)
+        cd, cu = idx - lo, hi - idx
+        tot = cd + cu
+        q = np.repeat(idx, tot)
+        first = np.zeros(len(idx) + 1, dtype=np.int64)
+        np.cumsum(tot, out=first[1:])
+        r = np.arange(int(first[-1]), dtype=np.int64) - np.repeat(first[:-1], tot)      # rank within the query's list
+        cdr, cur = np.repeat(cd, tot), np.repeat(cu, tot)
+        both = np.minimum(cdr, cur)
+        # the first 2 * both entries alternate down / up; then only the longer side continues
+        j_alt = r // 2 + 1
+        down_alt = (r % 2) == 0
+        rest = r - 2 * both
+        in_alt = r < 2 * both
+        j = np.where(in_alt, j_alt, both + rest + 1)
+        down = np.where(in_alt, down_alt, cdr > cur)
+        t = np.where(down, q - j, q + j)
+        return q, t
+    for i in idx.tolist():                                     # general list (not length-sorted): the loop itself
+        stop_down = stop_up = False
+        j = 1
+        while True:
+            if i - j < 0:
+                stop_down = True
+            if i + j >= n:
+                stop_up = True
+            if not stop_down and abs(int(lens[i]) - int(lens[i - j])) > window:
+                stop_down = True
+            if not stop_up and abs(int(lens[i]) - int(lens[i + j])) > window:
+                stop_up = True
+            if not stop_down:
+                qs.append(i); ts.append(i - j)
+            if not stop_up:
+                qs.append(i); ts.append(i + j)
+            if (stop_down and stop_up) or j >= depth:
+                break
+            j += 1
+    return np.asarray(qs, dtype=np.int64), np.asarray(ts, dtype=np.int64)
+
+
+def get_all_NN(batch_of_queries, global_index_in_matrix, start_index, seq_to_acc_list_sorted, neighbor_search_depth, ignore_ends_threshold):
+    """end_invariant_functions.py:622-681: {acc1: {acc2: ed}} for the queries start_index .. start_index + len(batch) of
+    the (length-sorted) list against their length window; an edge is kept iff 0 <= ed <= 10 after the end adjustments."""
+    max_variants = 10
+    max_ed_allowed = max_variants + ignore_ends_threshold
+    window = max_variants + 2 * ignore_ends_threshold
+    seqs = [s for s, _ in seq_to_acc_list_sorted]
+    accs = [a for _, a in seq_to_acc_list_sorted]
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    q_hi = start_index + len(batch_of_queries)
+    all_neighbors_graph = {accs[i]: {} for i in range(start_index, q_hi)}
+    q, t = _window_pairs(lens, start_index, q_hi, window, neighbor_search_depth)
+    if len(q) == 0:
+        return all_neighbors_graph
+    res = SeqStore(seqs).hw_pairs(q, t, np.full(len(q), max_ed_allowed, dtype=np.int32))
+    ed = _ends_adjusted(res, lens[t], ignore_ends_threshold)
+    for p in np.flatnonzero((ed >= 0) & (ed <= max_variants)).tolist():
+        all_neighbors_graph[accs[q[p]]][accs[t[p]]] = int(ed[p])
+    return all_neighbors_graph
+
+
+def get_all_NN_under_ignored_edge_ends(seq_to_acc_list_sorted, params):
+    """end_invariant_functions.py:687-754.  The reference's Pool chunks (halo = neighbor_search_depth + 1 on either side)
+    see exactly the neighbours the serial loop sees and are merged in query order: one call, nr_cores ignored."""
+    return get_all_NN(seq_to_acc_list_sorted, 0, 0, seq_to_acc_list_sorted, params.neighbor_search_depth, params.ignore_ends_len)
+
+
+def get_NN_graph_ignored_ends_edlib(candidate_transcripts, args):
+    """end_invariant_functions.py:757-788: the graph above on the unique candidate sequences (last accession wins, first
+    position kept, stable sort by length), made symmetric with the smaller of the two directed values."""
+    seq_to_acc = {seq: acc for (acc, seq) in candidate_transcripts.items()}
+    seq_to_acc_list_sorted = sorted(seq_to_acc.items(), key=lambda x: len(x[0]))
+    all_neighbors_graph = get_all_NN_under_ignored_edge_ends(seq_to_acc_list_sorted, args)
+    for c1 in all_neighbors_graph:                             # the reference inserts while it iterates the inner dict of
+        for c2 in list(all_neighbors_graph[c1]):               # c1 only when c2 == c1, which cannot happen
+            ed = all_neighbors_graph[c1][c2]
+            if c1 not in all_neighbors_graph[c2]:
+                all_neighbors_graph[c2][c1] = ed
+            else:
+                all_neighbors_graph[c2][c1] = min(all_neighbors_graph[c1][c2], all_neighbors_graph[c2][c1])
+    assert len(candidate_transcripts) == len(all_neighbors_graph)
+    return all_neighbors_graph

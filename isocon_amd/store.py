@@ -69,6 +69,21 @@ class SeqStore(object):
                                            _ptr(out, _lib.i32p), ctypes.byref(ms)), "isocon_ed_pairs")
         return (out, ms.value) if return_ms else out
 
+    def hw_pairs(self, q, t, k, return_ms=False):
+        """Infix (edlib "HW", task="path") alignment of sequence q[p] inside sequence t[p] with threshold k[p]:
+        int32 [n, 5] = distance (-1 if > k), start, end, leading insertion run, trailing insertion run
+        (isocon_hw_pairs; reference call site end_invariant_functions.py:594)."""
+        q = np.ascontiguousarray(q, dtype=np.uint32)
+        t = np.ascontiguousarray(t, dtype=np.uint32)
+        kk = np.ascontiguousarray(np.broadcast_to(np.asarray(k, dtype=np.int32), q.shape))
+        if len(q) != len(t):
+            raise ValueError("pair arrays differ in length")
+        out = np.full((len(q), 5), -1, dtype=np.int32)
+        ms = ctypes.c_float(0)
+        _lib.check(self._L.isocon_hw_pairs(self._h, _ptr(q, _lib.u32p), _ptr(t, _lib.u32p), _ptr(kk, _lib.i32p), len(q),
+                                           _ptr(out, _lib.i32p), ctypes.byref(ms)), "isocon_hw_pairs")
+        return (out, ms.value) if return_ms else out
+
     # ---- nearest-neighbour graph (store must be length-sorted) ------------------------------------------------
     def nn_graph(self, is_converged=None, is_target=None, depth=2 ** 32):
         """Returns (best[n], row_ptr[n+1], cols, stats dict)."""

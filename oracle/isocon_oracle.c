@@ -559,6 +559,104 @@ int32_t orc_sg_score(const uint8_t *s1, int32_t m, const uint8_t *s2, int32_t n,
     return best;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * 5. Infix ("HW") edit distance with location and path -- edlib.align(q, t, mode="HW", task="path", k)
+ *    as consumed at modules/end_invariant_functions.py:593-620 (edlib_traceback) and :661,:668 (get_all_NN).
+ *    "PARITY UNPINNED": edlib's source is absent.  Restated from its published semantics (Sosic & Sikic 2017 and
+ *    the library's documentation): the query is aligned globally, gaps before and after it in the target are free;
+ *    editDistance = min over end columns; endLocations = every end column attaining it, ascending; the start
+ *    location of an end location = the smallest start whose global distance to target[start..end] equals the
+ *    optimum (edlib searches the reversed problem in prefix mode and keeps the LAST position found, "so that the
+ *    alignment does not start with an insertion if it can start with a mismatch"); locations[0] is the pair for
+ *    the first end location and the path is the global alignment of the query to that substring.  Which optimal
+ *    path is reported is a tie decision: as everywhere in this oracle (tests/golden/shims/edlib.py, min_ed in
+ *    isocon_amd/functions.py) the traceback starts at the end and prefers a query-only step ('I'), then a
+ *    target-only step ('D'), then the diagonal.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out[0] = distance (-1 if > k, k < 0 = unbounded), out[1] = start, out[2] = end (0-based, inclusive; -1 when no hit).
+ * Full matrix, O(n*m) ints: test sizes only. */
+int32_t orc_hw_locate(const uint8_t *q, int32_t n, const uint8_t *t, int32_t m, int32_t k, int32_t *out)
+{
+    out[0] = -1; out[1] = -1; out[2] = -1;
+    if (n <= 0 || m <= 0) return -1;
+    const size_t W = (size_t)m + 1;
+    int32_t *row = (int32_t *)malloc(sizeof(int32_t) * W * 2);
+    int32_t *prev = row, *cur = row + W;
+    for (int32_t j = 0; j <= m; ++j) prev[j] = 0;                       /* free start in the target */
+    for (int32_t i = 1; i <= n; ++i) {
+        cur[0] = i;
+        for (int32_t j = 1; j <= m; ++j) {
+            int32_t v = prev[j - 1] + (q[i - 1] != t[j - 1]);
+            if (prev[j] + 1 < v) v = prev[j] + 1;
+            if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
+            cur[j] = v;
+        }
+        int32_t *x = prev; prev = cur; cur = x;
+    }
+    int32_t h = prev[1], end = 0;
+    for (int32_t j = 2; j <= m; ++j) if (prev[j] < h) { h = prev[j]; end = j - 1; }     /* first minimum */
+    if (k >= 0 && h > k) { free(row); return -1; }
+    /* start: reversed query against reversed target[0..end], global in the query, prefix of the reversed target */
+    const int32_t mb = end + 1;
+    for (int32_t j = 0; j <= mb; ++j) prev[j] = j;
+    for (int32_t i = 1; i <= n; ++i) {
+        cur[0] = i;
+        for (int32_t j = 1; j <= mb; ++j) {
+            int32_t v = prev[j - 1] + (q[n - i] != t[end - (j - 1)]);
+            if (prev[j] + 1 < v) v = prev[j] + 1;
+            if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
+            cur[j] = v;
+        }
+        int32_t *x = prev; prev = cur; cur = x;
+    }
+    int32_t plast = -1;
+    for (int32_t j = 1; j <= mb; ++j) if (prev[j] == h) plast = j - 1;  /* last position with the optimum */
+    free(row);
+    if (plast < 0) return -2;
+    out[0] = h; out[1] = end - plast; out[2] = end;
+    return h;
+}
+
+/* Global unit-cost alignment path of q against t, run-length ops (len << 4 | code; 0 '=', 1 'X', 2 'I' query only,
+ * 3 'D' target only) in forward order; returns the distance, *n_ops = number of ops (-1 if cap is too small). */
+int32_t orc_nw_path(const uint8_t *q, int32_t n, const uint8_t *t, int32_t m, uint32_t *ops, int64_t cap, int64_t *n_ops)
+{
+    const size_t W = (size_t)m + 1;
+    int32_t *D = (int32_t *)malloc(sizeof(int32_t) * W * ((size_t)n + 1));
+    for (int32_t j = 0; j <= m; ++j) D[j] = j;
+    for (int32_t i = 1; i <= n; ++i) {
+        D[i * W] = i;
+        for (int32_t j = 1; j <= m; ++j) {
+            int32_t v = D[(i - 1) * W + j - 1] + (q[i - 1] != t[j - 1]);
+            if (D[(i - 1) * W + j] + 1 < v) v = D[(i - 1) * W + j] + 1;
+            if (D[i * W + j - 1] + 1 < v) v = D[i * W + j - 1] + 1;
+            D[i * W + j] = v;
+        }
+    }
+    const int32_t ed = D[(size_t)n * W + m];
+    uint8_t *rev = (uint8_t *)malloc((size_t)n + m + 1);
+    int64_t L = 0;
+    int32_t i = n, j = m;
+    while (i > 0 || j > 0) {
+        if (i > 0 && D[(i - 1) * W + j] + 1 == D[i * W + j]) { rev[L++] = 2; --i; }
+        else if (j > 0 && D[i * W + j - 1] + 1 == D[i * W + j]) { rev[L++] = 3; --j; }
+        else { rev[L++] = q[i - 1] == t[j - 1] ? 0 : 1; --i; --j; }
+    }
+    int64_t no = 0;
+    for (int64_t a = L - 1; a >= 0;) {
+        int64_t b = a;
+        while (b >= 0 && rev[b] == rev[a]) --b;
+        if (no < cap) ops[no] = ((uint32_t)(a - b) << 4) | rev[a];
+        ++no;
+        a = b;
+    }
+    *n_ops = no <= cap ? no : -1;
+    free(rev);
+    free(D);
+    return ed;
+}
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,10 @@ def lib():
         L.orc_sg_score.restype = ctypes.c_int32
         L.orc_sg_score.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32,
                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        L.orc_hw_locate.restype = ctypes.c_int32
+        L.orc_hw_locate.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, _i32p]
+        L.orc_nw_path.restype = ctypes.c_int32
+        L.orc_nw_path.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32, _u32p, ctypes.c_int64, _i64p]
         _lib = L
     return _lib
 
@@ -97,6 +101,50 @@ def ed_bounded(a: str, b: str, k: int = -1) -> int:
     """edlib.align(a, b, mode="NW", task="distance", k=k)["editDistance"] (NNG:104-107)."""
     a, b = _b(a), _b(b)
     return lib().orc_ed_bounded(a, len(a), b, len(b), int(k))
+
+
+def nw_path(q: str, t: str):
+    """(distance, [(length, op)]) of the global unit-cost alignment, ops '=', 'X', 'I' (query only), 'D' (target only);
+    traceback rule of the oracle: from the end, I before D before the diagonal (edlib task="path"; parity unpinned)."""
+    qb, tb = _b(q), _b(t)
+    ops = np.zeros(len(qb) + len(tb) + 2, dtype=np.uint32)
+    n_ops = np.zeros(1, dtype=np.int64)
+    ed = lib().orc_nw_path(qb, len(qb), tb, len(tb), _p(ops, _u32p), len(ops), _p(n_ops, _i64p))
+    return ed, [(int(o >> 4), "=XID"[int(o & 15)]) for o in ops[:int(n_ops[0])]]
+
+
+def hw_locate(q: str, t: str, k: int = -1):
+    """(distance or -1, start, end) of edlib.align(q, t, mode="HW", k=k)["locations"][0] (module header of section 5)."""
+    qb, tb = _b(q), _b(t)
+    out = np.zeros(3, dtype=np.int32)
+    lib().orc_hw_locate(qb, len(qb), tb, len(tb), int(k), _p(out, _i32p))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def hw_path(q: str, t: str, k: int = -1):
+    """edlib.align(q, t, mode="HW", task="path", k=k) as a dict like edlib's (cigar None when the distance exceeds k)."""
+    ed, start, end = hw_locate(q, t, k)
+    if ed < 0:
+        return {"editDistance": -1, "locations": [], "cigar": None}
+    ed2, ops = nw_path(q, t[start:end + 1])
+    assert ed2 == ed
+    return {"editDistance": ed, "locations": [(start, end)], "cigar": "".join("%d%s" % o for o in ops)}
+
+
+def edlib_traceback_hw(x, y, k=1, end_threshold=0):
+    """end_invariant_functions.py:593-620: HW distance of x inside y, target overhangs beyond `end_threshold`
+    charged, terminal insertion runs of the path forgiven up to `end_threshold`."""
+    r = hw_path(x, y, k)
+    ed = r["editDistance"]
+    if r["cigar"]:
+        start, end = r["locations"][0]
+        ed += max(0, start - end_threshold) + max(0, len(y) - (end + 1) - end_threshold)
+        _, ops = nw_path(x, y[start:end + 1])
+        if ops[-1][1] == "I":
+            ed -= min(ops[-1][0], end_threshold)
+        if ops[0][1] == "I":
+            ed -= min(ops[0][0], end_threshold)
+    return ed
 
 
 def ed_pairs(seqs, a_idx, b_idx, k=None) -> np.ndarray:
@@ -469,3 +517,62 @@ def find_best_matches_2set(highest_paf_scores, X, C, params):
             else:
                 out[x_acc] = {c_acc: (ed, xa, ca)}
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# candidate-vs-candidate graph with ignored ends (modules/end_invariant_functions.py:622-788), loop by loop
+# ---------------------------------------------------------------------------------------------------
+
+def get_all_NN(batch_of_queries, global_index_in_matrix, start_index, seq_to_acc_list_sorted, neighbor_search_depth,
+               ignore_ends_threshold):
+    all_neighbors_graph = {}
+    max_variants = 10
+    max_ed_allowed = max_variants + ignore_ends_threshold
+    n = len(seq_to_acc_list_sorted)
+    for i in range(start_index, start_index + len(batch_of_queries)):
+        seq1, acc1 = seq_to_acc_list_sorted[i]
+        all_neighbors_graph[acc1] = {}
+        stop_up = stop_down = False
+        j = 1
+        while True:
+            if i - j < 0:
+                stop_down = True
+            if i + j >= n:
+                stop_up = True
+            if not stop_down:
+                seq2, acc2 = seq_to_acc_list_sorted[i - j]
+                if abs(len(seq1) - len(seq2)) > max_variants + 2 * ignore_ends_threshold:
+                    stop_down = True
+            if not stop_up:
+                seq3, acc3 = seq_to_acc_list_sorted[i + j]
+                if abs(len(seq1) - len(seq3)) > max_variants + 2 * ignore_ends_threshold:
+                    stop_up = True
+            if not stop_down:
+                ed = edlib_traceback_hw(seq1, seq2, k=max_ed_allowed, end_threshold=ignore_ends_threshold)
+                if 0 <= ed <= max_variants:
+                    all_neighbors_graph[acc1][acc2] = ed
+            if not stop_up:
+                ed = edlib_traceback_hw(seq1, seq3, k=max_ed_allowed, end_threshold=ignore_ends_threshold)
+                if 0 <= ed <= max_variants:
+                    all_neighbors_graph[acc1][acc3] = ed
+            if stop_down and stop_up:
+                break
+            if j >= neighbor_search_depth:
+                break
+            j += 1
+    return all_neighbors_graph
+
+
+def get_NN_graph_ignored_ends_edlib(candidate_transcripts, args):
+    seq_to_acc = {seq: acc for (acc, seq) in candidate_transcripts.items()}
+    lst = sorted(seq_to_acc.items(), key=lambda x: len(x[0]))
+    g = get_all_NN(lst, 0, 0, lst, args.neighbor_search_depth, args.ignore_ends_len)
+    for c1 in g:
+        for c2 in list(g[c1]):
+            ed = g[c1][c2]
+            if c1 not in g[c2]:
+                g[c2][c1] = ed
+            else:
+                g[c2][c1] = min(g[c1][c2], g[c2][c1])
+    assert len(candidate_transcripts) == len(g)
+    return g

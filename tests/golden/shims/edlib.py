@@ -38,8 +38,14 @@ def nw_path(query, target):
 
 
 def align(query, target, mode="NW", task="distance", k=-1):
+    if mode == "HW" and task == "path":
+        # infix mode with location and path: oracle/isocon_oracle.c section 5 (edlib's published semantics; the choice
+        # among equally good paths is "parity unpinned")
+        r = _O.hw_path(query, target, k)
+        r["alphabetLength"] = len(set(query) | set(target))
+        return r
     if mode != "NW":
-        raise NotImplementedError("shim supports the hot path's NW mode only")
+        raise NotImplementedError("shim supports NW, and HW with task='path'")
     if task == "path":
         ed, cigar = nw_path(query, target)
         return {"editDistance": ed, "alphabetLength": len(set(query) | set(target)), "locations": [(0, len(target) - 1)], "cigar": cigar}
