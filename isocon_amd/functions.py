@@ -251,3 +251,167 @@ def create_position_frequency_matrix(alignment_matrix, partition):
         for j, nucl in enumerate(row):
             PFM[j][nucl] += deg
     return PFM
+
+
+# ---- helpers of the statistical-test phase (callers: hypothesis_test_module, isocon_statistical_test) ----
+def transform(read):
+    """functions.py:53-61: homopolymer compression (every run of equal characters becomes one character)."""
+    return "".join(c for i, c in enumerate(read) if i == 0 or c != read[i - 1])
+
+
+def get_homopolymer_invariants(candidate_transcripts):
+    """functions.py:63-86: {acc: {other acc: 1}} over candidates that are equal after homopolymer compression."""
+    clusters = {}
+    for acc, seq in candidate_transcripts.items():
+        clusters.setdefault(transform(seq), []).append(acc)
+    edges = {}
+    for members in clusters.values():
+        if len(members) > 1:
+            for acc in members:
+                edges[acc] = {}
+            for a in members:
+                for b in members:
+                    if a is not b:
+                        edges[a][b] = 1
+    return edges
+
+
+def _run_length(s, ch):
+    """length of the run of `ch` the string starts with"""
+    n = 0
+    while n < len(s) and s[n] == ch:
+        n += 1
+    return n
+
+
+def get_variant_coordinates(t_seq, c_seq, aln_t, aln_c, variants):
+    """functions.py:89-146.  For every differing alignment column (i, p_t, p_c): its coordinate on the reference t and
+    on the candidate c, the variant type seen from c ('S', 'I' = c has an extra base, 'D' = c lacks one), the number u_v
+    of equivalent placements inside a homopolymer of t, and the alignment snippets around it.  Returns
+    (variant_coords_t, variant_coords_c, alignment_c_to_t, alignment_t_to_c); later variants overwrite earlier ones that
+    land on the same coordinate, as in the reference."""
+    variant_coords_t, variant_coords_c, alignment_c_to_t, alignment_t_to_c = {}, {}, {}, {}
+    # number of sequence characters in aln[:i + 1], for both rows
+    upto_t, upto_c = [], []
+    nt = nc = 0
+    for a, b in zip(aln_t, aln_c):
+        nt += a != "-"
+        nc += b != "-"
+        upto_t.append(nt)
+        upto_c.append(nc)
+    for (i, p_t, p_c) in variants:
+        t_last, c_last = upto_t[i] - 1, upto_c[i] - 1           # last base of t / c at or before column i
+        if p_c == "-":                                          # the candidate lacks a base of t
+            v = t_seq[t_last]
+            fwd = _run_length(t_seq[t_last + 1:], v)
+            back = _run_length(t_seq[t_last::-1], v)            # includes t_last itself
+            u_v = fwd + back if (fwd and back) else (fwd or back or 1)
+            entry = ("D", "-", u_v)
+            variant_coords_t[t_last] = entry
+            variant_coords_c[c_last + 1] = entry                # the base right of the deletion carries it on c
+            alignment_c_to_t[t_last] = aln_c[max(0, i - 1): i + u_v + 1]
+            alignment_t_to_c[c_last + 1] = aln_t[max(0, i - 1): i + u_v + 1]
+        elif p_t == "-":                                        # the candidate has an extra base
+            v = c_seq[c_last]
+            fwd = _run_length(t_seq[t_last + 1:], v)
+            back = _run_length(t_seq[t_last::-1], v)            # t_last == -1 slices from the END of t, as in the reference
+            # x + 1 ways to insert one more character into a homopolymer of x characters
+            u_v = fwd + back + 1 if (fwd and back) else (fwd + 1 if fwd else (back + 1 if back else 1))
+            entry = ("I", p_c, u_v)
+            variant_coords_t[t_last + 1] = entry
+            variant_coords_c[c_last] = entry
+            alignment_c_to_t[t_last + 1] = aln_c[max(0, i - 1): i + u_v + 1]
+            alignment_t_to_c[c_last] = aln_t[max(0, i - 1): i + u_v + 1]
+        else:
+            entry = ("S", p_c, 1)
+            variant_coords_t[t_last] = entry
+            variant_coords_c[c_last] = entry
+            alignment_c_to_t[t_last] = aln_c[max(0, i - 1): i + 2]
+            alignment_t_to_c[c_last] = aln_t[max(0, i - 1): i + 2]
+    return variant_coords_t, variant_coords_c, alignment_c_to_t, alignment_t_to_c
+
+
+def get_support(read_alignments_to_c, variant_coords_c, read_alignments_to_t, variant_coords_t, alignment_c_to_t):
+    """functions.py:149-201: the reads that carry every variant of the candidate.  A read aligned to c must agree with
+    c's alignment row over the variant and one column either side (u_v columns for a homopolymer); a read aligned to t
+    must show c's snippet there (shifted by one for an insertion, whose coordinate on t is the base to its right).
+    Returns the accessions: supporters among c's reads, then supporters among t's reads."""
+    supporters = []
+    for read_acc, (aln_c, aln_read, _) in read_alignments_to_c.items():
+        col_of = [j for j, ch in enumerate(aln_c) if ch != "-"]
+        for i, (_, _, u_v) in variant_coords_c.items():
+            pos = col_of[i]
+            lo, hi = max(0, pos - 1), pos + u_v + 1
+            if aln_read[lo:hi] != aln_c[lo:hi]:
+                break
+        else:
+            supporters.append(read_acc)
+    from_t = []
+    for read_acc, (aln_t, aln_read, _) in read_alignments_to_t.items():
+        col_of = [j for j, ch in enumerate(aln_t) if ch != "-"]
+        for i, (v_type, _, u_v) in variant_coords_t.items():
+            pos = col_of[i]
+            window = aln_read[max(0, pos - 2): pos + u_v] if v_type == "I" else aln_read[max(0, pos - 1): pos + u_v + 1]
+            if window != alignment_c_to_t[i]:
+                break
+        else:
+            from_t.append(read_acc)
+    return supporters + from_t
+
+
+def read_errors_from_alignment(ref_aln, read_aln):
+    """functions.py:495-522: (insertions, deletions, substitutions) of the read, end gaps of either row excluded."""
+    n = len(ref_aln)
+    start = max(n - len(ref_aln.lstrip("-")), len(read_aln) - len(read_aln.lstrip("-")))
+    stop = n - max(n - len(ref_aln.rstrip("-")), len(read_aln) - len(read_aln.rstrip("-")))
+    ins = dele = sub = 0
+    for a, b in zip(ref_aln[start:stop], read_aln[start:stop]):
+        if a != b:
+            if a == "-":
+                ins += 1
+            elif b == "-":
+                dele += 1
+            else:
+                sub += 1
+    return ins, dele, sub
+
+
+def get_read_errors(read_alignments_to_c, read_alignments_to_t):
+    """functions.py:204-216: {read: (insertions, deletions, substitutions)}, t's reads first."""
+    errors = {}
+    for read_acc, (aln_ref, aln_read, _) in read_alignments_to_t.items():
+        errors[read_acc] = read_errors_from_alignment(aln_ref, aln_read)
+    for read_acc, (aln_ref, aln_read, _) in read_alignments_to_c.items():
+        errors[read_acc] = read_errors_from_alignment(aln_ref, aln_read)
+    return errors
+
+
+def get_empirical_error_probabilities(segment_length, errors, variant_coords_t):
+    """functions.py:435-466: per read the probability of producing all variants by sequencing error, from its own error
+    counts (never below one error per class: p = 0 is not allowed), uniform over positions and, for substitutions and
+    insertions, over the 3 / 4 possible characters; homopolymer multiplicity u_v; indel factors capped at 0.5."""
+    delta_size = float(len(variant_coords_t))
+    assert delta_size > 0.0
+    probability = {}
+    for read_acc, (insertions, deletions, substitutions) in errors.items():
+        p_S = (max(substitutions, delta_size) / float(segment_length)) / 3.0
+        p_I = (max(insertions, delta_size) / float(segment_length)) / 4.0
+        p_D = (max(deletions, delta_size) / float(segment_length))
+        prob = 1.0
+        for v_type, _, u_v in variant_coords_t.values():
+            if v_type == "S":
+                prob *= p_S * u_v
+            elif v_type == "I":
+                prob *= min(0.5, p_I * u_v)
+            elif v_type == "D":
+                prob *= min(0.5, p_D * u_v)
+        if prob >= 1.0:
+            prob = 0.99999
+        probability[read_acc] = prob
+    return probability
+
+
+def choose(n, k):
+    """functions.py:479-492: binomial coefficient, 0 outside 0 <= k <= n."""
+    import math
+    return math.comb(n, k) if 0 <= k <= n else 0

@@ -1,0 +1,205 @@
+"""The statistical-test phase: mirror of
+/root/reference/modules/isocon_statistical_test.py:152-536 (`stat_filter_candidates`, `product_with_check_overflow`).
+
+Rounds until nothing changes: (re)assign unassigned reads to the surviving candidates (2-set NN search, exact distances,
+semi-global alignments, exon filter -- the hot-path kernels), pick for every candidate the closest surviving candidates
+of the static candidate-vs-candidate graph (built once with the infix kernel, end_invariant_functions), test each such
+edge (hypothesis_test_module), drop the candidates whose largest corrected p-value is at or above the threshold (the
+larger of p_value_threshold and the median corrected p-value), hand their reads to the next round.  One extra round
+re-aligns every read ("to avoid local maxima") and adds homopolymer-equivalent candidates as references.  Same files
+written: temp_candidates_step_<k>.fa, remaining_to_align.fa, p_values_<k>.tsv, candidates_after_step_<k>.fa,
+final_candidates.fa, cluster_info.tsv.  Not provided: quality values (params.is_fastq / params.ccs read the qualities in
+the reference; here FASTQ input contributes its sequences only and a BAM file raises).
+
+Where the reference iterates a Python set (the reads of a candidate's partition), this module iterates the sorted set:
+the reference's p-values depend on that order in their last digits (tests/golden/make_golden_stat_test.py)."""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+
+from . import end_invariant_functions, functions, hypothesis_test_module, partitions
+from .SW_alignment_module import sw_align_sequences_keeping_accession
+from .edlib_alignment_module import edlib_align_sequences_keeping_accession
+from .input_output import fasta_parser, fastq_parser, write_output
+
+
+def product_with_check_overflow(p_value, mult_factor_inv):
+    """isocon_statistical_test.py:143-149: p-value x (integer) correction factor; 1.0 when the product overflows a float."""
+    try:
+        return p_value * mult_factor_inv
+    except OverflowError:
+        return 1.0
+
+
+def _assign_reads(to_realign, C, X, read_partition, params, remaining_file, candidate_file_name):
+    """:269-313: reads without a candidate go to their nearest candidate; candidates left without reads disappear."""
+    write_output.print_reads(remaining_file, to_realign)
+    _, partition_of_realigned_reads = partitions.partition_strings_2set(to_realign, C, remaining_file, candidate_file_name, params)
+    reassigned = {c_acc: {read_acc: (C[c_acc], X[read_acc]) for read_acc in sorted(reads)} for c_acc, reads in partition_of_realigned_reads.items()}
+    edit_distances = edlib_align_sequences_keeping_accession(reassigned, nr_cores=params.nr_cores)
+    alignments = sw_align_sequences_keeping_accession(edit_distances, nr_cores=params.nr_cores)
+    functions.filter_exon_differences(alignments, params.min_exon_diff, params.ignore_ends_len)
+    for c_acc in alignments:
+        for read_acc in alignments[c_acc]:
+            read_partition[c_acc][read_acc] = alignments[c_acc][read_acc]
+    for c_acc in list(read_partition.keys()):
+        if len(read_partition[c_acc]) == 0:
+            del C[c_acc]
+            del read_partition[c_acc]
+
+
+def _tests_of_this_round(C, static_graph, add_homopolymer_edges):
+    """:327-366: for every candidate its closest surviving candidates in the static graph."""
+    graph = {}
+    min_ed = None
+    for c_acc in C:
+        graph[c_acc] = {}
+        if len(static_graph[c_acc]) > 0:
+            alive = [ed for nbr, ed in static_graph[c_acc].items() if nbr in C]
+            if alive:
+                min_ed = min(alive)
+            for nbr in static_graph[c_acc]:
+                if nbr in C and static_graph[c_acc][nbr] == min_ed:
+                    graph[c_acc][nbr] = min_ed
+    if add_homopolymer_edges:
+        for c_acc, nbrs in functions.get_homopolymer_invariants(C).items():
+            graph.setdefault(c_acc, {})
+            for t_acc in nbrs:
+                graph[c_acc].setdefault(t_acc, 1)
+    return graph
+
+
+def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign, params):
+    """isocon_statistical_test.py:152-536.  read_partition: {c_acc: {read_acc: (c_aln, read_aln, (matches, mismatches,
+    indels))}} and to_realign as returned by find_candidate_transcripts.  Returns the surviving candidates {acc: seq}."""
+    if getattr(params, "ccs", None):
+        raise NotImplementedError("stat_filter_candidates: CCS quality values from a BAM file are not provided")
+    if params.is_fastq:
+        X_original = {acc: seq for (acc, seq, qual) in fastq_parser.readfq(open(read_file, "r"))}
+    else:
+        X_original = {acc: seq for (acc, seq) in fasta_parser.read_fasta(open(read_file, "r"))}
+    assigned = set(x_acc for c_acc in read_partition for x_acc in read_partition[c_acc])
+    X = {acc: seq for (acc, seq) in X_original.items() if acc in assigned or acc in to_realign}
+    final_out_file_name = os.path.join(params.outfolder, "final_candidates.fa")
+    tsv_info = os.path.join(params.outfolder, "cluster_info.tsv")
+    if os.stat(candidate_file).st_size == 0:
+        write_output.print_candidates(final_out_file_name, {}, {}, {}, {}, params, final=True, reads_to_consensus_tsv=tsv_info)
+        sys.exit(0)
+    C = {acc: seq for (acc, seq) in fasta_parser.read_fasta(open(candidate_file, "r"))}
+    ccs_dict = {}
+
+    candidates_nn_graph_static = end_invariant_functions.get_NN_graph_ignored_ends_edlib(C, params)
+
+    modified = True
+    step = 1
+    previous_partition_of_X = copy.deepcopy(read_partition)
+    previous_edges = {c_acc: set() for c_acc in C}
+    significance_values = {}
+    highest_significance_values = {}
+    realignment_to_avoid_local_max = 0
+    remaining_to_align_read_file = os.path.join(params.outfolder, "remaining_to_align.fa")
+    while modified:
+        modified = False
+        temp_candidate_name = os.path.join(params.outfolder, "temp_candidates_step_{0}.fa".format(step))
+        with open(temp_candidate_name, "w") as fh:
+            for c_acc, c_seq in C.items():
+                fh.write(">{0}\n{1}\n".format(c_acc, c_seq))
+
+        if realignment_to_avoid_local_max == 1:         # the final round: every read is placed again
+            to_realign = X
+            read_partition = {c_acc: {} for c_acc in C}
+        if to_realign:
+            _assign_reads(to_realign, C, X, read_partition, params, remaining_to_align_read_file, temp_candidate_name)
+
+        nearest_neighbor_graph = _tests_of_this_round(C, candidates_nn_graph_static, realignment_to_avoid_local_max > 0)
+
+        # :373-400: no test for a candidate that dominates its reference; a test whose two read sets are unchanged keeps
+        # its previous result
+        previous_significance_values = {}
+        for c_acc in list(nearest_neighbor_graph.keys()):
+            for t_acc in list(nearest_neighbor_graph[c_acc].keys()):
+                if len(read_partition[c_acc]) >= params.min_test_ratio * len(read_partition[t_acc]):
+                    del nearest_neighbor_graph[c_acc][t_acc]
+            previous_significance_values[c_acc] = {}
+            unchanged = []
+            for t_acc in list(nearest_neighbor_graph[c_acc].keys()):
+                if ((c_acc, t_acc) in previous_edges[c_acc] and previous_partition_of_X[t_acc] == read_partition[t_acc]
+                        and previous_partition_of_X[c_acc] == read_partition[c_acc]):
+                    previous_significance_values[c_acc][t_acc] = significance_values[c_acc][t_acc]
+                    unchanged.append(t_acc)
+            previous_edges[c_acc] = set((c_acc, t_acc) for t_acc in nearest_neighbor_graph[c_acc])
+            for t_acc in unchanged:
+                del nearest_neighbor_graph[c_acc][t_acc]
+
+        if any(len(nbrs) > 0 for nbrs in nearest_neighbor_graph.values()):
+            new_significance_values = hypothesis_test_module.do_statistical_tests_per_edge(nearest_neighbor_graph, C, X, read_partition, ccs_dict, params)
+            for c_acc in new_significance_values:
+                for t_acc in new_significance_values[c_acc]:
+                    previous_significance_values[c_acc][t_acc] = new_significance_values[c_acc][t_acc]
+        significance_values = copy.deepcopy(previous_significance_values)
+        assert len(significance_values) == len(C)
+
+        # :421-431: per candidate the test with the largest corrected p-value (the last one among equals)
+        highest_significance_values = {}
+        for c_acc in significance_values:
+            corrected_p_val_max = 0.0
+            highest = (c_acc, "", "not_tested", 1.0, len(read_partition[c_acc]), len(read_partition[c_acc]), "")
+            for t_acc in significance_values[c_acc]:
+                (p_value, mult_factor_inv, k, N_t, variants) = significance_values[c_acc][t_acc]
+                corr_p_value = product_with_check_overflow(p_value, mult_factor_inv)
+                if corr_p_value >= corrected_p_val_max:
+                    corrected_p_val_max = corr_p_value
+                    highest = (c_acc, t_acc, p_value, mult_factor_inv, k, N_t, variants)
+            highest_significance_values[c_acc] = highest
+
+        # :433-446: threshold = max(p_value_threshold, median corrected p-value of the tested candidates)
+        p_val_threshold = params.p_value_threshold
+        corrected_pvals = sorted(product_with_check_overflow(h[2], h[3]) for h in highest_significance_values.values() if h[2] != "not_tested")
+        if corrected_pvals:
+            half = int(len(corrected_pvals) / 2)
+            median = (corrected_pvals[half - 1] + corrected_pvals[half]) / 2.0 if len(corrected_pvals) % 2 == 0 else corrected_pvals[half]
+            p_val_threshold = median if median > params.p_value_threshold else params.p_value_threshold
+
+        to_realign = {}
+        with open(os.path.join(params.outfolder, "p_values_{0}.tsv".format(step)), "w") as p_value_tsv_file:
+            for (c_acc, t_acc, p_value, mult_factor_inv, k, N_t, variants) in list(highest_significance_values.values()):
+                if p_value == "not_tested":
+                    continue
+                if k == 0 or product_with_check_overflow(p_value, mult_factor_inv) >= p_val_threshold:
+                    del C[c_acc]
+                    modified = True
+                    for x_acc in read_partition[c_acc]:
+                        to_realign[x_acc] = X[x_acc]
+                    del read_partition[c_acc]
+                shown = 1.0 if k == 0 else min(1.0, product_with_check_overflow(p_value, mult_factor_inv))
+                p_value_tsv_file.write("{0}\t{1}\n".format(c_acc + "_" + str(k) + "_" + str(shown) + "_" + str(N_t) + "_" + str(len(variants)), str(p_value)))
+
+        previous_partition_of_X = copy.deepcopy(read_partition)
+        candidate_file = os.path.join(params.outfolder, "candidates_after_step_{0}.fa".format(step))
+        step += 1
+        if len(C) == 0:
+            break
+        write_output.print_candidates(candidate_file, C, highest_significance_values, read_partition, X, params)
+
+        if realignment_to_avoid_local_max == 1:
+            realignment_to_avoid_local_max = 2
+        elif not modified and realignment_to_avoid_local_max == 0:
+            realignment_to_avoid_local_max = 1
+            modified = True
+        write_output.logger("Statistical test, step {0} done".format(step), getattr(params, "logfile", None))
+
+    if params.ignore_ends_len > 0:          # :509-528: candidates equal up to their ends collapse once more
+        c_acc_to_support = {c_acc: len(reads) for c_acc, reads in read_partition.items()}
+        remaining = end_invariant_functions.collapse_candidates_under_ends_invariant(C, c_acc_to_support, params)
+        for c_acc in remaining:
+            for removed_c_acc in remaining[c_acc]:
+                for read_acc, aln in read_partition[removed_c_acc].items():
+                    read_partition[c_acc][read_acc] = aln
+                del C[removed_c_acc]
+                del c_acc_to_support[removed_c_acc]
+                del read_partition[removed_c_acc]
+
+    write_output.print_candidates(final_out_file_name, C, highest_significance_values, read_partition, X, params, final=True, reads_to_consensus_tsv=tsv_info)
+    return C

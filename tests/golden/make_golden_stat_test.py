@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Golden fixture tests/golden/g15_stat_test.json: the reference's own pipeline of IsoCon:145-177 --
+modules/isocon_get_candidates.py::find_candidate_transcripts followed by
+modules/isocon_statistical_test.py::stat_filter_candidates -- on its public test FASTA (n = 200) and on synthetic read
+sets, default parameters (ignore_ends_len 15, p_value_threshold 0.01, min_test_ratio 5), under PYTHONHASHSEED 0..2 (kept if
+all agree up to the last digits of the p-values, see norm_floats).  Stored: final_candidates.fa (accession incl. support / p-value / N_t / variants, sequence digest),
+cluster_info.tsv (read -> candidate), every p_values_<step>.tsv, the number of test rounds.  edlib / parasail are absent:
+tests/golden/shims forward to the CPU oracle (tie-breaks "parity unpinned").  Build container only."""
+import contextlib
+import glob
+import hashlib
+import io
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def sha(s):
+    return hashlib.sha1(s.encode()).hexdigest()[:16]
+
+
+def inputs():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    from isocon_amd import synth
+    from make_golden_inputs import read_fasta
+    fa = read_fasta(os.path.join(REF, "test", "data", "simulated_pacbio_reads_n_200.fa"))
+    accs, seqs, _ = synth.make_reads(150, 500, 3, seed=81)
+    accs2, seqs2, _ = synth.make_reads(260, 700, 4, seed=82)
+    return [("test_data_n200", fa), ("synth_150x500_3iso", dict(zip(accs, seqs))), ("synth_260x700_4iso", dict(zip(accs2, seqs2)))]
+
+
+def collect(tmp):
+    finals = []
+    acc = None
+    for line in open(os.path.join(tmp, "final_candidates.fa")):
+        if line.startswith(">"):
+            acc = line[1:].strip()
+        else:
+            finals.append([acc, sha(line.strip()), len(line.strip())])
+    info = [l.rstrip("\n").split("\t") for l in open(os.path.join(tmp, "cluster_info.tsv"))]
+    pv = {}
+    for f in sorted(glob.glob(os.path.join(tmp, "p_values_*.tsv"))):
+        pv[os.path.basename(f)] = [l.rstrip("\n").split("\t") for l in open(f)]
+    return {"final_candidates": finals, "cluster_info": sorted(info), "p_values": pv}
+
+
+def child(ci):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(HERE, "shims"))
+    sys.path.insert(0, REF)
+    import networkx
+    if not hasattr(networkx.Graph, "node"):
+        networkx.Graph.node = property(lambda g: g.nodes)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from modules import isocon_get_candidates as R_IGC
+        from modules import isocon_statistical_test as R_ST
+    name, S = inputs()[ci]
+    with tempfile.TemporaryDirectory() as tmp:
+        read_file = os.path.join(tmp, "reads.fa")
+        with open(read_file, "w") as fh:
+            for acc, seq in S.items():
+                fh.write(">%s\n%s\n" % (acc, seq))
+
+        class Params(object):
+            nr_cores = 1
+            neighbor_search_depth = 2 ** 32
+            verbose = False
+            develop_logfile = None
+            logfile = open(os.path.join(tmp, "log.txt"), "w")
+            min_exon_diff = 20
+            ignore_ends_len = 15
+            min_candidate_support = 2
+            p_value_threshold = 0.01
+            min_test_ratio = 5
+            max_phred_q_trusted = 43
+            is_fastq = False
+            ccs = None
+            outfolder = tmp
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            cand_file, read_partition, to_realign = R_IGC.find_candidate_transcripts(read_file, Params())
+            R_ST.stat_filter_candidates(read_file, cand_file, read_partition, to_realign, Params())
+        out = collect(tmp)
+    sys.stdout.write(json.dumps(out))
+
+
+def norm_floats(obj):
+    """Floats inside strings (p-values in accessions / tsv cells) rounded to 10 significant digits: the reference sums
+    per-read terms in dict order, which follows set iteration (PYTHONHASHSEED) -- the last ulp of a p-value moves, nothing
+    else does.  tests/test_stat_test.py applies the same normalisation (tolerance 1e-10 relative)."""
+    import re
+    if isinstance(obj, list):
+        return [norm_floats(x) for x in obj]
+    if isinstance(obj, dict):
+        return {k: norm_floats(v) for k, v in obj.items()}
+    if isinstance(obj, str):
+        return re.sub(r"\d+\.\d+(e-?\d+)?", lambda m: "%.9e" % float(m.group()), obj)
+    return obj
+
+
+def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--child":
+        return child(int(sys.argv[2]))
+    kept, dropped, stored_inputs = [], [], {}
+    for ci, (name, S) in enumerate(inputs()):
+        outs = []
+        for seed in range(3):
+            env = dict(os.environ, PYTHONHASHSEED=str(seed))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(ci)], env=env, capture_output=True, text=True)
+            if r.returncode:
+                print(r.stderr[-3000:])
+                raise SystemExit(1)
+            outs.append(r.stdout)
+        agree = all(norm_floats(json.loads(o)) == norm_floats(json.loads(outs[0])) for o in outs)
+        e = json.loads(outs[0])
+        if agree:
+            kept.append({"name": name, "input": name, "expect": e})
+            stored_inputs[name] = [[a, s] for a, s in S.items()]
+        else:
+            dropped.append(name)
+        print(name, "agree" if agree else "HASH-ORDER DEPENDENT", len(S), "reads ->", len(e["final_candidates"]), "final candidates,", len(e["p_values"]), "test rounds,",
+              len(e["cluster_info"]), "reads assigned")
+        for f in e["final_candidates"]:
+            print("   ", f[0][:110], f[2])
+    g12 = json.load(open(os.path.join(HERE, "g12_candidates.json")))["inputs"]
+    stored_inputs = {k: v for k, v in stored_inputs.items() if g12.get(k) != v}
+    json.dump({"generator": "tests/golden/make_golden_stat_test.py", "hash_order_dependent_cases_dropped": dropped, "cases": kept, "inputs": stored_inputs,
+               "inputs_note": "inputs not listed here are the ones of the same name in g12_candidates.json"},
+              open(os.path.join(HERE, "g15_stat_test.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    main()
