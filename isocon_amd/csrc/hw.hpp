@@ -17,7 +17,7 @@
 //   cur[d] = min over d' <= d of a[d'] + (d - d')                       (horizontal runs: a prefix-min of a[d'] - d')
 // Integer work on 32-bit lanes; both sequences sit in LDS as one byte per base.  HBM traffic = the two packed sequences in
 // and 20 B out per pair (+ 16 B per row and block of decision bits for the pairs that reach phase C), so the kernel is
-// bound by the cross-lane operations of the prefix-min (6 per row and block), not by memory.
+// bound by the dependent chain of cross-lane operations per row (prefix-min: 7 DPP steps; shifts: DPP wave shifts), not by memory.
 #pragma once
 #include "common.hpp"
 
@@ -25,14 +25,26 @@ namespace isocon {
 
 static constexpr int32_t HW_INF = 1 << 24;
 
-__device__ __forceinline__ int32_t hw_prefix_min(int32_t v, int lane)
+// Cross-lane moves as DPP modifiers (VALU, no LDS round trip): a lane that has no source keeps `old`.
+template <int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ int32_t hw_dpp(int32_t old, int32_t v)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t w = __shfl_up(v, o, 64);
-        if (lane >= o) v = w < v ? w : v;
-    }
-    return v;
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ int32_t hw_min(int32_t a, int32_t b) { return a < b ? a : b; }
+
+// inclusive prefix-min over the 64 lanes: three single shifts inside the 16-lane rows, shifts by 4 and 8 for the upper
+// banks, then lane 15 / lane 31 broadcast into the following rows
+__device__ __forceinline__ int32_t hw_prefix_min(int32_t v)
+{
+    constexpr int32_t I = 0x7fffffff;
+    int32_t r = hw_min(v, hw_dpp<0x111, 0xf, 0xf>(I, v));                // row_shr:1
+    r = hw_min(r, hw_dpp<0x112, 0xf, 0xf>(I, v));                        // row_shr:2
+    r = hw_min(r, hw_dpp<0x113, 0xf, 0xf>(I, v));                        // row_shr:3
+    r = hw_min(r, hw_dpp<0x114, 0xf, 0xe>(I, r));                        // row_shr:4, banks 1-3
+    r = hw_min(r, hw_dpp<0x118, 0xf, 0xc>(I, r));                        // row_shr:8, banks 2-3
+    r = hw_min(r, hw_dpp<0x142, 0xa, 0xf>(I, r));                        // row_bcast:15 into rows 1 and 3
+    r = hw_min(r, hw_dpp<0x143, 0xc, 0xf>(I, r));                        // row_bcast:31 into rows 2 and 3
+    return r;
 }
 
 // Rows 0..n of one banded matrix.  Cell (i, j): query base i (1-based; reversed order when qrev), target base j
@@ -56,23 +68,21 @@ __device__ __forceinline__ void hw_band_rows(const uint8_t *Q, int32_t n, bool q
         for (int b = 0; b < NB; ++b) {
             const int32_t d = lane + 64 * b;
             const int32_t j = i + d - off;
-            int32_t up = __shfl_down(cur[b], 1, 64);
             const int32_t nxt0 = b + 1 < NB ? __builtin_amdgcn_readfirstlane(cur[b + 1 < NB ? b + 1 : b]) : HW_INF;
-            if (lane == 63) up = nxt0;
+            const int32_t up = hw_dpp<0x130, 0xf, 0xf>(nxt0, cur[b]);    // wave_shl:1: lane l takes lane l + 1, lane 63 keeps nxt0
             const bool valid = j >= 0 && j <= m;
             int32_t tc = 255;
             if (j >= 1 && j <= m) tc = T[trev ? t0 - (j - 1) : t0 + (j - 1)];
             const int32_t diag = cur[b] + (tc != qc ? 1 : 0);           // (i-1, j-1) is diagonal d of the previous row
             int32_t a = diag < up + 1 ? diag : up + 1;
             if (!valid || a > HW_INF) a = HW_INF;
-            int32_t pm = hw_prefix_min(a - d, lane);
+            int32_t pm = hw_prefix_min(a - d);
             pm = pm < run ? pm : run;
             int32_t v = pm + d;
             if (!valid || v > HW_INF) v = HW_INF;
             run = __builtin_amdgcn_readlane(pm, 63);
             if (TRACE) {
-                int32_t left = __shfl_up(v, 1, 64);
-                if (lane == 0) left = left_in;
+                const int32_t left = hw_dpp<0x138, 0xf, 0xf>(left_in, v);   // wave_shr:1: lane l takes lane l - 1, lane 0 keeps left_in
                 const uint64_t m_up = __ballot(valid && up + 1 == v);
                 const uint64_t m_left = __ballot(valid && left + 1 == v);
                 if (lane == 0) {

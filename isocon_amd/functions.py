@@ -291,16 +291,9 @@ def get_variant_coordinates(t_seq, c_seq, aln_t, aln_c, variants):
     (variant_coords_t, variant_coords_c, alignment_c_to_t, alignment_t_to_c); later variants overwrite earlier ones that
     land on the same coordinate, as in the reference."""
     variant_coords_t, variant_coords_c, alignment_c_to_t, alignment_t_to_c = {}, {}, {}, {}
-    # number of sequence characters in aln[:i + 1], for both rows
-    upto_t, upto_c = [], []
-    nt = nc = 0
-    for a, b in zip(aln_t, aln_c):
-        nt += a != "-"
-        nc += b != "-"
-        upto_t.append(nt)
-        upto_c.append(nc)
     for (i, p_t, p_c) in variants:
-        t_last, c_last = upto_t[i] - 1, upto_c[i] - 1           # last base of t / c at or before column i
+        # last base of t / c at or before column i (sequence characters in aln[:i + 1], minus one)
+        t_last, c_last = i - aln_t.count("-", 0, i + 1), i - aln_c.count("-", 0, i + 1)
         if p_c == "-":                                          # the candidate lacks a base of t
             v = t_seq[t_last]
             fwd = _run_length(t_seq[t_last + 1:], v)

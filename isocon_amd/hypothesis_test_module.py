@@ -17,13 +17,63 @@ from __future__ import annotations
 import decimal
 import math
 
+import numpy as np
+
 from . import functions
 from . import SW_alignment_module as SWM
 
 
+class _ReadTable(object):
+    """The stored alignments of one candidate's reads as flat arrays, so that the per-read quantities of a test --
+    alignment column of a candidate position, error counts, window comparisons -- are computed once per round and for all
+    reads at a time instead of once per (edge, read) as functions.get_support / get_read_errors do.  Same results
+    (tests/test_stat_test.py::test_read_tables_equal_the_per_read_functions)."""
+
+    def __init__(self, ref_len, read_alignments):
+        self.__dict__.update(_build_tables([(ref_len, read_alignments)])[0].__dict__)
+
+    def column_of(self, i, still_ok):
+        """alignment column of candidate position i, per read (functions.get_support: c_seq_to_coord_in_almnt[i])"""
+        if not -self.ref_len <= i < self.ref_len:
+            if still_ok.any():
+                raise IndexError("list index out of range")         # what the per-read statement raises for these reads
+            return np.zeros(self.n, dtype=np.int64)
+        if i < 0:
+            i += self.ref_len
+        return i + np.bincount(self.gap_row[self.gap_h <= i], minlength=self.n)
+
+    def agree_with_candidate(self, variant_coords):
+        """reads whose row equals the candidate's row over every variant window (get_support, reads of c)"""
+        ok = np.ones(self.n, dtype=bool)
+        for i, (_, _, u_v) in variant_coords.items():
+            pos = self.column_of(i, ok)
+            for w in range(-1, u_v + 1):
+                col = pos + w
+                valid = (col >= 0) & (col < self.len)
+                ok &= ~(valid & self.diff[np.clip(self.off0 + col, 0, self.total - 1)])
+        return ok
+
+    def show_snippets(self, variant_coords, snippets):
+        """reads that show the other sequence's snippet at every variant (get_support, reads of t)"""
+        ok = np.ones(self.n, dtype=bool)
+        for i, (v_type, _, u_v) in variant_coords.items():
+            pos = self.column_of(i, ok)
+            snippet = np.frombuffer(snippets[i].encode("ascii"), dtype=np.uint8)
+            before, after = (2, u_v) if v_type == "I" else (1, u_v + 1)
+            lo = np.maximum(0, pos - before)
+            hi = np.minimum(self.len, pos + after)
+            match = np.maximum(hi - lo, 0) == len(snippet)
+            for j in range(len(snippet)):
+                match &= self.read[np.clip(self.off0 + lo + j, 0, self.total - 1)] == snippet[j]
+            ok &= match
+        return ok
+
+
 def _variants_of(aln_t, aln_c):
     start, end = functions.get_mask_start_and_end(aln_t, aln_c)           # indels in the ends are length differences, not variants
-    return [(i, p_t, p_c) for i, (p_t, p_c) in enumerate(zip(aln_t, aln_c)) if p_t != p_c and start <= i < end]
+    a = np.frombuffer(aln_t.encode("ascii"), dtype=np.uint8)
+    b = np.frombuffer(aln_c.encode("ascii"), dtype=np.uint8)
+    return [(i, aln_t[i], aln_c[i]) for i in np.flatnonzero(a != b).tolist() if start <= i < end]
 
 
 def _candidate_vs_reference(alignment_tc, alignment_ct):
@@ -53,6 +103,136 @@ def _test_on_alignments(t_seq, c_seq, alignment_tc, alignment_ct, read_alignment
     else:
         p_value = raghavan_upper_pvalue_bound(probability, reads_support)
     return variant_coords_t, p_value, reads_support, len(probability)
+
+
+def _build_tables(items):
+    """_ReadTable objects for [(ref_len, read_alignments)]: one pass of array operations over the reads of all of them,
+    the tables are slices of the shared arrays."""
+    per, rows_ref, rows_read, end_ref, end_read = [0], [], [], [], []
+    for _, ra in items:
+        for v in ra.values():
+            a, b = v[0], v[1]
+            rows_ref.append(a)
+            rows_read.append(b)
+            # columns of the leading + trailing gap run of either row (they are not errors: read_errors_from_alignment)
+            end_ref.append(2 * len(a) - len(a.lstrip("-")) - len(a.rstrip("-")))
+            end_read.append(2 * len(b) - len(b.lstrip("-")) - len(b.rstrip("-")))
+        per.append(len(rows_ref))
+    n = len(rows_ref)
+    lens = np.fromiter((len(r) for r in rows_ref), dtype=np.int64, count=n)
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    off0 = off[:-1]
+    ref = np.frombuffer("".join(rows_ref).encode("ascii"), dtype=np.uint8)
+    read = np.frombuffer("".join(rows_read).encode("ascii"), dtype=np.uint8)
+    diff = ref != read
+    # gaps of the candidate's row: a gap with h candidate characters before it shifts every position >= h by one column
+    g = np.flatnonzero(ref == 45)
+    gap_row = np.searchsorted(off, g, side="right") - 1
+    first_gap = np.searchsorted(gap_row, np.arange(n + 1))
+    gap_h = (g - off0[gap_row]) - (np.arange(len(g), dtype=np.int64) - first_gap[gap_row])
+    # Error counts between the end gaps (functions.read_errors_from_alignment).  A column never holds two gaps and an end
+    # run of one row faces bases of the other, so: insertions = gaps of the candidate's row outside its end runs,
+    # deletions = the same for the read's row, substitutions = the remaining differing columns.
+    if n:
+        gaps_ref = first_gap[1:] - first_gap[:-1]
+        gaps_read = np.fromiter((r.count("-") for r in rows_read), dtype=np.int64, count=n)
+        ins = gaps_ref - np.asarray(end_ref, dtype=np.int64)
+        dele = gaps_read - np.asarray(end_read, dtype=np.int64)
+        sub = np.add.reduceat(diff.view(np.uint8), off0, dtype=np.int64) - gaps_ref - gaps_read
+    else:
+        ins = dele = sub = np.zeros(0, dtype=np.int64)
+    tables = []
+    for k, (ref_len, ra) in enumerate(items):
+        r0, r1 = per[k], per[k + 1]
+        b0, b1 = int(off[r0]), int(off[r1])
+        g0, g1 = int(first_gap[r0]), int(first_gap[r1])
+        t = _ReadTable.__new__(_ReadTable)
+        t.accs = list(ra)
+        t.n = r1 - r0
+        t.ref_len = ref_len
+        t.len = lens[r0:r1]
+        t.off0 = off0[r0:r1] - b0
+        t.total = b1 - b0
+        t.read = read[b0:b1]
+        t.diff = diff[b0:b1]
+        t.gap_row = gap_row[g0:g1] - r0
+        t.gap_h = gap_h[g0:g1]
+        t.ins, t.dele, t.sub = ins[r0:r1], dele[r0:r1], sub[r0:r1]
+        tables.append(t)
+    return tables
+
+
+_TABLES = {}        # id(read-alignment dict) -> (the dict, its values' identities, table); reset by clear_tables()
+
+
+def clear_tables():
+    _TABLES.clear()
+
+
+def _tables_for(wanted):
+    """{id(read_alignments): table} for [(ref_seq, read_alignments)]; a table is rebuilt only when the candidate's reads or
+    their alignments have changed since the last round (the loop keeps most partitions untouched from round to round)."""
+    out, todo = {}, []
+    for ref_seq, ra in wanted:
+        if id(ra) in out:
+            continue
+        stamp = [id(v) for v in ra.values()]
+        hit = _TABLES.get(id(ra))
+        if hit is not None and hit[0] is ra and hit[1] == stamp and hit[2].ref_len == len(ref_seq):
+            out[id(ra)] = hit[2]
+        else:
+            out[id(ra)] = None
+            todo.append((ref_seq, ra, stamp))
+    if len(_TABLES) > 200000:
+        _TABLES.clear()
+    for lo in range(0, len(todo), 2048):                 # bounded batches: the shared arrays stay small
+        part = todo[lo:lo + 2048]
+        for (ref_seq, ra, stamp), tab in zip(part, _build_tables([(len(r), a) for r, a, _ in part])):
+            _TABLES[id(ra)] = (ra, stamp, tab)
+            out[id(ra)] = tab
+    return out
+
+
+def _test_on_tables(t_seq, c_seq, alignment_tc, alignment_ct, tab_c, tab_t):
+    """_test_on_alignments on the read tables of c and t: same tuple, the supporting reads as a count."""
+    aln_t, aln_c, variants = _candidate_vs_reference(alignment_tc, alignment_ct)
+    variant_coords_t, variant_coords_c, alignment_c_to_t, alignment_t_to_c = functions.get_variant_coordinates(t_seq, c_seq, aln_t, aln_c, variants)
+    sup_c = np.flatnonzero(tab_c.agree_with_candidate(variant_coords_c))
+    sup_t = np.flatnonzero(tab_t.show_snippets(variant_coords_t, alignment_c_to_t))
+    n_support = len(sup_c) + len(sup_t)
+    if len(variants) == 0:
+        return variant_coords_t, 0.0, n_support, tab_c.n + tab_t.n
+    # error probabilities per read, t's reads first (functions.get_read_errors / get_empirical_error_probabilities)
+    n_reads = tab_t.n + tab_c.n
+    if n_reads == 0:
+        assert n_support == 0
+        return variant_coords_t, 0.0, n_support, 0
+    delta_size = float(len(variant_coords_t))
+    seg = float(len(t_seq))
+    p_S = (np.maximum(np.concatenate([tab_t.sub, tab_c.sub]), delta_size) / seg) / 3.0
+    p_I = (np.maximum(np.concatenate([tab_t.ins, tab_c.ins]), delta_size) / seg) / 4.0
+    p_D = np.maximum(np.concatenate([tab_t.dele, tab_c.dele]), delta_size) / seg
+    prob = np.ones(n_reads, dtype=np.float64)
+    for v_type, _, u_v in variant_coords_t.values():
+        if v_type == "S":
+            prob *= p_S * u_v
+        elif v_type == "I":
+            prob *= np.minimum(0.5, p_I * u_v)
+        elif v_type == "D":
+            prob *= np.minimum(0.5, p_D * u_v)
+    prob[prob >= 1.0] = 0.99999
+    # Raghavan's bound (raghavan_upper_pvalue_bound): logarithms with math.log per distinct probability, sums in read order
+    assert prob.max() <= 1.0 and prob.min() > 0.0
+    uniq, inv = np.unique(prob, return_inverse=True)
+    logs = [-math.log(p, 10) for p in uniq.tolist()]
+    log_max = max(logs)
+    assert log_max > 0
+    w_u = np.asarray([l / log_max for l in logs], dtype=np.float64)
+    weight = w_u[inv]
+    m_sum = sum((w_u * uniq)[inv].tolist())
+    y_sum = sum(weight[np.concatenate([tab_t.n + sup_c, sup_t])].tolist()) if n_support else 0
+    return variant_coords_t, _raghavan_from_sums(m_sum, y_sum), n_support, n_reads
 
 
 def arrange_alignments_new_no_realign(t_acc, c_acc, t_seq, c_seq, read_alignments_to_c, read_alignments_to_t, ccs_dict, ignore_ends_len, max_phred_q_trusted):
@@ -93,14 +273,16 @@ def do_statistical_tests_per_edge(nearest_neighbor_graph, C, X, read_partition, 
     alignments = SWM._align_pairs(pairs, [-3] * len(pairs), 2, 3, 1) if pairs else []
     of_edge = {e: (alignments[2 * i], alignments[2 * i + 1]) for i, e in enumerate(live)}
     p_values = {c_acc: {} for c_acc in nearest_neighbor_graph}
+    tables = _tables_for([(C[acc], read_partition[acc]) for e in live for acc in e])
     for c_acc, t_acc in edges:
         if (c_acc, t_acc) not in of_edge:
             p_values[c_acc][t_acc] = (1.0, 1.0, 0, 0, "")
             continue
         assert not (set(read_partition[c_acc]) & set(read_partition[t_acc]))
         tc, ct = of_edge[(c_acc, t_acc)]
-        delta_t, p_value, reads_support, used = _test_on_alignments(C[t_acc], C[c_acc], tc, ct, read_partition[c_acc], read_partition[t_acc])
-        p_values[c_acc][t_acc] = _result(c_acc, t_acc, C[t_acc], delta_t, p_value, reads_support, used)[2:]
+        delta_t, p_value, n_support, used = _test_on_tables(C[t_acc], C[c_acc], tc, ct, tables[id(read_partition[c_acc])],
+                                                            tables[id(read_partition[t_acc])])
+        p_values[c_acc][t_acc] = _result(c_acc, t_acc, C[t_acc], delta_t, p_value, range(n_support), used)[2:]
     return p_values
 
 
@@ -115,10 +297,14 @@ def raghavan_upper_pvalue_bound(probability, x_equal_to_one):
     log_p_i_max = max(log_probabilities.values())
     assert log_p_i_max > 0
     weight = {acc: log_probabilities[acc] / log_p_i_max for acc in log_probabilities}
+    return _raghavan_from_sums(sum([weight[acc] * probability[acc] for acc in probability]), sum([weight[x_i] for x_i in x_equal_to_one]))
+
+
+def _raghavan_from_sums(m_sum, y_sum):
     with decimal.localcontext() as ctx:
         ctx.prec = 100
-        m = decimal.Decimal(sum([weight[acc] * probability[acc] for acc in probability]))
-        y = decimal.Decimal(sum([weight[x_i] for x_i in x_equal_to_one]))
+        m = decimal.Decimal(m_sum)
+        y = decimal.Decimal(y_sum)
         d = y / m - 1
         k = m * d
         if y == 0:

@@ -15,7 +15,6 @@ Where the reference iterates a Python set (the reads of a candidate's partition)
 the reference's p-values depend on that order in their last digits (tests/golden/make_golden_stat_test.py)."""
 from __future__ import annotations
 
-import copy
 import os
 import sys
 
@@ -31,6 +30,12 @@ def product_with_check_overflow(p_value, mult_factor_inv):
         return p_value * mult_factor_inv
     except OverflowError:
         return 1.0
+
+
+def _snapshot(read_partition):
+    """What the reference gets from copy.deepcopy(read_partition) (:209, :483): the values are tuples of strings and
+    integers, never modified in place, so copying the two dict levels is the same thing."""
+    return {c_acc: dict(reads) for c_acc, reads in read_partition.items()}
 
 
 def _assign_reads(to_realign, C, X, read_partition, params, remaining_file, candidate_file_name):
@@ -94,8 +99,9 @@ def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign
 
     modified = True
     step = 1
-    previous_partition_of_X = copy.deepcopy(read_partition)
+    previous_partition_of_X = _snapshot(read_partition)
     previous_edges = {c_acc: set() for c_acc in C}
+    hypothesis_test_module.clear_tables()
     significance_values = {}
     highest_significance_values = {}
     realignment_to_avoid_local_max = 0
@@ -138,7 +144,7 @@ def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign
             for c_acc in new_significance_values:
                 for t_acc in new_significance_values[c_acc]:
                     previous_significance_values[c_acc][t_acc] = new_significance_values[c_acc][t_acc]
-        significance_values = copy.deepcopy(previous_significance_values)
+        significance_values = {c_acc: dict(tests) for c_acc, tests in previous_significance_values.items()}
         assert len(significance_values) == len(C)
 
         # :421-431: per candidate the test with the largest corrected p-value (the last one among equals)
@@ -176,7 +182,7 @@ def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign
                 shown = 1.0 if k == 0 else min(1.0, product_with_check_overflow(p_value, mult_factor_inv))
                 p_value_tsv_file.write("{0}\t{1}\n".format(c_acc + "_" + str(k) + "_" + str(shown) + "_" + str(N_t) + "_" + str(len(variants)), str(p_value)))
 
-        previous_partition_of_X = copy.deepcopy(read_partition)
+        previous_partition_of_X = _snapshot(read_partition)
         candidate_file = os.path.join(params.outfolder, "candidates_after_step_{0}.fa".format(step))
         step += 1
         if len(C) == 0:
@@ -202,4 +208,5 @@ def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign
                 del read_partition[removed_c_acc]
 
     write_output.print_candidates(final_out_file_name, C, highest_significance_values, read_partition, X, params, final=True, reads_to_consensus_tsv=tsv_info)
+    hypothesis_test_module.clear_tables()
     return C

@@ -129,3 +129,55 @@ def test_raghavan_bound_known_values():
 @pytest.mark.parametrize("case", G15, ids=[c["name"] for c in G15])
 def test_gpu_pipeline(case, tmp_path):
     assert norm_floats(run(case, tmp_path)) == norm_floats(case["expect"])
+
+
+def test_read_tables_equal_the_per_read_functions():
+    """The vectorised per-candidate read tables (hypothesis_test_module._ReadTable / _test_on_tables) against the per-read
+    statements in isocon_amd.functions (get_support, get_read_errors, get_empirical_error_probabilities) and
+    raghavan_upper_pvalue_bound: identical variants, supporter counts, reads used and bit-equal p-values."""
+    import random
+    from isocon_amd import hypothesis_test_module as H
+    from oracle import oracle as O
+    rng = random.Random(11)
+
+    def mut(b, n, homopolymer=0.5):
+        v = list(b)
+        for _ in range(n):
+            p = rng.randrange(len(v))
+            r = rng.random()
+            if r < 0.4:
+                v[p] = rng.choice("ACGT")
+            elif r < 0.7:
+                del v[p]
+            else:
+                v.insert(p, v[p] if rng.random() < homopolymer else rng.choice("ACGT"))
+        return "".join(v)
+
+    def aln(a, b, **kw):
+        return O.parasail_alignment(a, b, 0, 0, **kw)[2]
+
+    tested = 0
+    for trial in range(120):
+        t = "".join(rng.choice("AACGTT") for _ in range(rng.randint(40, 160)))
+        c = mut(t, rng.randint(0, 4))
+        if rng.random() < 0.3:
+            c = c[rng.randint(0, 6):]
+        if rng.random() < 0.3:
+            c = c + "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 6)))
+        if c == t:
+            continue
+        reads_c = {"c%d" % k: aln(c, mut(c, rng.randint(0, 4))[rng.randint(0, 3):]) for k in range(rng.randint(0, 7))}
+        reads_t = {"t%d" % k: aln(t, mut(t if rng.random() < 0.6 else c, rng.randint(0, 4))) for k in range(rng.randint(0, 9))}
+        tc = aln(t, c, opening_penalty=3, mismatch_penalty=-3, gap_ext=1)
+        ct = aln(c, t, opening_penalty=3, mismatch_penalty=-3, gap_ext=1)
+        try:
+            slow = H._test_on_alignments(t, c, tc, ct, reads_c, reads_t)
+        except IndexError:
+            with pytest.raises(IndexError):
+                H._test_on_tables(t, c, tc, ct, H._ReadTable(len(c), reads_c), H._ReadTable(len(t), reads_t))
+            continue
+        fast = H._test_on_tables(t, c, tc, ct, H._ReadTable(len(c), reads_c), H._ReadTable(len(t), reads_t))
+        assert list(slow[0].items()) == list(fast[0].items())
+        assert slow[1] == fast[1] and len(slow[2]) == fast[2] and slow[3] == fast[3], (trial, slow[1], fast[1])
+        tested += slow[1] not in (0.0, 1.0)
+    assert tested > 20
