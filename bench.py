@@ -286,7 +286,14 @@ def main():
             store.sg_trace(t[:64], q[:64], mm[:64], ed_upper=ed[:64])
             t0 = time.perf_counter(); ops_b, ptr_b, res_b, swb_ms = store.sg_trace(t, q, mm, return_ms=True, ed_upper=ed); swb_wall = time.perf_counter() - t0
             same = bool((res_b == res).all() and len(ops_b) == len(ops) and (ops_b == ops).all())
+            # infix alignments (edlib HW + path, the candidate graph of the statistical test) of the same pairs, k = 25 and 63
+            store.hw_pairs(t[:64], q[:64], 25)
+            hw25, hw25_ms = store.hw_pairs(t, q, 25, return_ms=True)
+            hw63, hw63_ms = store.hw_pairs(t, q, 63, return_ms=True)
             result["other_kernels"] = {
+                "hw_pairs_per_s_kernel_k25": len(q) / (hw25_ms / 1e3) if hw25_ms > 0 else None, "hw_hits_k25": int((hw25[:, 0] >= 0).sum()),
+                "hw_pairs_per_s_kernel_k63": len(q) / (hw63_ms / 1e3) if hw63_ms > 0 else None, "hw_hits_k63": int((hw63[:, 0] >= 0).sum()),
+                "hw_distance_le_global_distance": bool(((hw63[:, 0] <= ed) | (ed > 63))[hw63[:, 0] >= 0].all()),
                 "pairs": int(len(q)),
                 "ed_pairs_per_s_kernel": len(q) / (ed_ms / 1e3) if ed_ms > 0 else None, "ed_pairs_wall_ms": ed_wall * 1e3,
                 "sw_pairs_per_s_kernel": len(q) / (sw_ms / 1e3) if sw_ms > 0 else None, "sw_wall_ms": sw_wall * 1e3,
