@@ -408,3 +408,71 @@ def choose(n, k):
     """functions.py:479-492: binomial coefficient, 0 outside 0 <= k <= n."""
     import math
     return math.comb(n, k) if 0 <= k <= n else 0
+
+
+def _ccs_probabilities(read_alignments, variant_coords, other_snippets, ccs_dict, errors, max_phred_q_trusted, shifted_type, coord_when_other):
+    """Shared body of get_read_ccs_probabilities_c / _t (functions.py:240-331, :334-433).  For every read aligned to one of
+    the two sequences ("own"): at every variant the read must show either its own sequence's row or the other sequence's
+    snippet exactly (else the read is not informative); the base quality at that place -- remapped from [3, 93] to
+    [3, max_phred_q_trusted] -- gives the probability of the variant arising by a base-call error, split over the error
+    classes by the partition's overall ratios (a homopolymer variant takes the whole base-call uncertainty).
+    shifted_type: the variant type whose coordinate on "own" is the base to its right (snippet window shifted by one);
+    coord_when_other: {type: offset} of the read coordinate relative to the bases seen up to the variant column when the
+    read shows the OTHER sequence."""
+    subs = float(max(1.0, sum([s for i, d, s in errors.values()])))
+    ins = float(max(1.0, sum([i for i, d, s in errors.values()])))
+    del_ = float(max(1.0, sum([d for i, d, s in errors.values()])))
+    tot_errors = subs + ins + del_
+    subs_ratio, ins_ratio, del_ratio = subs / tot_errors, ins / tot_errors, del_ / tot_errors
+    assert len(variant_coords) > 0
+    probabilities = {}
+    not_supporting = set()
+    for read_acc, (aln_own, aln_read, _) in read_alignments.items():
+        col_of = [j for j, ch in enumerate(aln_own) if ch != "-"]
+        prob = 1.0
+        for i, (v_type, _, u_v) in variant_coords.items():
+            pos = col_of[i]
+            lo, hi = max(0, pos - 1), pos + u_v + 1
+            shows_own = aln_read[lo:hi] == aln_own[lo:hi]
+            if v_type == shifted_type:
+                shows_other = aln_read[max(0, pos - 2): pos + u_v] == other_snippets[i]
+            else:
+                shows_other = aln_read[lo:hi] == other_snippets[i]
+            assert not (shows_own and shows_other)
+            seen = pos + 1 - aln_read.count("-", 0, pos + 1)           # read bases in aln_read[:pos + 1]
+            if shows_own:
+                read_coord = seen - 1
+            elif shows_other:
+                read_coord = seen + coord_when_other.get(v_type, -1)
+            else:
+                not_supporting.add(read_acc)
+                prob = -1
+                break
+            record = ccs_dict[read_acc]
+            q_qual = record.qual[record.read_aln_to_ccs_coord(aln_read, read_coord)]
+            q_qual_mapped = (q_qual - 3) * (max_phred_q_trusted - 3.0) / (90.0) + 3
+            if u_v > 1:
+                p_error = (10 ** (-q_qual_mapped / 10.0))
+            elif v_type == "S":
+                p_error = ((10 ** (-q_qual_mapped / 10.0)) * subs_ratio) / 3.0
+            elif v_type == "I":
+                p_error = ((10 ** (-q_qual_mapped / 10.0)) * ins_ratio) / 4.0
+            else:
+                p_error = (10 ** (-q_qual_mapped / 10.0)) * del_ratio
+            prob *= p_error
+        if prob >= 0:
+            assert 0.0 < prob < 1.0
+            probabilities[read_acc] = prob
+    return probabilities, not_supporting
+
+
+def get_read_ccs_probabilities_c(read_alignments_to_c, variant_coords_c, alignment_t_to_c, ccs_dict, errors, max_phred_q_trusted):
+    """functions.py:240-331: reads aligned to the candidate.  A deletion sits on the base to its right on c; a read that
+    shows t at an insertion is judged on the base after the variant column."""
+    return _ccs_probabilities(read_alignments_to_c, variant_coords_c, alignment_t_to_c, ccs_dict, errors, max_phred_q_trusted, "D", {"I": 0})
+
+
+def get_read_ccs_probabilities_t(read_alignments_to_t, variant_coords_t, alignment_c_to_t, ccs_dict, errors, max_phred_q_trusted):
+    """functions.py:334-433: reads aligned to the reference.  An insertion sits on the base to its right on t; a read that
+    shows c is judged on the next base at a deletion and two bases back at an insertion."""
+    return _ccs_probabilities(read_alignments_to_t, variant_coords_t, alignment_c_to_t, ccs_dict, errors, max_phred_q_trusted, "I", {"D": 0, "I": -2})

@@ -10,8 +10,8 @@ alignments) that carry all of them; bound the probability of that many supporter
 
 The reference aligns the two orders of every edge one call at a time (or one Pool task per edge); here ALL edges of a
 round go to the GPU as one batch of isocon_sg_strings_batch (2 x edges alignments), everything after that is string
-bookkeeping on the host as in the reference.  Quality-value based probabilities (a `ccs_dict`, FASTQ / BAM input of the
-reference) are not provided: a non-empty ccs_dict raises."""
+bookkeeping on the host as in the reference.  With base qualities (a `ccs_dict`: FASTQ input) the error probabilities
+come from functions.get_read_ccs_probabilities_c / _t and the per-read statement is used as is."""
 from __future__ import annotations
 
 import decimal
@@ -88,7 +88,7 @@ def _candidate_vs_reference(alignment_tc, alignment_ct):
     return aln_t, aln_c, variants
 
 
-def _test_on_alignments(t_seq, c_seq, alignment_tc, alignment_ct, read_alignments_to_c, read_alignments_to_t):
+def _test_on_alignments(t_seq, c_seq, alignment_tc, alignment_ct, read_alignments_to_c, read_alignments_to_t, ccs_dict=None, max_phred_q_trusted=None):
     """hypothesis_test_module.py:92-171 after the two alignments: (variant_coords_t, p_value, supporting reads, reads used)."""
     aln_t, aln_c, variants = _candidate_vs_reference(alignment_tc, alignment_ct)
     variant_coords_t, variant_coords_c, alignment_c_to_t, alignment_t_to_c = functions.get_variant_coordinates(t_seq, c_seq, aln_t, aln_c, variants)
@@ -96,7 +96,11 @@ def _test_on_alignments(t_seq, c_seq, alignment_tc, alignment_ct, read_alignment
     if len(variants) == 0:      # identical up to the ignored ends
         return variant_coords_t, 0.0, reads_support, len(read_alignments_to_c) + len(read_alignments_to_t)
     errors = functions.get_read_errors(read_alignments_to_c, read_alignments_to_t)
-    probability = functions.get_empirical_error_probabilities(len(t_seq), errors, variant_coords_t)
+    if ccs_dict:            # base qualities decide (FASTQ input): reads showing neither sequence at a variant drop out
+        probability, _ = functions.get_read_ccs_probabilities_c(read_alignments_to_c, variant_coords_c, alignment_t_to_c, ccs_dict, errors, max_phred_q_trusted)
+        probability.update(functions.get_read_ccs_probabilities_t(read_alignments_to_t, variant_coords_t, alignment_c_to_t, ccs_dict, errors, max_phred_q_trusted)[0])
+    else:
+        probability = functions.get_empirical_error_probabilities(len(t_seq), errors, variant_coords_t)
     if len(probability) == 0:
         assert len(reads_support) == 0
         p_value = 0.0
@@ -237,15 +241,14 @@ def _test_on_tables(t_seq, c_seq, alignment_tc, alignment_ct, tab_c, tab_t):
 
 def arrange_alignments_new_no_realign(t_acc, c_acc, t_seq, c_seq, read_alignments_to_c, read_alignments_to_t, ccs_dict, ignore_ends_len, max_phred_q_trusted):
     """hypothesis_test_module.py:92-171 (single edge; the batch entry point is do_statistical_tests_per_edge)."""
-    if ccs_dict:
-        raise NotImplementedError("quality-value based error probabilities (ccs_dict) are not provided")
     tc, ct = SWM._align_pairs([(t_seq, c_seq), (c_seq, t_seq)], [-3, -3], 2, 3, 1)
-    return _test_on_alignments(t_seq, c_seq, tc, ct, read_alignments_to_c, read_alignments_to_t)
+    return _test_on_alignments(t_seq, c_seq, tc, ct, read_alignments_to_c, read_alignments_to_t, ccs_dict, max_phred_q_trusted)
 
 
-def _result(c_acc, t_acc, t_seq, variant_coords_t, p_value, reads_support, nr_reads_used):
+def _result(c_acc, t_acc, t_seq, variant_coords_t, p_value, reads_support, nr_reads_used, with_qualities=False):
     variant_types = ";".join("(" + str(v[0]) + "," + str(j) + "," + str(v[2]) + ")" for j, v in variant_coords_t.items())
-    return (c_acc, t_acc, p_value, get_correction_factor(t_seq, c_acc, variant_coords_t), len(reads_support), nr_reads_used, variant_types)
+    factor = 1.0 if with_qualities else get_correction_factor(t_seq, c_acc, variant_coords_t)      # :242-246
+    return (c_acc, t_acc, p_value, factor, len(reads_support), nr_reads_used, variant_types)
 
 
 def statistical_test(c_acc, t_acc, c_seq, t_seq, reads_to_c, read_alignments_to_t, read_alignments_to_c, ignore_ends_len, ccs_dict, max_phred_q_trusted):
@@ -254,16 +257,17 @@ def statistical_test(c_acc, t_acc, c_seq, t_seq, reads_to_c, read_alignments_to_
     N_t = len(set(reads_to_c) | set(read_alignments_to_t))
     if N_t == 0:    # all reads of both went elsewhere in the realignment
         return c_acc, t_acc, 1.0, 1.0, 0, N_t, ""
+    if ccs_dict:
+        for x_acc in reads_to_c:
+            assert reads_to_c[x_acc] == ccs_dict[x_acc].seq
     delta_t, p_value, reads_support, used = arrange_alignments_new_no_realign(t_acc, c_acc, t_seq, c_seq, read_alignments_to_c, read_alignments_to_t,
                                                                               ccs_dict, ignore_ends_len, max_phred_q_trusted)
-    return _result(c_acc, t_acc, t_seq, delta_t, p_value, reads_support, used)
+    return _result(c_acc, t_acc, t_seq, delta_t, p_value, reads_support, used, bool(ccs_dict))
 
 
 def do_statistical_tests_per_edge(nearest_neighbor_graph, C, X, read_partition, ccs_dict, params):
     """hypothesis_test_module.py:20-77: {c_acc: {t_acc: (p_value, correction factor, support, reads used, variants)}} for
     every edge c -> t of the graph (nr_cores is irrelevant here: one device batch for all edges)."""
-    if ccs_dict:
-        raise NotImplementedError("quality-value based error probabilities (ccs_dict) are not provided")
     edges = [(c_acc, t_acc) for c_acc in nearest_neighbor_graph for t_acc in nearest_neighbor_graph[c_acc]]
     live = [(c, t) for c, t in edges if len(read_partition[c]) + len(read_partition[t]) > 0]
     pairs = []
@@ -273,13 +277,20 @@ def do_statistical_tests_per_edge(nearest_neighbor_graph, C, X, read_partition, 
     alignments = SWM._align_pairs(pairs, [-3] * len(pairs), 2, 3, 1) if pairs else []
     of_edge = {e: (alignments[2 * i], alignments[2 * i + 1]) for i, e in enumerate(live)}
     p_values = {c_acc: {} for c_acc in nearest_neighbor_graph}
-    tables = _tables_for([(C[acc], read_partition[acc]) for e in live for acc in e])
+    tables = {} if ccs_dict else _tables_for([(C[acc], read_partition[acc]) for e in live for acc in e])
     for c_acc, t_acc in edges:
         if (c_acc, t_acc) not in of_edge:
             p_values[c_acc][t_acc] = (1.0, 1.0, 0, 0, "")
             continue
         assert not (set(read_partition[c_acc]) & set(read_partition[t_acc]))
         tc, ct = of_edge[(c_acc, t_acc)]
+        if ccs_dict:        # with base qualities: the per-read statement (the reads' records are looked up one by one)
+            for x_acc in read_partition[c_acc]:
+                assert X[x_acc] == ccs_dict[x_acc].seq
+            delta_t, p_value, reads_support, used = _test_on_alignments(C[t_acc], C[c_acc], tc, ct, read_partition[c_acc], read_partition[t_acc],
+                                                                        ccs_dict, params.max_phred_q_trusted)
+            p_values[c_acc][t_acc] = _result(c_acc, t_acc, C[t_acc], delta_t, p_value, reads_support, used, True)[2:]
+            continue
         delta_t, p_value, n_support, used = _test_on_tables(C[t_acc], C[c_acc], tc, ct, tables[id(read_partition[c_acc])],
                                                             tables[id(read_partition[t_acc])])
         p_values[c_acc][t_acc] = _result(c_acc, t_acc, C[t_acc], delta_t, p_value, range(n_support), used)[2:]

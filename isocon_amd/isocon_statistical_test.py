@@ -8,8 +8,8 @@ edge (hypothesis_test_module), drop the candidates whose largest corrected p-val
 larger of p_value_threshold and the median corrected p-value), hand their reads to the next round.  One extra round
 re-aligns every read ("to avoid local maxima") and adds homopolymer-equivalent candidates as references.  Same files
 written: temp_candidates_step_<k>.fa, remaining_to_align.fa, p_values_<k>.tsv, candidates_after_step_<k>.fa,
-final_candidates.fa, cluster_info.tsv.  Not provided: quality values (params.is_fastq / params.ccs read the qualities in
-the reference; here FASTQ input contributes its sequences only and a BAM file raises).
+final_candidates.fa, cluster_info.tsv.  FASTQ input (params.is_fastq) brings base qualities into the tests (ccs_info);
+qualities from a BAM file (params.ccs, pysam) are not provided and raise.
 
 Where the reference iterates a Python set (the reads of a candidate's partition), this module iterates the sorted set:
 the reference's p-values depend on that order in their last digits (tests/golden/make_golden_stat_test.py)."""
@@ -18,7 +18,7 @@ from __future__ import annotations
 import os
 import sys
 
-from . import end_invariant_functions, functions, hypothesis_test_module, partitions
+from . import ccs_info, end_invariant_functions, functions, hypothesis_test_module, partitions
 from .SW_alignment_module import sw_align_sequences_keeping_accession
 from .edlib_alignment_module import edlib_align_sequences_keeping_accession
 from .input_output import fasta_parser, fastq_parser, write_output
@@ -94,6 +94,15 @@ def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign
         sys.exit(0)
     C = {acc: seq for (acc, seq) in fasta_parser.read_fasta(open(candidate_file, "r"))}
     ccs_dict = {}
+    if params.is_fastq:         # :180-192: the reads' base qualities, cut and keyed like X
+        ccs_dict_raw = {x_acc.split(" ")[0]: ccs_info.CCS(x_acc.split(" ")[0], seq, [ord(ch) - 33 for ch in qual], "NA")
+                        for (x_acc, seq, qual) in fastq_parser.readfq(open(read_file, "r"))}
+        X_ids = {x_acc.split(" ")[0]: x_acc for x_acc in X}
+        for x_acc in X:
+            assert X_ids[x_acc.split(" ")[0]] == x_acc
+        ccs_dict = ccs_info.modify_strings_and_acc_fastq(ccs_dict_raw, X_ids, X)
+        for x_acc in X:
+            assert X[x_acc] == ccs_dict[x_acc].seq
 
     candidates_nn_graph_static = end_invariant_functions.get_NN_graph_ignored_ends_edlib(C, params)
 

@@ -33,7 +33,18 @@ def inputs():
     fa = read_fasta(os.path.join(REF, "test", "data", "simulated_pacbio_reads_n_200.fa"))
     accs, seqs, _ = synth.make_reads(150, 500, 3, seed=81)
     accs2, seqs2, _ = synth.make_reads(260, 700, 4, seed=82)
-    return [("test_data_n200", fa), ("synth_150x500_3iso", dict(zip(accs, seqs))), ("synth_260x700_4iso", dict(zip(accs2, seqs2)))]
+    # a FASTQ case: the statistical test then takes its error probabilities from the base qualities
+    # (isocon_statistical_test.py:180-192, functions.py:240-433); every third read is marked strand=- (qualities of
+    # homopolymer runs get sorted, ccs_info.py:131-151)
+    import numpy as np
+    accs3, seqs3, _ = synth.make_reads(180, 450, 3, seed=83)
+    rng = np.random.Generator(np.random.PCG64(830))
+    fq = {}
+    for i, (a, s3) in enumerate(zip(accs3, seqs3)):
+        q = rng.integers(4, 61, size=len(s3))
+        fq[a + (";strand=-" if i % 3 == 0 else ";strand=+")] = (s3, "".join(chr(int(v) + 33) for v in q))
+    return [("test_data_n200", fa), ("synth_150x500_3iso", dict(zip(accs, seqs))), ("synth_260x700_4iso", dict(zip(accs2, seqs2))),
+            ("synth_180x450_3iso_fastq", fq)]
 
 
 def collect(tmp):
@@ -62,11 +73,15 @@ def child(ci):
         from modules import isocon_get_candidates as R_IGC
         from modules import isocon_statistical_test as R_ST
     name, S = inputs()[ci]
+    fastq = name.endswith("_fastq")
     with tempfile.TemporaryDirectory() as tmp:
-        read_file = os.path.join(tmp, "reads.fa")
+        read_file = os.path.join(tmp, "reads.fq" if fastq else "reads.fa")
         with open(read_file, "w") as fh:
             for acc, seq in S.items():
-                fh.write(">%s\n%s\n" % (acc, seq))
+                if fastq:
+                    fh.write("@%s\n%s\n+\n%s\n" % (acc, seq[0], seq[1]))
+                else:
+                    fh.write(">%s\n%s\n" % (acc, seq))
 
         class Params(object):
             nr_cores = 1
@@ -80,7 +95,7 @@ def child(ci):
             p_value_threshold = 0.01
             min_test_ratio = 5
             max_phred_q_trusted = 43
-            is_fastq = False
+            is_fastq = fastq
             ccs = None
             outfolder = tmp
 
@@ -122,7 +137,7 @@ def main():
         e = json.loads(outs[0])
         if agree:
             kept.append({"name": name, "input": name, "expect": e})
-            stored_inputs[name] = [[a, s] for a, s in S.items()]
+            stored_inputs[name] = [[a, s] if isinstance(s, str) else [a, s[0], s[1]] for a, s in S.items()]
         else:
             dropped.append(name)
         print(name, "agree" if agree else "HASH-ORDER DEPENDENT", len(S), "reads ->", len(e["final_candidates"]), "final candidates,", len(e["p_values"]), "test rounds,",

@@ -35,9 +35,13 @@ def run(case, tmp_path):
     from isocon_amd import isocon_get_candidates as IGC
     from isocon_amd import isocon_statistical_test as IST
     tmp = str(tmp_path)
-    read_file = os.path.join(tmp, "reads.fa")
+    fastq = case["name"].endswith("_fastq")          # records [acc, seq, qualities]: the tests then use the base qualities
+    read_file = os.path.join(tmp, "reads.fq" if fastq else "reads.fa")
     with open(read_file, "w") as fh:
-        fh.write("".join(">%s\n%s\n" % (a, s) for a, s in case["S"]))
+        if fastq:
+            fh.write("".join("@%s\n%s\n+\n%s\n" % (a, s, q) for a, s, q in case["S"]))
+        else:
+            fh.write("".join(">%s\n%s\n" % (a, s) for a, s in case["S"]))
 
     class Params(object):
         nr_cores = 1
@@ -51,7 +55,7 @@ def run(case, tmp_path):
         p_value_threshold = 0.01
         min_test_ratio = 5
         max_phred_q_trusted = 43
-        is_fastq = False
+        is_fastq = fastq
         ccs = None
         outfolder = tmp
 
@@ -181,3 +185,44 @@ def test_read_tables_equal_the_per_read_functions():
         assert slow[1] == fast[1] and len(slow[2]) == fast[2] and slow[3] == fast[3], (trial, slow[1], fast[1])
         tested += slow[1] not in (0.0, 1.0)
     assert tested > 20
+
+
+_G16 = json.load(open(os.path.join(HERE, "golden", "g16_stat_helpers.json")))
+
+
+@pytest.mark.parametrize("ci", range(len(_G16["cases"])))
+def test_stat_helpers_equal_reference(ci):
+    """The helper functions of the test, called directly, against the reference's own (fixture g16): variant coordinates,
+    supporting reads, per-read errors, empirical and quality-based error probabilities (floats bit-equal)."""
+    from isocon_amd import ccs_info as CI
+    from isocon_amd import functions as F
+    g = _G16["cases"][ci]
+    variants = [tuple(v) for v in g["variants"]]
+    vt, vc, ac2t, at2c = F.get_variant_coordinates(g["t"], g["c"], g["aln_t"], g["aln_c"], variants)
+    assert [[k, list(v)] for k, v in vt.items()] == g["variant_coords_t"] and [[k, list(v)] for k, v in vc.items()] == g["variant_coords_c"]
+    assert [[k, v] for k, v in ac2t.items()] == g["alignment_c_to_t"] and [[k, v] for k, v in at2c.items()] == g["alignment_t_to_c"]
+    rc = {a: (v[0], v[1], tuple(v[2])) for a, v in g["reads_c"].items()}
+    rt = {a: (v[0], v[1], tuple(v[2])) for a, v in g["reads_t"].items()}
+    if g["support"] == "IndexError":
+        with pytest.raises(IndexError):
+            F.get_support(rc, vc, rt, vt, ac2t)
+    else:
+        assert F.get_support(rc, vc, rt, vt, ac2t) == g["support"]
+    errors = F.get_read_errors(rc, rt)
+    assert [[a, list(e)] for a, e in errors.items()] == g["errors"]
+    assert [[a, repr(p)] for a, p in F.get_empirical_error_probabilities(len(g["t"]), errors, vt).items()] == g["empirical"]
+    reads = {a: v[1].replace("-", "") for a, v in list(rc.items()) + list(rt.items())}
+    ccs = {a: CI.CCS(a, reads[a], g["qual"][a], "NA") for a in reads}
+    for key, fn, ra, v, sn in (("ccs_c", F.get_read_ccs_probabilities_c, rc, vc, at2c), ("ccs_t", F.get_read_ccs_probabilities_t, rt, vt, ac2t)):
+        if isinstance(g[key], str):
+            with pytest.raises((AssertionError, IndexError)):
+                fn(ra, v, sn, ccs, errors, 43)
+        else:
+            pr, non = fn(ra, v, sn, ccs, errors, 43)
+            assert [[a, repr(p)] for a, p in pr.items()] == g[key]["prob"] and sorted(non) == g[key]["non_informative"]
+
+
+def test_fix_quality_values_equal_reference():
+    from isocon_amd import ccs_info as CI
+    for s, q, expect in _G16["fix_quality_values"]:
+        assert CI.fix_quality_values(s, q) == expect
