@@ -180,7 +180,7 @@ int isocon_msa_correct(const uint8_t *matrix, uint32_t n_rows, uint32_t n_cols, 
  * as consumed by edlib_traceback (modules/end_invariant_functions.py:593-620) inside get_all_NN (:622-681), the
  * candidate-vs-candidate graph of the statistical-test phase: the query is aligned globally inside the target, target
  * prefix and suffix are free.  k[p] >= 0 is required (k = 10 + ignore_ends_len there); the diagonals a path of cost <= k
- * can visit must fit 256 (max(len(t) - len(q), 0) + 2 k + 1 <= 256), otherwise ISOCON_E_UNSUPPORTED.
+ * can visit must fit 512 (max(len(t) - len(q), 0) + 2 k + 1 <= 512), otherwise ISOCON_E_UNSUPPORTED.
  * out[5 p ..] = editDistance (-1 if > k[p]; then the rest is -1 / 0), locations[0] start, end (0-based, inclusive: the
  * first optimal end, the smallest start for it), length of the insertion run (query bases without target) the path
  * starts with, length of the one it ends with (0 = the CIGAR does not start / end with 'I').  Path = global alignment of

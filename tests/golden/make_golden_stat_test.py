@@ -43,8 +43,10 @@ def inputs():
     for i, (a, s3) in enumerate(zip(accs3, seqs3)):
         q = rng.integers(4, 61, size=len(s3))
         fq[a + (";strand=-" if i % 3 == 0 else ";strand=+")] = (s3, "".join(chr(int(v) + 33) for v in q))
+    fa500 = read_fasta(os.path.join(REF, "test", "data", "simulated_pacbio_reads_n_500.fa"))
+    fa1000 = read_fasta(os.path.join(REF, "test", "data", "simulated_pacbio_reads_n_1000.fa"))
     return [("test_data_n200", fa), ("synth_150x500_3iso", dict(zip(accs, seqs))), ("synth_260x700_4iso", dict(zip(accs2, seqs2))),
-            ("synth_180x450_3iso_fastq", fq)]
+            ("synth_180x450_3iso_fastq", fq), ("test_data_n500", fa500), ("test_data_n1000", fa1000)]
 
 
 def collect(tmp):
@@ -146,8 +148,12 @@ def main():
             print("   ", f[0][:110], f[2])
     g12 = json.load(open(os.path.join(HERE, "g12_candidates.json")))["inputs"]
     stored_inputs = {k: v for k, v in stored_inputs.items() if g12.get(k) != v}
+    import gzip
+    for k in [k for k in stored_inputs if k.startswith("test_data_n")]:      # the larger public test sets: gzipped FASTA next to this file
+        with gzip.GzipFile(os.path.join(HERE, "inputs_%s.fa.gz" % k), "wb", mtime=0) as fh:
+            fh.write("".join(">%s\n%s\n" % (a, q) for a, q in stored_inputs.pop(k)).encode())
     json.dump({"generator": "tests/golden/make_golden_stat_test.py", "hash_order_dependent_cases_dropped": dropped, "cases": kept, "inputs": stored_inputs,
-               "inputs_note": "inputs not listed here are the ones of the same name in g12_candidates.json"},
+               "inputs_note": "inputs not listed here are the ones of the same name in g12_candidates.json or in inputs_<name>.fa.gz"},
               open(os.path.join(HERE, "g15_stat_test.json"), "w"), indent=0)
 
 

@@ -134,7 +134,8 @@ def _mut(rng, b, nmut, ends):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("L,k,ends,npairs", [(120, 25, 20, 300), (700, 25, 20, 120), (2500, 25, 20, 40), (300, 40, 45, 100), (400, 70, 60, 60),
-                                             (200, 0, 0, 60), (64, 5, 3, 200)], ids=["short", "mid", "ccs", "two_blocks", "four_blocks", "k0", "tiny"])
+                                             (600, 120, 50, 40), (200, 0, 0, 60), (64, 5, 3, 200)],
+                         ids=["short", "mid", "ccs", "two_blocks", "four_blocks", "eight_blocks", "k0", "tiny"])
 def test_gpu_hw_pairs_equal_oracle(L, k, ends, npairs):
     """All five outputs (distance, start, end, leading / trailing insertion run) for random related and unrelated pairs,
     one, two and four 64-diagonal blocks."""
@@ -166,5 +167,5 @@ def test_gpu_hw_pairs_limits():
     with pytest.raises(RuntimeError):
         st.hw_pairs([0], [1], [-1])                 # k is required
     with pytest.raises(RuntimeError):
-        st.hw_pairs([0], [1], [200])                # 350 + 400 + 1 diagonals
+        st.hw_pairs([0], [1], [200])                # 350 + 400 + 1 diagonals > 512
     assert list(st.hw_pairs([1], [0], [5])[0]) == [-1, -1, -1, 0, 0]        # query longer than target + k
