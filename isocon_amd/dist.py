@@ -8,7 +8,8 @@ Phase 0 = seed pass (64 nearest longer neighbours of the owned entries); phase 1
 pairs; phase 2 = 128/256/512-row bands (only entries still unresolved after the min-reduction act as queries) and the
 un-banded kernel for the owned queries whose neighbour is further than 511 edits.  Exchange steps (the only data-path
 collectives):
-    all_reduce(MIN) of best[n]   after each of the three phases (tight thresholds everywhere)   (4 B x n)
+    all_reduce(MIN) of best[n]   after each phase (tight thresholds everywhere; phase 2 and its
+                                 reduction are skipped when no query is left unresolved)          (4 B x n)
     all_gather of the candidate edges that attain best[] on their rank                         (12 B x edges)
 The reference has no distributed path (its Pool chunking: /root/reference/modules/nearest_neighbor_graph.py:33-35).
 """
@@ -85,6 +86,18 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
     for phase in (0, 1, 2):
+        if phase == 2:
+            # Nothing left for the wide bands (isocon_nn_partial's own test: a query without a neighbour within 63 edits
+            # that is longer than 63)?  best[] is identical on all ranks after the reduction, so all ranks skip together:
+            # one call and one collective less per step.
+            is_query = np.ones(n, dtype=bool)
+            if is_converged is not None:
+                is_query &= np.asarray(is_converged)[:n] == 0
+            if is_target is not None:
+                is_query &= np.asarray(is_target)[:n] == 0
+            if not (is_query & (best[:n] == _lib.NN_INF) & (np.asarray(store.lens)[:n] > 63)).any():
+                stats_all.append({k: 0 for k in stats_all[-1]} if stats_all else {})
+                continue
         hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth,
                                        q_stride=qs)
         t = torch.from_numpy(best).to(device)
