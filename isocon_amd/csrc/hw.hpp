@@ -50,9 +50,11 @@ __device__ __forceinline__ int32_t hw_prefix_min(int32_t v)
 // Rows 0..n of one banded matrix.  Cell (i, j): query base i (1-based; reversed order when qrev), target base j
 // (t0 + j - 1, or t0 - (j - 1) when trev), j in [0, m].  Diagonal index d = j - i + off.  cur[b] = last row on return.
 // TRACE: trace[(i * NB + b) * 2 + {0,1}] = ballots "vertical step optimal" / "horizontal step optimal" of row i.
-template <int NB, bool TRACE>
-__device__ __forceinline__ void hw_band_rows(const uint8_t *Q, int32_t n, bool qrev, const uint8_t *T, int32_t t0, bool trev, int32_t m,
-                                             int32_t off, bool topzero, uint64_t *trace, int lane, int32_t (&cur)[NB])
+// EARLY: every 32 rows the smallest value of the row is compared with kstop -- row minima never decrease from one row to
+// the next, so once a row exceeds kstop no end cell can be <= kstop: returns false at once (cur is then meaningless).
+template <int NB, bool TRACE, bool EARLY>
+__device__ __forceinline__ bool hw_band_rows(const uint8_t *Q, int32_t n, bool qrev, const uint8_t *T, int32_t t0, bool trev, int32_t m,
+                                             int32_t off, bool topzero, uint64_t *trace, int lane, int32_t (&cur)[NB], int32_t kstop)
 {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -95,13 +97,21 @@ __device__ __forceinline__ void hw_band_rows(const uint8_t *Q, int32_t n, bool q
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) cur[b] = nw[b];
+        if (EARLY && (i & 31) == 0) {
+            int32_t rowmin = cur[0];
+#pragma unroll
+            for (int b = 1; b < NB; ++b) rowmin = hw_min(rowmin, cur[b]);
+            if (wave_min_i32(rowmin) > kstop) return false;            // wave-uniform
+        }
     }
+    return true;
 }
 
-// out[5 p ..] = distance (-1: > k, -3: band does not fit 64 NB diagonals), start, end, leading insertion run, trailing insertion run.
+// out[5 p ..] = distance (-1: > k, -3: band does not fit), start, end, leading insertion run, trailing insertion run.
+// NBA blocks of 64 diagonals for phase A (max(len(t) - len(q), 0) + 2 k + 1 diagonals), NB for phases B and C (2 k + 1).
 // grid = any number of 64-thread blocks (pairs are dealt round-robin); trace: (maxlen + 1) * NB * 2 words per block;
 // dynamic LDS = 2 * lds_stride bytes (lds_stride >= maxlen, multiple of 8).
-template <int NB>
+template <int NBA, int NB>
 __global__ __launch_bounds__(64) void k_hw_path(DevStore S, const uint32_t *__restrict__ pq, const uint32_t *__restrict__ pt, const int32_t *__restrict__ pk,
                                                  uint32_t n_pairs, uint64_t *__restrict__ trace_all, uint32_t trace_rows,
                                                  uint32_t lds_stride, int32_t *__restrict__ out)
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(64) void k_hw_path(DevStore S, const uint32_t *__re
         const int32_t delta = m - n;
         const int32_t width_a = delta + 2 * k + 1, width_b = 2 * k + 1;
         if (n > 0 && m > 0 && k >= 0 && delta >= -k) {
-            if (width_a > 64 * NB || width_b > 64 * NB || n + 1 > (int32_t)trace_rows || n > (int32_t)lds_stride || m > (int32_t)lds_stride) r_h = -3;
+            if (width_a > 64 * NBA || width_b > 64 * NB || n + 1 > (int32_t)trace_rows || n > (int32_t)lds_stride || m > (int32_t)lds_stride) r_h = -3;
             else {
                 __syncthreads();                                        // previous pair's readers are done with the LDS
                 for (int32_t x = lane; x < n; x += 64) {
@@ -134,26 +144,26 @@ __global__ __launch_bounds__(64) void k_hw_path(DevStore S, const uint32_t *__re
                     T[x] = (uint8_t)(((lo >> (x & 63)) & 1) | (((hi >> (x & 63)) & 1) << 1));
                 }
                 __syncthreads();
-                int32_t cur[NB];
+                int32_t cur_a[NBA], cur[NB];
                 // phase A: distance and first end column
-                hw_band_rows<NB, false>(Q, n, false, T, 0, false, m, k, true, nullptr, lane, cur);
+                const bool alive = hw_band_rows<NBA, false, true>(Q, n, false, T, 0, false, m, k, true, nullptr, lane, cur_a, k);
                 int32_t h = HW_INF;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
+                for (int b = 0; b < NBA; ++b) {
                     const int32_t j = n + lane + 64 * b - k;
-                    if (j >= 1 && j <= m && cur[b] < h) h = cur[b];
+                    if (alive && j >= 1 && j <= m && cur_a[b] < h) h = cur_a[b];
                 }
                 h = wave_min_i32(h);
                 if (h <= k) {
                     int32_t e = HW_INF;
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
+                    for (int b = 0; b < NBA; ++b) {
                         const int32_t j = n + lane + 64 * b - k;
-                        if (j >= 1 && j <= m && cur[b] == h && j < e) e = j;
+                        if (j >= 1 && j <= m && cur_a[b] == h && j < e) e = j;
                     }
                     const int32_t end = wave_min_i32(e) - 1;
                     // phase B: smallest start whose global distance to target[start..end] is h
-                    hw_band_rows<NB, false>(Q, n, true, T, end, true, end + 1, k, false, nullptr, lane, cur);
+                    hw_band_rows<NB, false, false>(Q, n, true, T, end, true, end + 1, k, false, nullptr, lane, cur, k);
                     int32_t pl = -1;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(64) void k_hw_path(DevStore S, const uint32_t *__re
                     else {
                         const int32_t start = end - (pl - 1), ms = pl;
                         // phase C: decision bits of the global alignment query vs target[start..end], then the walk
-                        hw_band_rows<NB, true>(Q, n, false, T, start, false, ms, k, false, trace, lane, cur);
+                        hw_band_rows<NB, true, false>(Q, n, false, T, start, false, ms, k, false, trace, lane, cur, k);
                         // the walk: every lane follows the same cells (uniform addresses, one broadcast load per step)
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // lane 0's decision words, read by all lanes
                         int32_t trail = 0;
