@@ -76,6 +76,50 @@ def _tests_of_this_round(C, static_graph, add_homopolymer_edges):
     return graph
 
 
+def _prune_tests(tests, read_partition, last_round_reads, last_round_tests, results, min_test_ratio):
+    """:373-400.  Drops from `tests` (in place) the edges c -> t where c has at least min_test_ratio times the reads of t
+    (it would pass anyway) and those that were scheduled last round with both read sets unchanged since (their result is
+    carried over).  Returns (carried results per candidate, the edges scheduled this round per candidate)."""
+    carried, scheduled = {}, dict(last_round_tests)
+    for c_acc, row in tests.items():
+        for t_acc in [t for t in row if len(read_partition[c_acc]) >= min_test_ratio * len(read_partition[t])]:
+            del row[t_acc]
+        same_c = None
+        carried[c_acc] = {}
+        for t_acc in list(row):
+            if (c_acc, t_acc) not in last_round_tests[c_acc]:
+                continue
+            if same_c is None:
+                same_c = last_round_reads[c_acc] == read_partition[c_acc]
+            if same_c and last_round_reads[t_acc] == read_partition[t_acc]:
+                carried[c_acc][t_acc] = results[c_acc][t_acc]
+        scheduled[c_acc] = set((c_acc, t_acc) for t_acc in row)
+        for t_acc in carried[c_acc]:
+            del row[t_acc]
+    return carried, scheduled
+
+
+def _worst_test(c_acc, rows, n_reads):
+    """:421-431: the test of a candidate with the largest corrected p-value (the last one among equals), as the tuple
+    (c_acc, t_acc, p_value, correction factor, supporting reads, reads used, variants) the writers expect."""
+    worst, worst_corrected = (c_acc, "", "not_tested", 1.0, n_reads, n_reads, ""), 0.0
+    for t_acc, (p_value, factor, support, N_t, variants) in rows.items():
+        corrected = product_with_check_overflow(p_value, factor)
+        if corrected >= worst_corrected:
+            worst, worst_corrected = (c_acc, t_acc, p_value, factor, support, N_t, variants), corrected
+    return worst
+
+
+def _rejection_threshold(worst, p_value_threshold):
+    """:433-446: the larger of p_value_threshold and the median corrected p-value over the tested candidates."""
+    tested = sorted(product_with_check_overflow(w[2], w[3]) for w in worst.values() if w[2] != "not_tested")
+    if not tested:
+        return p_value_threshold
+    half = int(len(tested) / 2)
+    median = (tested[half - 1] + tested[half]) / 2.0 if len(tested) % 2 == 0 else tested[half]
+    return median if median > p_value_threshold else p_value_threshold
+
+
 def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign, params):
     """isocon_statistical_test.py:152-536.  read_partition: {c_acc: {read_acc: (c_aln, read_aln, (matches, mismatches,
     indels))}} and to_realign as returned by find_candidate_transcripts.  Returns the surviving candidates {acc: seq}."""
@@ -108,11 +152,11 @@ def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign
 
     modified = True
     step = 1
-    previous_partition_of_X = _snapshot(read_partition)
-    previous_edges = {c_acc: set() for c_acc in C}
+    last_round_reads = _snapshot(read_partition)
+    last_round_tests = {c_acc: set() for c_acc in C}
     hypothesis_test_module.clear_tables()
-    significance_values = {}
-    highest_significance_values = {}
+    results = {}            # {c_acc: {t_acc: (p_value, correction factor, supporting reads, reads used, variants)}}
+    worst = {}
     realignment_to_avoid_local_max = 0
     remaining_to_align_read_file = os.path.join(params.outfolder, "remaining_to_align.fa")
     while modified:
@@ -128,75 +172,39 @@ def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign
         if to_realign:
             _assign_reads(to_realign, C, X, read_partition, params, remaining_to_align_read_file, temp_candidate_name)
 
-        nearest_neighbor_graph = _tests_of_this_round(C, candidates_nn_graph_static, realignment_to_avoid_local_max > 0)
+        tests = _tests_of_this_round(C, candidates_nn_graph_static, realignment_to_avoid_local_max > 0)
 
-        # :373-400: no test for a candidate that dominates its reference; a test whose two read sets are unchanged keeps
-        # its previous result
-        previous_significance_values = {}
-        for c_acc in list(nearest_neighbor_graph.keys()):
-            for t_acc in list(nearest_neighbor_graph[c_acc].keys()):
-                if len(read_partition[c_acc]) >= params.min_test_ratio * len(read_partition[t_acc]):
-                    del nearest_neighbor_graph[c_acc][t_acc]
-            previous_significance_values[c_acc] = {}
-            unchanged = []
-            for t_acc in list(nearest_neighbor_graph[c_acc].keys()):
-                if ((c_acc, t_acc) in previous_edges[c_acc] and previous_partition_of_X[t_acc] == read_partition[t_acc]
-                        and previous_partition_of_X[c_acc] == read_partition[c_acc]):
-                    previous_significance_values[c_acc][t_acc] = significance_values[c_acc][t_acc]
-                    unchanged.append(t_acc)
-            previous_edges[c_acc] = set((c_acc, t_acc) for t_acc in nearest_neighbor_graph[c_acc])
-            for t_acc in unchanged:
-                del nearest_neighbor_graph[c_acc][t_acc]
+        # :373-400: which of these tests are actually run
+        kept_results, last_round_tests = _prune_tests(tests, read_partition, last_round_reads, last_round_tests, results, params.min_test_ratio)
+        if any(tests.values()):
+            for c_acc, row in hypothesis_test_module.do_statistical_tests_per_edge(tests, C, X, read_partition, ccs_dict, params).items():
+                kept_results[c_acc].update(row)
+        results = kept_results
+        assert len(results) == len(C)
 
-        if any(len(nbrs) > 0 for nbrs in nearest_neighbor_graph.values()):
-            new_significance_values = hypothesis_test_module.do_statistical_tests_per_edge(nearest_neighbor_graph, C, X, read_partition, ccs_dict, params)
-            for c_acc in new_significance_values:
-                for t_acc in new_significance_values[c_acc]:
-                    previous_significance_values[c_acc][t_acc] = new_significance_values[c_acc][t_acc]
-        significance_values = {c_acc: dict(tests) for c_acc, tests in previous_significance_values.items()}
-        assert len(significance_values) == len(C)
+        worst = {c_acc: _worst_test(c_acc, rows, len(read_partition[c_acc])) for c_acc, rows in results.items()}     # :421-431
+        limit = _rejection_threshold(worst, params.p_value_threshold)                                                 # :433-446
 
-        # :421-431: per candidate the test with the largest corrected p-value (the last one among equals)
-        highest_significance_values = {}
-        for c_acc in significance_values:
-            corrected_p_val_max = 0.0
-            highest = (c_acc, "", "not_tested", 1.0, len(read_partition[c_acc]), len(read_partition[c_acc]), "")
-            for t_acc in significance_values[c_acc]:
-                (p_value, mult_factor_inv, k, N_t, variants) = significance_values[c_acc][t_acc]
-                corr_p_value = product_with_check_overflow(p_value, mult_factor_inv)
-                if corr_p_value >= corrected_p_val_max:
-                    corrected_p_val_max = corr_p_value
-                    highest = (c_acc, t_acc, p_value, mult_factor_inv, k, N_t, variants)
-            highest_significance_values[c_acc] = highest
-
-        # :433-446: threshold = max(p_value_threshold, median corrected p-value of the tested candidates)
-        p_val_threshold = params.p_value_threshold
-        corrected_pvals = sorted(product_with_check_overflow(h[2], h[3]) for h in highest_significance_values.values() if h[2] != "not_tested")
-        if corrected_pvals:
-            half = int(len(corrected_pvals) / 2)
-            median = (corrected_pvals[half - 1] + corrected_pvals[half]) / 2.0 if len(corrected_pvals) % 2 == 0 else corrected_pvals[half]
-            p_val_threshold = median if median > params.p_value_threshold else params.p_value_threshold
-
+        # :448-480: candidates without support or not significant leave, their reads are placed again in the next round
         to_realign = {}
-        with open(os.path.join(params.outfolder, "p_values_{0}.tsv".format(step)), "w") as p_value_tsv_file:
-            for (c_acc, t_acc, p_value, mult_factor_inv, k, N_t, variants) in list(highest_significance_values.values()):
+        with open(os.path.join(params.outfolder, "p_values_{0}.tsv".format(step)), "w") as tsv:
+            for (c_acc, t_acc, p_value, factor, support, N_t, variants) in list(worst.values()):
                 if p_value == "not_tested":
                     continue
-                if k == 0 or product_with_check_overflow(p_value, mult_factor_inv) >= p_val_threshold:
+                corrected = product_with_check_overflow(p_value, factor)
+                if support == 0 or corrected >= limit:
+                    to_realign.update((x_acc, X[x_acc]) for x_acc in read_partition.pop(c_acc))
                     del C[c_acc]
                     modified = True
-                    for x_acc in read_partition[c_acc]:
-                        to_realign[x_acc] = X[x_acc]
-                    del read_partition[c_acc]
-                shown = 1.0 if k == 0 else min(1.0, product_with_check_overflow(p_value, mult_factor_inv))
-                p_value_tsv_file.write("{0}\t{1}\n".format(c_acc + "_" + str(k) + "_" + str(shown) + "_" + str(N_t) + "_" + str(len(variants)), str(p_value)))
+                label = "_".join([c_acc, str(support), str(1.0 if support == 0 else min(1.0, corrected)), str(N_t), str(len(variants))])
+                tsv.write(label + "\t" + str(p_value) + "\n")
 
-        previous_partition_of_X = _snapshot(read_partition)
+        last_round_reads = _snapshot(read_partition)
         candidate_file = os.path.join(params.outfolder, "candidates_after_step_{0}.fa".format(step))
         step += 1
         if len(C) == 0:
             break
-        write_output.print_candidates(candidate_file, C, highest_significance_values, read_partition, X, params)
+        write_output.print_candidates(candidate_file, C, worst, read_partition, X, params)
 
         if realignment_to_avoid_local_max == 1:
             realignment_to_avoid_local_max = 2
@@ -216,6 +224,6 @@ def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign
                 del c_acc_to_support[removed_c_acc]
                 del read_partition[removed_c_acc]
 
-    write_output.print_candidates(final_out_file_name, C, highest_significance_values, read_partition, X, params, final=True, reads_to_consensus_tsv=tsv_info)
+    write_output.print_candidates(final_out_file_name, C, worst, read_partition, X, params, final=True, reads_to_consensus_tsv=tsv_info)
     hypothesis_test_module.clear_tables()
     return C
