@@ -1,5 +1,5 @@
 """Wall time of the whole pipeline (find_candidate_transcripts + stat_filter_candidates) on synthetic CCS reads, with a
-breakdown of the statistical-test phase.  Usage: python scripts/time_full_pipeline.py [n_reads] [length] [isoforms]"""
+breakdown of the statistical-test phase.  Usage: python scripts/time_full_pipeline.py [n_reads] [length] [isoforms] [ont]"""
 import cProfile, os, pstats, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from isocon_amd import synth
@@ -8,7 +8,10 @@ from isocon_amd import isocon_statistical_test as IST
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 2500
 iso = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-accs, seqs, isoforms = synth.make_reads(n, L, iso, 30001)
+if len(sys.argv) > 4 and sys.argv[4] == "ont":      # ONT error profile (6 %), two gene families of mixed length
+    accs, seqs, isoforms = synth.make_reads(n, 0, iso, 50001, profile=synth.ONT_PROFILE, families=2, length_range=(1000, L))
+else:
+    accs, seqs, isoforms = synth.make_reads(n, L, iso, 30001)
 with tempfile.TemporaryDirectory() as tmp:
     rf = os.path.join(tmp, "reads.fa")
     with open(rf, "w") as fh:
