@@ -160,6 +160,30 @@ def sharded_ed_pairs(store, a, b, k=None, dist=None, device=None):
     return out
 
 
+def sharded_hw_pairs(store, q, t, k, dist=None, device=None):
+    """Infix alignments (SeqStore.hw_pairs: distance, start, end, leading / trailing insertion run) of the pairs (q[i] inside
+    t[i]) computed by all ranks, gathered everywhere -- the candidate-vs-candidate graph of the statistical test
+    (end_invariant_functions.get_all_NN) is an explicit pair list like the others; the reference's counterpart is the Pool
+    of end_invariant_functions.py:708-741."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLC0415
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    q = np.asarray(q, dtype=np.uint32); t = np.asarray(t, dtype=np.uint32)
+    kk = np.ascontiguousarray(np.broadcast_to(np.asarray(k, dtype=np.int32), q.shape))
+    lens = np.asarray(store.lens)
+    shards = _pair_shards(lens[q], lens[t], world)
+    mine = shards[rank]
+    res = np.asarray(store.hw_pairs(q[mine], t[mine], kk[mine]), dtype=np.int32).reshape(-1) if len(mine) else np.zeros(0, np.int32)
+    parts = _all_gather_ragged(dist, res, device)
+    out = np.empty((len(q), 5), dtype=np.int32)
+    for r in range(world):
+        out[shards[r]] = parts[r].reshape(-1, 5)
+    return out
+
+
 def sharded_sg_trace(store, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ed_upper=None, dist=None, device=None):
     """Semi-global alignments of the pairs computed by all ranks, gathered everywhere: returns (ops, ops_ptr, res) in the
     caller's pair order like SeqStore.sg_trace.  CIGAR ops travel as one ragged int32 all_gather (a few hundred bytes per

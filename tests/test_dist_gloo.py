@@ -140,6 +140,13 @@ class FakePairStore(object):
         from oracle import oracle as O
         return np.array([O.ed_bounded(self.seqs[int(x)], self.seqs[int(y)], -1 if k is None else int(k[i])) for i, (x, y) in enumerate(zip(a, b))], dtype=np.int32)
 
+    def hw_pairs(self, q, t, k):
+        import sys
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import oracle as O
+        from test_all_nn import hw_row
+        return np.array([hw_row(O, self.seqs[int(x)], self.seqs[int(y)], int(kk)) for x, y, kk in zip(q, t, k)], dtype=np.int32).reshape(-1, 5)
+
     def sg_trace(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ed_upper=None):
         from oracle import oracle as O
         import re
@@ -160,11 +167,12 @@ def _worker_pairs(rank, world, port, seqs, a, b, out_dir):
     import sys
     sys.path.insert(0, ROOT)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from isocon_amd.dist import sharded_ed_pairs, sharded_sg_trace
+    from isocon_amd.dist import sharded_ed_pairs, sharded_hw_pairs, sharded_sg_trace
     st = FakePairStore(seqs)
     ed = sharded_ed_pairs(st, a, b, dist=dist, device=torch.device("cpu"))
+    hw = sharded_hw_pairs(st, a, b, 12, dist=dist, device=torch.device("cpu"))
     ops, ptr, res = sharded_sg_trace(st, a, b, np.full(len(a), -2, np.int8), dist=dist, device=torch.device("cpu"))
-    np.savez(os.path.join(out_dir, "pairs%d.npz" % rank), ed=ed, ops=ops, ptr=ptr, res=res)
+    np.savez(os.path.join(out_dir, "pairs%d.npz" % rank), ed=ed, ops=ops, ptr=ptr, res=res, hw=hw)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -177,11 +185,16 @@ def test_sharded_pair_lists_two_ranks(tmp_path):
     seqs += [s[:10] + "A" + s[10:] for s in seqs[:6]]
     a = np.array([rng.randrange(len(seqs)) for _ in range(23)], dtype=np.uint32)
     b = np.array([rng.randrange(len(seqs)) for _ in range(23)], dtype=np.uint32)
+    a = np.concatenate([a, np.arange(6, dtype=np.uint32)])              # each of the first six with its one-insertion variant
+    b = np.concatenate([b, np.arange(14, 20, dtype=np.uint32)])
     port = _free_port()
     mp.spawn(_worker_pairs, args=(2, port, seqs, a, b, str(tmp_path)), nprocs=2, join=True)
     st = FakePairStore(seqs)
     ed = st.ed_pairs(a, b)
     ops, ptr, res = st.sg_trace(a, b, np.full(len(a), -2, np.int8))
+    hw = st.hw_pairs(a, b, np.full(len(a), 12))
+    assert (hw[:, 0] >= 0).sum() >= 3
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), "pairs%d.npz" % r))
+        assert (z["hw"] == hw).all()
         assert (z["ed"] == ed).all() and (z["ptr"] == ptr).all() and (z["ops"] == ops).all() and (z["res"] == res).all()
