@@ -30,6 +30,14 @@ def test_product_fails_loudly_without_gpu():
     from isocon_amd import edlib_alignment_module as EAM
     with pytest.raises(_lib.IsoconError):
         EAM.edlib_align_sequences({"ACGT": ["ACGA"]})
+    # ... and so do the entry points built around the path: infix alignments, consensus correction
+    import numpy as np
+    from isocon_amd import correction_module as COR
+    from isocon_amd import end_invariant_functions as END
+    with pytest.raises(_lib.IsoconError):
+        END.edlib_traceback("ACGTACGT", "TTACGTTCGTAA", mode="HW", task="path", k=3, end_threshold=1)
+    with pytest.raises(_lib.IsoconError):
+        COR._correct_on_device(np.frombuffer(b"ACGTACGA", dtype=np.uint8).reshape(2, 4), np.array([1, 1]))
 
 
 def test_product_package_never_imports_the_oracle():
