@@ -3,7 +3,10 @@
 compute_nearest_neighbor_graph / compute_2set_nearest_neighbor_graph keep the reference's signatures and return the
 same dict-of-dict with the same key order.  The adaptive loops NNG:110-198 / :341-424 are
 replaced by isocon_nn_graph (include/isocon_hip.h); `params.nr_cores` is ignored (the result of the reference is
-independent of it).
+independent of it).  One process per GPU: when the calling program has initialised torch.distributed with more than one
+rank (every rank running the same pipeline on the same input), the search is shared between the ranks
+(isocon_amd.dist.sharded_nn_graph: pairs split by ownership, min-reductions and one all-gather) and every rank gets the
+full graph; nothing else in the callers changes.
 """
 from __future__ import annotations
 
@@ -12,6 +15,30 @@ import numpy as np
 from .store import SeqStore, remember
 
 LAST_STATS = {}  # statistics block of the most recent device call (bench / tests)
+
+
+def _process_group():
+    """torch.distributed if the caller runs one process per GPU (initialised, world size > 1), else None.  torch is never
+    imported from here: a program that shards has imported it itself."""
+    import sys
+    dist = sys.modules.get("torch.distributed")
+    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def _graph(st, **kw):
+    """(best, row_ptr, cols, stats) of the store: one device call, or this rank's share of it + the exchange steps."""
+    group = _process_group()
+    if group is None:
+        return st.nn_graph(**kw)
+    from .dist import sharded_nn_graph
+    best, row_ptr, cols, stats_all = sharded_nn_graph(st, dist=group, return_stats=True, **kw)
+    stats = {}
+    for part in stats_all:
+        for k, v in part.items():
+            stats[k] = stats.get(k, 0) + v
+    return best, row_ptr, cols, stats
 
 
 def _rows_to_dict(accs, is_query, best, row_ptr, cols):
@@ -33,7 +60,7 @@ def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
     conv = np.fromiter((1 if s in has_converged else 0 for s in seqs), dtype=np.uint8, count=len(seqs))
     st = SeqStore(seqs)
     try:
-        best, row_ptr, cols, stats = st.nn_graph(is_converged=conv, depth=depth)
+        best, row_ptr, cols, stats = _graph(st, is_converged=conv, depth=depth)
     except Exception:
         st.close()
         raise
@@ -129,7 +156,7 @@ def _nn_2set(seq_to_acc_list_sorted_all, target_accessions, depth):
     try:
         if depth < int(is_t.sum()):
             return _replay_2set_depth(seqs, accs, is_t, depth, st)
-        best, row_ptr, cols, stats = st.nn_graph(is_target=is_t.astype(np.uint8), depth=depth)
+        best, row_ptr, cols, stats = _graph(st, is_target=is_t.astype(np.uint8), depth=depth)
     finally:
         st.close()
     LAST_STATS.clear()
