@@ -63,6 +63,31 @@ def _all_gather_rows(dist, rows, device):
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, 3), np.int32)
 
 
+def same_everywhere(value, dist=None, device=None):
+    """True iff the int64 `value` (a store fingerprint, a hash of a pair list ...) is the same on every rank; every rank gets
+    the same answer (one all_reduce(MIN) of (value, -value))."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLC0415
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    value = int(value)
+    t = torch.tensor([value, -value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    ok = torch.tensor([1 if (int(t[0].item()) == value and int(t[1].item()) == -value) else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(int(ok.item()))
+
+
+def _digest(*arrays):
+    """63-bit digest of some numpy arrays (order-sensitive)"""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return int.from_bytes(h.digest(), "little") >> 1
+
+
 def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, dist=None, device=None, return_stats=False):
     """Exact NN graph of `store` (length-sorted) computed by all ranks of the default process group.
 
@@ -77,9 +102,7 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
     n = store.n
     fp = getattr(store, "fingerprint", None)
     if fp is not None:      # every rank must have packed the very same sequences in the very same order
-        t = torch.tensor([fp, -fp], dtype=torch.int64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t[0].item()) != fp or int(t[1].item()) != -fp:
+        if not same_everywhere(fp, dist, device):
             raise RuntimeError("sharded_nn_graph: the ranks hold different sequence sets / orders (fingerprint mismatch); "
                                "build the store from a deterministic order (not from set())")
     qb, qe, qs = rank, n, world          # cyclic ownership
@@ -174,6 +197,8 @@ def sharded_hw_pairs(store, q, t, k, dist=None, device=None):
     q = np.asarray(q, dtype=np.uint32); t = np.asarray(t, dtype=np.uint32)
     kk = np.ascontiguousarray(np.broadcast_to(np.asarray(k, dtype=np.int32), q.shape))
     lens = np.asarray(store.lens)
+    if not same_everywhere(_digest(q, t, kk, np.asarray([getattr(store, "fingerprint", 0)], dtype=np.int64)), dist, device):
+        raise RuntimeError("sharded_hw_pairs: the ranks hold different pair lists / sequence sets")
     shards = _pair_shards(lens[q], lens[t], world)
     mine = shards[rank]
     res = np.asarray(store.hw_pairs(q[mine], t[mine], kk[mine]), dtype=np.int32).reshape(-1) if len(mine) else np.zeros(0, np.int32)

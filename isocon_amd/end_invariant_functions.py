@@ -238,7 +238,13 @@ def get_all_NN(batch_of_queries, global_index_in_matrix, start_index, seq_to_acc
     q, t = _window_pairs(lens, start_index, q_hi, window, neighbor_search_depth)
     if len(q) == 0:
         return all_neighbors_graph
-    res = SeqStore(seqs).hw_pairs(q, t, np.full(len(q), max_ed_allowed, dtype=np.int32))
+    from .nearest_neighbor_graph import _process_group
+    group = _process_group()            # one process per GPU: every rank aligns its share of the pairs, all get all results
+    if group is None:
+        res = SeqStore(seqs).hw_pairs(q, t, np.full(len(q), max_ed_allowed, dtype=np.int32))
+    else:
+        from .dist import sharded_hw_pairs
+        res = sharded_hw_pairs(SeqStore(seqs), q, t, max_ed_allowed, dist=group)
     ed = _ends_adjusted(res, lens[t], ignore_ends_threshold)
     for p in np.flatnonzero((ed >= 0) & (ed <= max_variants)).tolist():
         all_neighbors_graph[accs[q[p]]][accs[t[p]]] = int(ed[p])

@@ -27,18 +27,46 @@ def _process_group():
     return None
 
 
-def _graph(st, **kw):
+def _graph(st, seqs, is_converged=None, is_target=None, depth=2 ** 32):
     """(best, row_ptr, cols, stats) of the store: one device call, or this rank's share of it + the exchange steps."""
     group = _process_group()
     if group is None:
-        return st.nn_graph(**kw)
-    from .dist import sharded_nn_graph
-    best, row_ptr, cols, stats_all = sharded_nn_graph(st, dist=group, return_stats=True, **kw)
-    stats = {}
-    for part in stats_all:
-        for k, v in part.items():
-            stats[k] = stats.get(k, 0) + v
-    return best, row_ptr, cols, stats
+        return st.nn_graph(is_converged=is_converged, is_target=is_target, depth=depth)
+    from . import dist as D
+
+    def shared(store, conv, targ):
+        best, row_ptr, cols, stats_all = D.sharded_nn_graph(store, is_converged=conv, is_target=targ, depth=depth, dist=group, return_stats=True)
+        stats = {}
+        for part in stats_all:
+            for k, v in part.items():
+                stats[k] = stats.get(k, 0) + v
+        return best, row_ptr, cols, stats
+
+    if D.same_everywhere(st.fingerprint, group):
+        return shared(st, is_converged, is_target)
+    # The ranks sorted equal-length sequences differently (the callers' orders go back to Python sets).  The arg-min
+    # sets do not depend on that order (SURVEY App. C) as long as the depth limit does not bind: search in a canonical
+    # order -- length, sequence, role -- and bring rows and neighbour order back to this rank's.
+    n = len(seqs)
+    if depth < n:
+        raise RuntimeError("nearest_neighbor_graph: the ranks hold the sequences in different orders and neighbor_search_depth binds")
+    conv = np.zeros(n, dtype=np.uint8) if is_converged is None else np.asarray(is_converged, dtype=np.uint8)
+    targ = np.zeros(n, dtype=np.uint8) if is_target is None else np.asarray(is_target, dtype=np.uint8)
+    order = np.asarray(sorted(range(n), key=lambda i: (len(seqs[i]), seqs[i], int(targ[i]), int(conv[i]))), dtype=np.int64)
+    canon = SeqStore([seqs[i] for i in order.tolist()])
+    try:
+        best_c, row_ptr_c, cols_c, stats = shared(canon, None if is_converged is None else conv[order], None if is_target is None else targ[order])
+    finally:
+        canon.close()
+    best = np.empty_like(best_c)
+    best[order] = best_c[:n]
+    rows = order[np.repeat(np.arange(n, dtype=np.int64), np.diff(np.asarray(row_ptr_c, dtype=np.int64)))]
+    cols = order[np.asarray(cols_c, dtype=np.int64)]
+    # this rank's insertion order inside a row: ascending offset, the lower index first (NNG:145-172)
+    srt = np.lexsort((cols, np.abs(cols - rows), rows))
+    row_ptr = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(np.bincount(rows, minlength=n), out=row_ptr[1:])
+    return best, row_ptr, cols[srt].astype(np.uint32), stats
 
 
 def _rows_to_dict(accs, is_query, best, row_ptr, cols):
@@ -60,7 +88,7 @@ def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
     conv = np.fromiter((1 if s in has_converged else 0 for s in seqs), dtype=np.uint8, count=len(seqs))
     st = SeqStore(seqs)
     try:
-        best, row_ptr, cols, stats = _graph(st, is_converged=conv, depth=depth)
+        best, row_ptr, cols, stats = _graph(st, seqs, is_converged=conv, depth=depth)
     except Exception:
         st.close()
         raise
@@ -156,7 +184,7 @@ def _nn_2set(seq_to_acc_list_sorted_all, target_accessions, depth):
     try:
         if depth < int(is_t.sum()):
             return _replay_2set_depth(seqs, accs, is_t, depth, st)
-        best, row_ptr, cols, stats = _graph(st, is_target=is_t.astype(np.uint8), depth=depth)
+        best, row_ptr, cols, stats = _graph(st, seqs, is_target=is_t.astype(np.uint8), depth=depth)
     finally:
         st.close()
     LAST_STATS.clear()

@@ -198,3 +198,56 @@ def test_sharded_pair_lists_two_ranks(tmp_path):
         z = np.load(os.path.join(str(tmp_path), "pairs%d.npz" % r))
         assert (z["hw"] == hw).all()
         assert (z["ed"] == ed).all() and (z["ptr"] == ptr).all() and (z["ops"] == ops).all() and (z["res"] == res).all()
+
+
+def _worker_orders(rank, world, port, lst, out_dir):
+    """every rank with its own order inside the groups of equal length: the drop-in module must still return, on each rank,
+    the graph a single process would return for THAT rank's list (dict order included)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    import zlib
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import isocon_amd.nearest_neighbor_graph as NNG
+    from oracle import oracle as O
+
+    class OrderedFakeStore(FakeStore):
+        def __init__(self, seqs):
+            FakeStore.__init__(self, list(seqs))
+            self.fingerprint = zlib.crc32("\n".join(seqs).encode())
+
+        def close(self):
+            pass
+
+    NNG.SeqStore = OrderedFakeStore
+    NNG.remember = lambda st, seqs: None
+    if rank == 1:           # reverse every group of equal length
+        groups = {}
+        for item in lst:
+            groups.setdefault(len(item[0]), []).append(item)
+        lst = [item for L in sorted(groups) for item in reversed(groups[L])]
+
+    class P(object):
+        nr_cores = 1
+        neighbor_search_depth = 2 ** 32
+        verbose = False
+
+    got = NNG.get_exact_nearest_neighbor_graph(lst, set(), P())
+    exp = O.get_exact_nearest_neighbor_graph(lst, set(), P())
+    same = [(k, list(v.items())) for k, v in got.items()] == [(k, list(v.items())) for k, v in exp.items()]
+    open(os.path.join(out_dir, "orders%d.txt" % rank), "w").write("%s %d" % (same, sum(len(v) for v in got.values())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_with_different_orders_of_equal_lengths(tmp_path):
+    from isocon_amd import synth
+    accs, seqs, _ = synth.make_reads(80, 110, 2, seed=21)
+    lst = sorted({s: a for a, s in zip(accs, seqs)}.items(), key=lambda x: len(x[0]))
+    assert len(set(len(s) for s, _ in lst)) < len(lst) - 20          # plenty of equal lengths
+    mp.spawn(_worker_orders, args=(2, _free_port(), lst, str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        flag, edges = open(tmp_path / ("orders%d.txt" % r)).read().split()
+        assert flag == "True" and int(edges) > 40
