@@ -7,7 +7,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = os.path.join(ROOT, "gpurun_out")
 prof = os.path.join(ROOT, "profiles")
 
-ks = glob.glob(os.path.join(out, "prof_" + tag, "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """the most recent match (a tag's directory may hold the files of several runs)"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+ks = newest(os.path.join(out, "prof_" + tag, "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(prof, tag + "_kernel_stats.csv"))
 b = os.path.join(out, "bench_%s.json" % tag)
@@ -16,7 +21,7 @@ if os.path.exists(b):
 
 
 def rows(kind):
-    f = glob.glob(os.path.join(out, "pmc_%s_%s" % (kind, tag), "*", "*_counter_collection.csv"))
+    f = newest(os.path.join(out, "pmc_%s_%s" % (kind, tag), "*", "*_counter_collection.csv"))
     res = []
     if not f:
         return res
