@@ -108,3 +108,40 @@ def test_c3_partitions_cover_and_follow_the_graph(c3):
         assert seen == comp
     G2, partition2, M2, _ = partitions.partition_strings(dict(reversed(list(S.items()))), P())
     assert partition2 == partition and M2 == M
+
+
+def test_c3_infix_alignments_properties(c3):
+    """isocon_hw_pairs at full read length (2.5 kb), size-independent properties: a read inside itself (distance 0, whole
+    range); a planted exact infix (distance 0, the planted start unless an earlier occurrence exists -- none in random
+    2.5 kb sequences, first end, no terminal insertions); a read against its nearest neighbour: the infix distance never
+    exceeds the global distance, equals -1 only above k, and the location spans a stretch of the target whose length differs
+    from the read's by at most the distance."""
+    from isocon_amd.store import SeqStore
+    seqs, st, best, row_ptr, cols, stats = c3
+    n = len(seqs)
+    rng = np.random.default_rng(4)
+    q = rng.choice(n, 3000, replace=False)
+    # 1. self
+    r = st.hw_pairs(q, q, 10)
+    assert (r[:, 0] == 0).all() and (r[:, 1] == 0).all() and (r[:, 2] == st.lens[q] - 1).all() and (r[:, 3:] == 0).all()
+    # 2. nearest neighbour, k = 63: compare with the global distance of the graph
+    t = cols[row_ptr[q]]
+    r = st.hw_pairs(q, t, 63)
+    ed = best[q]
+    hit = r[:, 0] >= 0
+    assert (r[hit, 0] <= ed[hit]).all() and hit[ed <= 63].all()
+    span = r[hit, 2] - r[hit, 1] + 1
+    assert (np.abs(span - st.lens[q][hit]) <= r[hit, 0]).all() and (r[hit, 1] >= 0).all() and (r[hit, 2] < st.lens[t][hit]).all()
+    assert (r[~hit, 1:] == np.array([-1, -1, 0, 0])).all()
+    # 3. planted infixes: prefix + read + suffix
+    sub = q[:400]
+    pre = rng.integers(0, 25, len(sub))
+    suf = rng.integers(0, 25, len(sub))
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    planted = [alphabet[rng.integers(0, 4, int(a))].tobytes().decode() + seqs[i] + alphabet[rng.integers(0, 4, int(b))].tobytes().decode()
+               for i, a, b in zip(sub.tolist(), pre.tolist(), suf.tolist())]
+    st2 = SeqStore([seqs[i] for i in sub.tolist()] + planted)
+    m = len(sub)
+    r = st2.hw_pairs(np.arange(m), np.arange(m, 2 * m), 25)
+    assert (r[:, 0] == 0).all() and (r[:, 1] == pre).all() and (r[:, 2] == pre + st.lens[sub] - 1).all() and (r[:, 3:] == 0).all()
+    st2.close()

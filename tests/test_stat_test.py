@@ -239,3 +239,23 @@ def test_fix_quality_values_equal_reference():
     from isocon_amd import ccs_info as CI
     for s, q, expect in _G16["fix_quality_values"]:
         assert CI.fix_quality_values(s, q) == expect
+
+
+def test_empty_candidate_file_writes_empty_outputs_and_exits(tmp_path):
+    """isocon_statistical_test.py:166-171: no candidate -> empty final_candidates.fa / cluster_info.tsv, then sys.exit(0)
+    (reached before any kernel is needed)."""
+    from isocon_amd import isocon_statistical_test as IST
+    reads = tmp_path / "reads.fa"
+    reads.write_text(">r1\nACGTACGT\n>r2\nACGTTCGT\n")
+    cands = tmp_path / "candidates_converged.fa"
+    cands.write_text("")
+
+    class Params(object):
+        is_fastq = False
+        ccs = None
+        outfolder = str(tmp_path)
+
+    with pytest.raises(SystemExit) as e:
+        IST.stat_filter_candidates(str(reads), str(cands), {}, {"r1": "ACGTACGT"}, Params())
+    assert e.value.code == 0
+    assert (tmp_path / "final_candidates.fa").read_text() == "" and (tmp_path / "cluster_info.tsv").read_text() == ""
