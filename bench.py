@@ -161,7 +161,7 @@ def main():
 
     from isocon_amd import synth
 
-    accs, seqs, _ = synth.make_reads(args.reads, args.length, args.isoforms, args.seed)
+    accs, seqs, true_isoforms = synth.make_reads(args.reads, args.length, args.isoforms, args.seed)
     # unique strings in first-appearance order, then a STABLE sort by length (NNG:243-246).  Not set(): its iteration
     # order depends on the per-process string hash seed, and every rank must pack the very same order.
     seqs = sorted(dict.fromkeys(seqs), key=len)
@@ -290,7 +290,18 @@ def main():
             store.hw_pairs(t[:64], q[:64], 25)
             hw25, hw25_ms = store.hw_pairs(t, q, 25, return_ms=True)
             hw63, hw63_ms = store.hw_pairs(t, q, 63, return_ms=True)
+            # the read -> candidate (2-set) search of the pipeline's last steps: all reads against the true isoforms
+            cands = [c for c in dict.fromkeys(true_isoforms) if c not in set(seqs)]
+            merged = sorted([(s, 0) for s in seqs] + [(c, 1) for c in cands], key=lambda x: len(x[0]))
+            st2 = SeqStore([s for s, _ in merged])
+            is_t = np.array([f for _, f in merged], dtype=np.uint8)
+            st2.nn_graph(is_target=is_t)
+            t0 = time.perf_counter(); b2, rp2, c2, stats2 = st2.nn_graph(is_target=is_t); two_wall = time.perf_counter() - t0
+            st2.close()
             result["other_kernels"] = {
+                "nn_2set_reads": int((is_t == 0).sum()), "nn_2set_candidates": int(is_t.sum()), "nn_2set_wall_ms": two_wall * 1e3,
+                "nn_2set_kernel_ms": float(stats2["kernel_ms"]), "nn_2set_pairs_evaluated": int(stats2["pairs_evaluated"]),
+                "nn_2set_reads_with_a_candidate": int((np.diff(rp2)[is_t == 0] > 0).sum()),
                 "hw_pairs_per_s_kernel_k25": len(q) / (hw25_ms / 1e3) if hw25_ms > 0 else None, "hw_hits_k25": int((hw25[:, 0] >= 0).sum()),
                 "hw_pairs_per_s_kernel_k63": len(q) / (hw63_ms / 1e3) if hw63_ms > 0 else None, "hw_hits_k63": int((hw63[:, 0] >= 0).sum()),
                 "hw_distance_le_global_distance": bool(((hw63[:, 0] <= ed) | (ed > 63))[hw63[:, 0] >= 0].all()),
