@@ -167,7 +167,7 @@ def _build_tables(items):
     return tables
 
 
-_TABLES = {}        # id(read-alignment dict) -> (the dict, its values' identities, table); reset by clear_tables()
+_TABLES = {}        # id(read-alignment dict) -> (the dict, its alignment tuples, table); reset by clear_tables()
 
 
 def clear_tables():
@@ -181,9 +181,10 @@ def _tables_for(wanted):
     for ref_seq, ra in wanted:
         if id(ra) in out:
             continue
-        stamp = [id(v) for v in ra.values()]
+        stamp = list(ra.values())           # the alignment tuples themselves (kept alive: identities cannot be recycled)
         hit = _TABLES.get(id(ra))
-        if hit is not None and hit[0] is ra and hit[1] == stamp and hit[2].ref_len == len(ref_seq):
+        if (hit is not None and hit[0] is ra and len(hit[1]) == len(stamp) and all(a is b for a, b in zip(hit[1], stamp))
+                and hit[2].ref_len == len(ref_seq)):
             out[id(ra)] = hit[2]
         else:
             out[id(ra)] = None
