@@ -45,8 +45,10 @@ def inputs():
         fq[a + (";strand=-" if i % 3 == 0 else ";strand=+")] = (s3, "".join(chr(int(v) + 33) for v in q))
     fa500 = read_fasta(os.path.join(REF, "test", "data", "simulated_pacbio_reads_n_500.fa"))
     fa1000 = read_fasta(os.path.join(REF, "test", "data", "simulated_pacbio_reads_n_1000.fa"))
+    fa2000 = read_fasta(os.path.join(REF, "test", "data", "simulated_pacbio_reads_n_2000.fa"))
     return [("test_data_n200", fa), ("synth_150x500_3iso", dict(zip(accs, seqs))), ("synth_260x700_4iso", dict(zip(accs2, seqs2))),
-            ("synth_180x450_3iso_fastq", fq), ("test_data_n500", fa500), ("test_data_n1000", fa1000)]
+            ("synth_180x450_3iso_fastq", fq), ("test_data_n500", fa500), ("test_data_n1000", fa1000),
+            ("test_data_n2000", fa2000)]
 
 
 def collect(tmp):
@@ -126,7 +128,15 @@ def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--child":
         return child(int(sys.argv[2]))
     kept, dropped, stored_inputs = [], [], {}
+    only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "--only" else None     # regenerate just these cases, keep the rest
+    previous = json.load(open(os.path.join(HERE, "g15_stat_test.json"))) if only else None
     for ci, (name, S) in enumerate(inputs()):
+        if only and name not in only:
+            old = [c for c in previous["cases"] if c["name"] == name]
+            kept.extend(old)
+            if name in previous["inputs"]:
+                stored_inputs[name] = previous["inputs"][name]
+            continue
         outs = []
         for seed in range(3):
             env = dict(os.environ, PYTHONHASHSEED=str(seed))
@@ -149,7 +159,7 @@ def main():
     g12 = json.load(open(os.path.join(HERE, "g12_candidates.json")))["inputs"]
     stored_inputs = {k: v for k, v in stored_inputs.items() if g12.get(k) != v}
     import gzip
-    for k in [k for k in stored_inputs if k.startswith("test_data_n")]:      # the larger public test sets: gzipped FASTA next to this file
+    for k in [k for k in stored_inputs if k.startswith("test_data_n") and (not only or k in only)]:      # the larger public test sets: gzipped FASTA next to this file
         with gzip.GzipFile(os.path.join(HERE, "inputs_%s.fa.gz" % k), "wb", mtime=0) as fh:
             fh.write("".join(">%s\n%s\n" % (a, q) for a, q in stored_inputs.pop(k)).encode())
     json.dump({"generator": "tests/golden/make_golden_stat_test.py", "hash_order_dependent_cases_dropped": dropped, "cases": kept, "inputs": stored_inputs,
