@@ -1,0 +1,37 @@
+"""Runs find_candidate_transcripts + stat_filter_candidates (default parameters) on a FASTA(.gz) file and dumps what the
+golden generator tests/golden/make_golden_stat_test.py collects.  Usage: python scripts/run_pipeline_dump.py reads.fa[.gz] out.json"""
+import glob, gzip, hashlib, json, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from isocon_amd import isocon_get_candidates as IGC
+from isocon_amd import isocon_statistical_test as IST
+
+src, dst = sys.argv[1], sys.argv[2]
+text = gzip.open(src, "rt").read() if src.endswith(".gz") else open(src).read()
+
+
+def sha(s):
+    return hashlib.sha1(s.encode()).hexdigest()[:16]
+
+
+with tempfile.TemporaryDirectory() as tmp:
+    rf = os.path.join(tmp, "reads.fa")
+    open(rf, "w").write(text)
+
+    class P:
+        nr_cores = 1; neighbor_search_depth = 2 ** 32; verbose = False; develop_logfile = None; logfile = None; min_exon_diff = 20
+        ignore_ends_len = 15; min_candidate_support = 2; p_value_threshold = 0.01; min_test_ratio = 5; max_phred_q_trusted = 43
+        is_fastq = False; ccs = None; outfolder = tmp
+    t = time.time()
+    cand_file, rp, to_realign = IGC.find_candidate_transcripts(rf, P)
+    IST.stat_filter_candidates(rf, cand_file, rp, to_realign, P)
+    dt = time.time() - t
+    finals, acc = [], None
+    for line in open(os.path.join(tmp, "final_candidates.fa")):
+        if line.startswith(">"):
+            acc = line[1:].strip()
+        else:
+            finals.append([acc, sha(line.strip()), len(line.strip())])
+    info = sorted(l.rstrip("\n").split("\t") for l in open(os.path.join(tmp, "cluster_info.tsv")))
+    pv = {os.path.basename(f): [l.rstrip("\n").split("\t") for l in open(f)] for f in sorted(glob.glob(os.path.join(tmp, "p_values_*.tsv")))}
+json.dump({"final_candidates": finals, "cluster_info": info, "p_values": pv}, open(dst, "w"))
+print("pipeline: %.2f s, %d final candidates, %d rounds" % (dt, len(finals), len(pv)))

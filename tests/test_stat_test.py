@@ -1,8 +1,8 @@
 """The whole pipeline (IsoCon:145-177: candidate inference, then the statistical filter) against what the reference's own
 find_candidate_transcripts + stat_filter_candidates write (tests/golden/g15_stat_test.json): final candidates with
 support / p-value / partition size / variants, the read -> candidate table, the p-value table of every round.
-Floats are compared after rounding to 10 significant digits (the reference's own last digits depend on PYTHONHASHSEED,
-tests/golden/make_golden_stat_test.py::norm_floats)."""
+Floats are compared with a relative tolerance of 1e-9 (the reference's own last digits depend on PYTHONHASHSEED,
+tests/golden/make_golden_stat_test.py::same_up_to_float_digits)."""
 import glob
 import hashlib
 import json
@@ -34,14 +34,21 @@ def sha(s):
     return hashlib.sha1(s.encode()).hexdigest()[:16]
 
 
-def norm_floats(obj):
-    if isinstance(obj, list):
-        return [norm_floats(x) for x in obj]
-    if isinstance(obj, dict):
-        return {k: norm_floats(v) for k, v in obj.items()}
-    if isinstance(obj, str):
-        return re.sub(r"\d+\.\d+(e-?\d+)?", lambda m: "%.9e" % float(m.group()), obj)
-    return obj
+_FLOAT = re.compile(r"\d+\.\d+(?:e-?\d+)?")
+
+
+def same_up_to_float_digits(a, b, rel=1e-9):
+    """Structural equality; decimal numbers inside strings (p-values in accessions / tsv cells) may differ by `rel` relative:
+    the reference's own last digits move with PYTHONHASHSEED (it sums per-read terms in set order)."""
+    if isinstance(a, list) and isinstance(b, list):
+        return len(a) == len(b) and all(same_up_to_float_digits(x, y, rel) for x, y in zip(a, b))
+    if isinstance(a, dict) and isinstance(b, dict):
+        return list(a) == list(b) and all(same_up_to_float_digits(a[k], b[k], rel) for k in a)
+    if isinstance(a, str) and isinstance(b, str):
+        if _FLOAT.sub("#", a) != _FLOAT.sub("#", b):
+            return False
+        return all(abs(float(x) - float(y)) <= rel * max(abs(float(x)), abs(float(y))) for x, y in zip(_FLOAT.findall(a), _FLOAT.findall(b)))
+    return a == b
 
 
 def run(case, tmp_path):
@@ -126,7 +133,7 @@ def test_pipeline_with_the_oracle_kernels(case, tmp_path, monkeypatch):
     monkeypatch.setattr(IST, "sw_align_sequences_keeping_accession", O.sw_align_sequences_keeping_accession)
     monkeypatch.setattr(SWM, "_align_pairs", oracle_align_pairs)
     monkeypatch.setattr(END, "SeqStore", OracleStore)
-    assert norm_floats(run(case, tmp_path)) == norm_floats(case["expect"])
+    assert same_up_to_float_digits(run(case, tmp_path), case["expect"])
 
 
 def test_raghavan_bound_known_values():
@@ -145,7 +152,7 @@ def test_raghavan_bound_known_values():
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", G15, ids=[c["name"] for c in G15])
 def test_gpu_pipeline(case, tmp_path):
-    assert norm_floats(run(case, tmp_path)) == norm_floats(case["expect"])
+    assert same_up_to_float_digits(run(case, tmp_path), case["expect"])
 
 
 def test_read_tables_equal_the_per_read_functions():
