@@ -53,6 +53,9 @@ void isocon_release_scratch(void);
 int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t n, isocon_store **out);
 void isocon_store_destroy(isocon_store *s);
 uint32_t isocon_store_size(const isocon_store *s);
+/* 64-bit digest of the whole packed set, order-sensitive (computed on the device from the planes and the lengths): the
+ * ranks of a sharded run compare it before they split the work (isocon_amd/dist.py). */
+int isocon_store_digest(const isocon_store *s, uint64_t *out);
 uint64_t isocon_store_device_bytes(const isocon_store *s);
 
 /*

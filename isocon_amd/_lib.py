@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("ISOCON_LIB", os.path.join(_HERE, "lib", "libisocon_hip.so"))   # override: kernel experiments
 SRC_DIR = os.path.join(_HERE, "csrc")
 _SOURCES = ["isocon_hip.hip", "band_core.hpp", "common.hpp", "ed_band.hpp", "ed_full.hpp", "nn.hpp", "nn_host.inc",
-            "sg.hpp", "sg_host.inc", "msa.hpp", "msa_host.inc"]
+            "sg.hpp", "sg_host.inc", "msa.hpp", "msa_host.inc", "hw.hpp", "hw_host.inc"]
 
 ISOCON_OK = 0
 ISOCON_E_CAPACITY = -4
@@ -48,6 +48,7 @@ SYMBOLS = {
     "isocon_store_destroy": (None, [ctypes.c_void_p]),
     "isocon_store_size": (ctypes.c_uint32, [ctypes.c_void_p]),
     "isocon_store_device_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
+    "isocon_store_digest": (ctypes.c_int, [ctypes.c_void_p, u64p]),
     "isocon_ed_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, i32p, ctypes.c_uint64, i32p, f32p]),
     "isocon_nn_graph": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, i32p, u64p, u32p, ctypes.c_uint64,
                                        u64p, ctypes.POINTER(NNStats)]),

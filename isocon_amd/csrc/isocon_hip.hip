@@ -453,6 +453,37 @@ int ed_pairs_impl(isocon_store *st, const uint32_t *a, const uint32_t *b, const 
 
 }  // namespace isocon
 
+// 64-bit digest of the packed set (every plane word and every length, each mixed with its position): two stores have the
+// same digest iff -- up to hash collisions -- they hold the same sequences in the same order.  Sharded runs compare it.
+__global__ __launch_bounds__(256) void k_store_digest(const uint64_t *__restrict__ planes, size_t n_words, const int32_t *__restrict__ lens, uint32_t n,
+                                                      unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words + n; i += stride) {
+        unsigned long long v = i < n_words ? planes[i] : (unsigned long long)(uint32_t)lens[i - n_words];
+        v ^= (unsigned long long)i * 0xD6E8FEB86659FD93ull;
+        v ^= v >> 32; v *= 0x9E3779B97F4A7C15ull; v ^= v >> 29; v *= 0xBF58476D1CE4E5B9ull; v ^= v >> 32;
+        acc += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+extern "C" int isocon_store_digest(const isocon_store *s, uint64_t *out)
+{
+    if (!s || !out) return ISOCON_E_ARG;
+    DevBuf d_acc;
+    int rc;
+    if ((rc = d_acc.alloc(8))) return rc;
+    ISO_HIP_CHECK(hipMemset(d_acc.p, 0, 8));
+    const size_t n_words = (size_t)s->dev.nchunks * std::max<uint32_t>(s->dev.n, 1) * 2;
+    hipLaunchKernelGGL(k_store_digest, dim3(1024), dim3(256), 0, 0, s->d_planes, n_words, s->d_lens, s->dev.n, d_acc.as<unsigned long long>());
+    ISO_HIP_CHECK(hipGetLastError());
+    ISO_HIP_CHECK(hipMemcpy(out, d_acc.p, 8, hipMemcpyDeviceToHost));
+    return ISOCON_OK;
+}
+
 extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const int32_t *k, uint64_t n_pairs,
                                int32_t *out_ed, float *kernel_ms)
 {

@@ -31,12 +31,17 @@ class SeqStore(object):
                    "isocon_store_create")
         self._h = h
         self._L = L
-        # cheap identity of the packed set (lengths + 64 sampled sequences): ranks of a sharded run compare it
-        import zlib
-        fp = zlib.crc32(self.lens.tobytes())
-        for i in range(0, self.n, max(1, self.n // 64)):
-            fp = zlib.crc32(seqs[i].encode("ascii"), fp)
-        self.fingerprint = int(fp)
+        self._fingerprint = None
+
+    @property
+    def fingerprint(self):
+        """Identity of the packed set, order included (isocon_store_digest: every plane word and length, hashed on the
+        device): the ranks of a sharded run compare it.  Computed on first use."""
+        if self._fingerprint is None:
+            out = np.zeros(1, dtype=np.uint64)
+            _lib.check(self._L.isocon_store_digest(self._h, _ptr(out, _lib.u64p)), "isocon_store_digest")
+            self._fingerprint = int(out[0] >> np.uint64(1))          # 63 bits: travels as int64 through the collectives
+        return self._fingerprint
 
     @property
     def handle(self):

@@ -80,3 +80,22 @@ def test_hit_list_overflow_restart_is_transparent():
     row_ptr, c, e, _ = O.nn_1set(seqs, np.zeros(len(seqs), np.uint8), 0, len(seqs))
     assert rp.tolist() == row_ptr.tolist() and cols.tolist() == c.tolist()
     assert (best == 2).all()
+
+
+@pytest.mark.gpu
+def test_store_digest_is_order_sensitive():
+    """isocon_store_digest (the identity the ranks of a sharded run compare): equal for equal stores, different as soon as
+    two equal-length sequences swap places or one base changes -- also where the old sampled fingerprint could not see it."""
+    import random
+    from isocon_amd.store import SeqStore
+    rng = random.Random(8)
+    seqs = sorted(("".join(rng.choice("ACGT") for _ in range(rng.choice([90, 90, 91, 200, 200, 350]))) for _ in range(700)), key=len)
+    a, b = SeqStore(seqs), SeqStore(list(seqs))
+    assert a.fingerprint == b.fingerprint and 0 <= a.fingerprint < 2 ** 63
+    swapped = list(seqs)
+    i = next(i for i in range(1, len(seqs) - 1) if len(seqs[i]) == len(seqs[i + 1]) and i % max(1, len(seqs) // 64) != 0 and (i + 1) % max(1, len(seqs) // 64) != 0)
+    swapped[i], swapped[i + 1] = swapped[i + 1], swapped[i]
+    assert SeqStore(swapped).fingerprint != a.fingerprint
+    changed = list(seqs)
+    changed[5] = changed[5][:-1] + ("A" if changed[5][-1] != "A" else "C")
+    assert SeqStore(changed).fingerprint != a.fingerprint
