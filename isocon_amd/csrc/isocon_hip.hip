@@ -54,6 +54,7 @@ enum {
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR,
+    SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD,
     SLOT_COUNT
 };
 static_assert(SLOT_COUNT <= 64, "ScratchPool::slots too small");
@@ -164,6 +165,33 @@ struct EventTimer {
     }
 };
 
+// Packs ASCII sequences into the store's bit-planes: one wavefront per (sequence, 64-base chunk) -- a coalesced 64-byte load,
+// the two code bits of every base become the chunk's two words through two ballots.  *first_bad receives the smallest
+// (sequence << 32 | position) holding a symbol outside ACGT.
+__global__ __launch_bounds__(256) void k_pack_planes(const uint8_t *__restrict__ ascii, const uint64_t *__restrict__ offsets, uint64_t base, uint32_t n,
+                                                      uint32_t nchunks, uint64_t *__restrict__ planes, unsigned long long *__restrict__ first_bad)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (uint64_t)nchunks * n) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t chunk = (uint32_t)(w / n), seq = (uint32_t)(w % n);           // consecutive waves: consecutive sequences
+    const uint64_t off = offsets[seq] - base, len = offsets[seq + 1] - offsets[seq];
+    const uint64_t pos = (uint64_t)chunk * 64 + lane;
+    int cd = 0;
+    bool bad = false;
+    if (pos < len) {
+        const uint8_t ch = ascii[off + pos];
+        cd = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
+        bad = cd < 0;
+    }
+    const unsigned long long lo = __ballot(!bad && (cd & 1)), hi = __ballot(!bad && (cd & 2)), bm = __ballot(bad);
+    if (lane == 0) {
+        planes[((size_t)chunk * n + seq) * 2] = lo;
+        planes[((size_t)chunk * n + seq) * 2 + 1] = hi;
+        if (bm) atomicMin(first_bad, ((unsigned long long)seq << 32) | ((unsigned long long)chunk * 64 + (unsigned long long)(__ffsll((long long)bm) - 1)));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,50 +240,51 @@ int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t 
         maxlen = std::max<int32_t>(maxlen, (int32_t)(offsets[i + 1] - offsets[i]));
     }
     const uint32_t nchunks = (uint32_t)((maxlen + 63) / 64 + 1);
-    std::vector<uint64_t> planes((size_t)nchunks * std::max<uint32_t>(n, 1) * 2, 0);
-    std::vector<int32_t> lens(std::max<uint32_t>(n, 1), 0);
-    static int8_t code[256];
-    static bool code_init = false;
-    if (!code_init) {
-        memset(code, -1, sizeof(code));
-        code['A'] = 0; code['C'] = 1; code['G'] = 2; code['T'] = 3;
-        code_init = true;
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint8_t *s = ascii + offsets[i];
-        const int32_t len = (int32_t)(offsets[i + 1] - offsets[i]);
-        lens[i] = len;
-        for (int32_t c0 = 0; c0 < len; c0 += 64) {
-            uint64_t lo = 0, hi = 0;
-            const int32_t e = std::min(len, c0 + 64);
-            for (int32_t p = c0; p < e; ++p) {
-                const int8_t cd = code[s[p]];
-                if (cd < 0) {
-                    g_last_error = "sequence " + std::to_string(i) + " position " + std::to_string(p) + ": symbol outside ACGT";
-                    return ISOCON_E_ALPHABET;
-                }
-                lo |= (uint64_t)(cd & 1) << (p - c0);
-                hi |= (uint64_t)(cd >> 1) << (p - c0);
-            }
-            const size_t at = ((size_t)(c0 >> 6) * n + i) * 2;
-            planes[at] = lo;
-            planes[at + 1] = hi;
-        }
-    }
+    const uint32_t nn = std::max<uint32_t>(n, 1);
+    std::vector<int32_t> lens(nn, 0);
+    for (uint32_t i = 0; i < n; ++i) lens[i] = (int32_t)(offsets[i + 1] - offsets[i]);
+    const uint64_t base = n ? offsets[0] : 0, total = n ? offsets[n] - offsets[0] : 0;
     isocon_store *st = new isocon_store();
     st->lens = lens;
     st->maxlen = maxlen;
-    const size_t pbytes = planes.size() * sizeof(uint64_t), lbytes = lens.size() * sizeof(int32_t);
+    const size_t pbytes = (size_t)nchunks * nn * 2 * sizeof(uint64_t), lbytes = lens.size() * sizeof(int32_t);
     if (hipMalloc((void **)&st->d_planes, pbytes) != hipSuccess || hipMalloc((void **)&st->d_lens, lbytes) != hipSuccess) {
         g_last_error = "hipMalloc(store) failed";
         isocon_store_destroy(st);
         return ISOCON_E_HIP;
     }
-    if (copy_h2d(st->d_planes, planes.data(), pbytes) != hipSuccess ||
-        copy_h2d(st->d_lens, lens.data(), lbytes) != hipSuccess) {
-        g_last_error = "hipMemcpy(store) failed";
-        isocon_store_destroy(st);
-        return ISOCON_E_HIP;
+    // The bytes go to the device as they are and are packed there (k_pack_planes: one wavefront per 64 bases, two ballots);
+    // the host only checked the offsets.  Scratch (ASCII, offsets, first bad position) comes from the process-wide pool.
+    {
+        DevBuf d_ascii(&g_scratch, SLOT_PACK_ASCII), d_off(&g_scratch, SLOT_PACK_OFF), d_bad(&g_scratch, SLOT_PACK_BAD);
+        const unsigned long long none = ~0ull;
+        int rc = ISOCON_OK;
+        if ((rc = d_ascii.alloc(total ? total : 16)) || (rc = d_off.alloc((size_t)(nn + 1) * 8)) || (rc = d_bad.alloc(8))) { isocon_store_destroy(st); return rc; }
+        bool ok = (total == 0 || copy_h2d(d_ascii.p, ascii + base, total) == hipSuccess) &&
+                  (n == 0 || copy_h2d(d_off.p, offsets, (size_t)(n + 1) * 8) == hipSuccess) &&
+                  hipMemcpy(d_bad.p, &none, 8, hipMemcpyHostToDevice) == hipSuccess && copy_h2d(st->d_lens, lens.data(), lbytes) == hipSuccess;
+        unsigned long long bad = none;
+        if (ok) {
+            if (n) {
+                const uint64_t waves = (uint64_t)nchunks * n;
+                hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
+                                   st->d_planes, d_bad.as<unsigned long long>());
+            } else {
+                ok = hipMemset(st->d_planes, 0, pbytes) == hipSuccess;
+            }
+            ok = ok && hipGetLastError() == hipSuccess && hipMemcpy(&bad, d_bad.p, 8, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (!ok) {
+            g_last_error = "isocon_store_create: device copy / packing failed";
+            (void)hipGetLastError();
+            isocon_store_destroy(st);
+            return ISOCON_E_HIP;
+        }
+        if (bad != none) {
+            g_last_error = "sequence " + std::to_string((uint32_t)(bad >> 32)) + " position " + std::to_string((uint32_t)bad) + ": symbol outside ACGT";
+            isocon_store_destroy(st);
+            return ISOCON_E_ALPHABET;
+        }
     }
     st->device_bytes = pbytes + lbytes;
     st->dev.planes = st->d_planes;
