@@ -99,3 +99,25 @@ def test_store_digest_is_order_sensitive():
     changed = list(seqs)
     changed[5] = changed[5][:-1] + ("A" if changed[5][-1] != "A" else "C")
     assert SeqStore(changed).fingerprint != a.fingerprint
+
+
+@pytest.mark.gpu
+def test_non_acgt_symbols_are_rejected_with_the_first_position():
+    """isocon_store_create packs on the device (k_pack_planes); a symbol outside ACGT comes back as ISOCON_E_ALPHABET naming
+    the FIRST offending (sequence, position) -- also when several sequences / chunks are bad, also lower case."""
+    from isocon_amd import _lib
+    from isocon_amd.store import SeqStore
+    good = ["ACGT" * 40, "TTGCA" * 30, "G" * 70]
+    SeqStore(good).close()
+    for bad_seqs, where in (
+            (good + ["ACGT" * 20 + "N" + "ACGT" * 20], "sequence 3 position 80"),
+            (["ACGT" * 40, "ACGTacgt", "NNNN"], "sequence 1 position 4"),
+            (["A" * 200 + "X" + "A" * 30 + "-", "ACGT"], "sequence 0 position 200"),
+            (["ACGT", "AC GT"], "sequence 1 position 2")):
+        with pytest.raises(_lib.IsoconError) as e:
+            SeqStore(bad_seqs)
+        assert "outside ACGT" in str(e.value) and where in str(e.value), str(e.value)
+    # empty sequences and an empty set are fine
+    st = SeqStore(["", "ACGT", ""])
+    assert list(st.ed_pairs([0, 0, 1], [1, 2, 2])) == [4, 0, 4]
+    st.close()
