@@ -1,6 +1,6 @@
 """Differential stress of the WHOLE pipeline: random small read sets through find_candidate_transcripts +
 stat_filter_candidates once on the HIP kernels and once with the CPU oracle substituted for every kernel (the way the CPU
-tests do it); the files written must be identical.  Usage: python scripts/stress_pipeline.py [seed] [n_cases]"""
+tests do it); the files written must be identical.  Usage: python scripts/stress_pipeline.py [seed] [n_cases] [hard]"""
 import hashlib, os, random, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -68,8 +68,12 @@ ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 bad = 0
 t0 = time.time()
 for case in range(ncases):
-    n, L, iso = rng.randint(20, 260), rng.choice([80, 150, 260, 400, 700]), rng.randint(1, 4)
-    prof = dict(synth.CCS_PROFILE, rate=rng.choice([0.005, 0.01, 0.02, 0.04]))
+    if len(sys.argv) > 3 and sys.argv[3] == "hard":      # noisy, longer reads: wide bands, multi-block infix alignments
+        n, L, iso = rng.randint(20, 120), rng.choice([400, 900, 1500]), rng.randint(1, 3)
+        prof = dict(synth.ONT_PROFILE if rng.random() < 0.5 else synth.CCS_PROFILE, rate=rng.choice([0.03, 0.06, 0.08]))
+    else:
+        n, L, iso = rng.randint(20, 260), rng.choice([80, 150, 260, 400, 700]), rng.randint(1, 4)
+        prof = dict(synth.CCS_PROFILE, rate=rng.choice([0.005, 0.01, 0.02, 0.04]))
     accs, seqs, _ = synth.make_reads(n, L, iso, seed=rng.randint(0, 10 ** 6), profile=prof)
     ends = rng.choice([0, 5, 15, 15])
     use(False); g = run(accs, seqs, ends)
