@@ -11,7 +11,7 @@ alignments) that carry all of them; bound the probability of that many supporter
 The reference aligns the two orders of every edge one call at a time (or one Pool task per edge); here ALL edges of a
 round go to the GPU as one batch of isocon_sg_strings_batch (2 x edges alignments), everything after that is string
 bookkeeping on the host as in the reference.  With base qualities (a `ccs_dict`: FASTQ input) the error probabilities
-come from functions.get_read_ccs_probabilities_c / _t and the per-read statement is used as is."""
+come from the qualities (functions.get_read_ccs_probabilities_c / _t), computed on the same read tables."""
 from __future__ import annotations
 
 import decimal
@@ -67,6 +67,103 @@ class _ReadTable(object):
                 match &= self.read[np.clip(self.off0 + lo + j, 0, self.total - 1)] == snippet[j]
             ok &= match
         return ok
+
+
+    # ---- pieces of the quality-based probabilities (functions._ccs_probabilities), per read and per variant ----
+    def own_window_equal(self, pos, u_v):
+        """aln_read[lo:hi] == aln_own[lo:hi] with lo = max(0, pos - 1), hi = pos + u_v + 1"""
+        ok = np.ones(self.n, dtype=bool)
+        for w in range(-1, u_v + 1):
+            col = pos + w
+            valid = (col >= 0) & (col < self.len)
+            ok &= ~(valid & self.diff[np.clip(self.off0 + col, 0, self.total - 1)])
+        return ok
+
+    def window_equals(self, pos, before, after, text):
+        """aln_read[max(0, pos - before): pos + after] == text"""
+        snippet = np.frombuffer(text.encode("ascii"), dtype=np.uint8)
+        lo = np.maximum(0, pos - before)
+        hi = np.minimum(self.len, pos + after)
+        match = np.maximum(hi - lo, 0) == len(snippet)
+        for j in range(len(snippet)):
+            match &= self.read[np.clip(self.off0 + lo + j, 0, self.total - 1)] == snippet[j]
+        return match
+
+    def read_bases_upto(self, pos):
+        """number of read bases in aln_read[:pos + 1]"""
+        if getattr(self, "_rgap_key", None) is None:
+            g = np.flatnonzero(self.read == 45)
+            row = np.searchsorted(self.off0, g, side="right") - 1
+            self._rgap_key = row * (np.int64(1) << 32) + (g - self.off0[row])          # sorted: by row, then column
+            self._rgap_first = np.searchsorted(row, np.arange(self.n + 1))
+        rows = np.arange(self.n, dtype=np.int64)
+        upto = np.searchsorted(self._rgap_key, rows * (np.int64(1) << 32) + np.clip(pos, -1, (1 << 31) - 1), side="right") - self._rgap_first[:-1]
+        return pos + 1 - np.where(pos >= 0, upto, 0)
+
+    def qualities(self, ccs_dict):
+        """(flat qualities, offset of every read's record, record length, start of the read inside its record)"""
+        if getattr(self, "_qual_of", None) is not ccs_dict:
+            recs = [ccs_dict[acc] for acc in self.accs]
+            lens = np.fromiter((len(r.qual) for r in recs), dtype=np.int64, count=self.n)
+            off = np.zeros(self.n + 1, dtype=np.int64)
+            np.cumsum(lens, out=off[1:])
+            for r in recs:                                  # the record's quality list as an array, made once per record
+                if getattr(r, "_qual_np_of", None) is not r.qual:
+                    r._qual_np, r._qual_np_of = np.asarray(r.qual, dtype=np.int64), r.qual
+            flat = np.concatenate([r._qual_np for r in recs]) if recs else np.zeros(0, dtype=np.int64)
+            reads = self.read_rows_without_gaps()
+            start = np.fromiter((r.seq.index(x) for r, x in zip(recs, reads)), dtype=np.int64, count=self.n)
+            self._qual = (flat, off[:-1], np.fromiter((len(r.seq) for r in recs), dtype=np.int64, count=self.n), start)
+            self._qual_of = ccs_dict
+        return self._qual
+
+    def read_rows_without_gaps(self):
+        raw = self.read.tobytes().decode("ascii")
+        o = self.off0.tolist() + [self.total]
+        return [raw[o[r]:o[r + 1]].replace("-", "") for r in range(self.n)]
+
+
+def _ccs_probabilities_on_table(tab, variant_coords, other_snippets, ccs_dict, ratios, max_phred_q_trusted, shifted_type, coord_when_other):
+    """functions._ccs_probabilities for all reads of a table at once: (informative mask, probability per read)."""
+    subs_ratio, ins_ratio, del_ratio = ratios
+    assert len(variant_coords) > 0
+    alive = np.ones(tab.n, dtype=bool)
+    prob = np.ones(tab.n, dtype=np.float64)
+    if tab.n == 0:
+        return alive, prob
+    flat, qoff, rec_len, rec_start = tab.qualities(ccs_dict)
+    base = np.asarray([10 ** (-((q - 3) * (max_phred_q_trusted - 3.0) / (90.0) + 3) / 10.0) for q in range(94)], dtype=np.float64)
+    for i, (v_type, _, u_v) in variant_coords.items():
+        pos = tab.column_of(i, alive)
+        shows_own = tab.own_window_equal(pos, u_v)
+        if v_type == shifted_type:
+            shows_other = tab.window_equals(pos, 2, u_v, other_snippets[i])
+        else:
+            shows_other = tab.window_equals(pos, 1, u_v + 1, other_snippets[i])
+        assert not (alive & shows_own & shows_other).any()
+        seen = tab.read_bases_upto(pos)
+        read_coord = np.where(shows_own, seen - 1, seen + coord_when_other.get(v_type, -1))
+        alive &= shows_own | shows_other
+        coord = rec_start + read_coord                     # CCS.read_aln_to_ccs_coord
+        if (alive & (coord > rec_len)).any():
+            raise SystemExit("Index error: read position beyond its quality record")
+        coord = np.where(coord == rec_len, coord - 1, coord)
+        coord = np.where(coord < 0, coord + rec_len, coord)        # a negative list index counts from the end
+        if (alive & ((coord < 0) | (coord >= rec_len))).any():
+            raise IndexError("list index out of range")
+        q = flat[np.clip(qoff + np.clip(coord, 0, np.maximum(rec_len - 1, 0)), 0, max(len(flat) - 1, 0))]
+        p10 = base[np.clip(q, 0, 93)]
+        if u_v > 1:
+            p_error = p10
+        elif v_type == "S":
+            p_error = (p10 * subs_ratio) / 3.0
+        elif v_type == "I":
+            p_error = (p10 * ins_ratio) / 4.0
+        else:
+            p_error = p10 * del_ratio
+        prob = np.where(alive, prob * p_error, prob)
+    assert ((prob[alive] > 0.0) & (prob[alive] < 1.0)).all()
+    return alive, prob
 
 
 def _variants_of(aln_t, aln_c):
@@ -199,7 +296,7 @@ def _tables_for(wanted):
     return out
 
 
-def _test_on_tables(t_seq, c_seq, alignment_tc, alignment_ct, tab_c, tab_t):
+def _test_on_tables(t_seq, c_seq, alignment_tc, alignment_ct, tab_c, tab_t, ccs_dict=None, max_phred_q_trusted=None):
     """_test_on_alignments on the read tables of c and t: same tuple, the supporting reads as a count."""
     aln_t, aln_c, variants = _candidate_vs_reference(alignment_tc, alignment_ct)
     variant_coords_t, variant_coords_c, alignment_c_to_t, alignment_t_to_c = functions.get_variant_coordinates(t_seq, c_seq, aln_t, aln_c, variants)
@@ -208,6 +305,23 @@ def _test_on_tables(t_seq, c_seq, alignment_tc, alignment_ct, tab_c, tab_t):
     n_support = len(sup_c) + len(sup_t)
     if len(variants) == 0:
         return variant_coords_t, 0.0, n_support, tab_c.n + tab_t.n
+    if ccs_dict:
+        # base qualities (functions.get_read_ccs_probabilities_c / _t): c's informative reads first, then t's
+        subs = float(max(1.0, int(tab_t.sub.sum() + tab_c.sub.sum())))
+        ins = float(max(1.0, int(tab_t.ins.sum() + tab_c.ins.sum())))
+        del_ = float(max(1.0, int(tab_t.dele.sum() + tab_c.dele.sum())))
+        tot_errors = subs + ins + del_
+        ratios = (subs / tot_errors, ins / tot_errors, del_ / tot_errors)
+        alive_c, prob_c = _ccs_probabilities_on_table(tab_c, variant_coords_c, alignment_t_to_c, ccs_dict, ratios, max_phred_q_trusted, "D", {"I": 0})
+        alive_t, prob_t = _ccs_probabilities_on_table(tab_t, variant_coords_t, alignment_c_to_t, ccs_dict, ratios, max_phred_q_trusted, "I", {"D": 0, "I": -2})
+        prob = np.concatenate([prob_c[alive_c], prob_t[alive_t]])
+        if len(prob) == 0:
+            assert n_support == 0
+            return variant_coords_t, 0.0, n_support, 0
+        assert alive_c[sup_c].all() and alive_t[sup_t].all()
+        slot_c = np.cumsum(alive_c) - 1                       # position of a read of c among the informative ones
+        slot_t = int(alive_c.sum()) + np.cumsum(alive_t) - 1
+        return variant_coords_t, _raghavan_on_arrays(prob, np.concatenate([slot_c[sup_c], slot_t[sup_t]]) if n_support else None), n_support, len(prob)
     # error probabilities per read, t's reads first (functions.get_read_errors / get_empirical_error_probabilities)
     n_reads = tab_t.n + tab_c.n
     if n_reads == 0:
@@ -227,7 +341,12 @@ def _test_on_tables(t_seq, c_seq, alignment_tc, alignment_ct, tab_c, tab_t):
         elif v_type == "D":
             prob *= np.minimum(0.5, p_D * u_v)
     prob[prob >= 1.0] = 0.99999
-    # Raghavan's bound (raghavan_upper_pvalue_bound): logarithms with math.log per distinct probability, sums in read order
+    return variant_coords_t, _raghavan_on_arrays(prob, np.concatenate([tab_t.n + sup_c, sup_t]) if n_support else None), n_support, n_reads
+
+
+def _raghavan_on_arrays(prob, supporters):
+    """raghavan_upper_pvalue_bound for probabilities in dict order and the indices of the supporting reads (in the order of
+    functions.get_support): logarithms with math.log per distinct probability, sums left to right like the reference's."""
     assert prob.max() <= 1.0 and prob.min() > 0.0
     uniq, inv = np.unique(prob, return_inverse=True)
     logs = [-math.log(p, 10) for p in uniq.tolist()]
@@ -236,8 +355,8 @@ def _test_on_tables(t_seq, c_seq, alignment_tc, alignment_ct, tab_c, tab_t):
     w_u = np.asarray([l / log_max for l in logs], dtype=np.float64)
     weight = w_u[inv]
     m_sum = sum((w_u * uniq)[inv].tolist())
-    y_sum = sum(weight[np.concatenate([tab_t.n + sup_c, sup_t])].tolist()) if n_support else 0
-    return variant_coords_t, _raghavan_from_sums(m_sum, y_sum), n_support, n_reads
+    y_sum = sum(weight[supporters].tolist()) if supporters is not None else 0
+    return _raghavan_from_sums(m_sum, y_sum)
 
 
 def arrange_alignments_new_no_realign(t_acc, c_acc, t_seq, c_seq, read_alignments_to_c, read_alignments_to_t, ccs_dict, ignore_ends_len, max_phred_q_trusted):
@@ -278,23 +397,19 @@ def do_statistical_tests_per_edge(nearest_neighbor_graph, C, X, read_partition, 
     alignments = SWM._align_pairs(pairs, [-3] * len(pairs), 2, 3, 1) if pairs else []
     of_edge = {e: (alignments[2 * i], alignments[2 * i + 1]) for i, e in enumerate(live)}
     p_values = {c_acc: {} for c_acc in nearest_neighbor_graph}
-    tables = {} if ccs_dict else _tables_for([(C[acc], read_partition[acc]) for e in live for acc in e])
+    tables = _tables_for([(C[acc], read_partition[acc]) for e in live for acc in e])
     for c_acc, t_acc in edges:
         if (c_acc, t_acc) not in of_edge:
             p_values[c_acc][t_acc] = (1.0, 1.0, 0, 0, "")
             continue
         assert not (set(read_partition[c_acc]) & set(read_partition[t_acc]))
         tc, ct = of_edge[(c_acc, t_acc)]
-        if ccs_dict:        # with base qualities: the per-read statement (the reads' records are looked up one by one)
+        if ccs_dict:
             for x_acc in read_partition[c_acc]:
                 assert X[x_acc] == ccs_dict[x_acc].seq
-            delta_t, p_value, reads_support, used = _test_on_alignments(C[t_acc], C[c_acc], tc, ct, read_partition[c_acc], read_partition[t_acc],
-                                                                        ccs_dict, params.max_phred_q_trusted)
-            p_values[c_acc][t_acc] = _result(c_acc, t_acc, C[t_acc], delta_t, p_value, reads_support, used, True)[2:]
-            continue
         delta_t, p_value, n_support, used = _test_on_tables(C[t_acc], C[c_acc], tc, ct, tables[id(read_partition[c_acc])],
-                                                            tables[id(read_partition[t_acc])])
-        p_values[c_acc][t_acc] = _result(c_acc, t_acc, C[t_acc], delta_t, p_value, range(n_support), used)[2:]
+                                                            tables[id(read_partition[t_acc])], ccs_dict, getattr(params, "max_phred_q_trusted", None))
+        p_values[c_acc][t_acc] = _result(c_acc, t_acc, C[t_acc], delta_t, p_value, range(n_support), used, bool(ccs_dict))[2:]
     return p_values
 
 

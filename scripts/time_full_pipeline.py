@@ -1,5 +1,5 @@
 """Wall time of the whole pipeline (find_candidate_transcripts + stat_filter_candidates) on synthetic CCS reads, with a
-breakdown of the statistical-test phase.  Usage: python scripts/time_full_pipeline.py [n_reads] [length] [isoforms] [ont]"""
+breakdown of the statistical-test phase.  Usage: python scripts/time_full_pipeline.py [n_reads] [length] [isoforms] [ont|ccs] [fastq]"""
 import cProfile, os, pstats, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from isocon_amd import synth
@@ -13,13 +13,19 @@ if len(sys.argv) > 4 and sys.argv[4] == "ont":      # ONT error profile (6 %), t
 else:
     accs, seqs, isoforms = synth.make_reads(n, L, iso, 30001)
 with tempfile.TemporaryDirectory() as tmp:
-    rf = os.path.join(tmp, "reads.fa")
+    fastq = "fastq" in sys.argv[4:]           # FASTQ input with random base qualities: the tests then use them
+    rf = os.path.join(tmp, "reads.fq" if fastq else "reads.fa")
     with open(rf, "w") as fh:
-        for a, s in zip(accs, seqs): fh.write(">%s\n%s\n" % (a, s))
+        if fastq:
+            import numpy as np
+            rq = np.random.default_rng(1)
+            for a, s in zip(accs, seqs): fh.write("@%s\n%s\n+\n%s\n" % (a, s, (rq.integers(5, 60, len(s)) + 33).astype(np.uint8).tobytes().decode()))
+        else:
+            for a, s in zip(accs, seqs): fh.write(">%s\n%s\n" % (a, s))
     class Out:
         def write(self, x): sys.stdout.write(x); sys.stdout.flush()
     class P: nr_cores = 1; neighbor_search_depth = 2 ** 32; verbose = False; develop_logfile = None; logfile = Out(); min_exon_diff = 20
-    P.ignore_ends_len = 15; P.min_candidate_support = 2; P.is_fastq = False; P.ccs = None; P.outfolder = tmp
+    P.ignore_ends_len = 15; P.min_candidate_support = 2; P.is_fastq = fastq; P.ccs = None; P.outfolder = tmp
     P.p_value_threshold = 0.01; P.min_test_ratio = 5; P.max_phred_q_trusted = 43
     t = time.time(); cand_file, rp, to_realign = IGC.find_candidate_transcripts(rf, P); t1 = time.time() - t
     ncand = sum(1 for l in open(cand_file) if l.startswith(">"))

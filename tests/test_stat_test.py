@@ -266,3 +266,67 @@ def test_empty_candidate_file_writes_empty_outputs_and_exits(tmp_path):
         IST.stat_filter_candidates(str(reads), str(cands), {}, {"r1": "ACGTACGT"}, Params())
     assert e.value.code == 0
     assert (tmp_path / "final_candidates.fa").read_text() == "" and (tmp_path / "cluster_info.tsv").read_text() == ""
+
+
+def test_read_tables_equal_the_per_read_functions_with_qualities():
+    """The quality-based probabilities on the read tables (hypothesis_test_module._ccs_probabilities_on_table) against the
+    per-read statement (functions.get_read_ccs_probabilities_c / _t + raghavan_upper_pvalue_bound): bit-equal p-values,
+    the same number of informative reads, the same exceptions."""
+    import random
+    from isocon_amd import ccs_info as CI
+    from isocon_amd import hypothesis_test_module as H
+    from oracle import oracle as O
+    rng = random.Random(12)
+
+    def mut(b, n):
+        v = list(b)
+        for _ in range(n):
+            p = rng.randrange(len(v))
+            r = rng.random()
+            if r < 0.4:
+                v[p] = rng.choice("ACGT")
+            elif r < 0.7:
+                del v[p]
+            else:
+                v.insert(p, v[p] if rng.random() < 0.5 else rng.choice("ACGT"))
+        return "".join(v)
+
+    def aln(a, b, **kw):
+        return O.parasail_alignment(a, b, 0, 0, **kw)[2]
+
+    compared = dropped = 0
+    for trial in range(150):
+        t = "".join(rng.choice("AACGTT") for _ in range(rng.randint(40, 150)))
+        c = mut(t, rng.randint(1, 3))
+        if c == t:
+            continue
+        reads, reads_c, reads_t = {}, {}, {}
+        for k in range(rng.randint(1, 8)):
+            x = c if rng.random() < 0.5 else mut(c, rng.randint(0, 2))
+            reads["c%d" % k] = x
+            reads_c["c%d" % k] = aln(c, x)
+        for k in range(rng.randint(1, 9)):
+            src = t if rng.random() < 0.6 else c
+            x = src if rng.random() < 0.5 else mut(src, rng.randint(0, 2))
+            reads["t%d" % k] = x
+            reads_t["t%d" % k] = aln(t, x)
+        ccs = {a: CI.CCS(a, s, [rng.randint(3, 70) for _ in s], "NA") for a, s in reads.items()}
+        tc = aln(t, c, opening_penalty=3, mismatch_penalty=-3, gap_ext=1)
+        ct = aln(c, t, opening_penalty=3, mismatch_penalty=-3, gap_ext=1)
+
+        def call(fn, *a):
+            try:
+                return fn(*a)
+            except (AssertionError, IndexError, SystemExit) as e:
+                return type(e).__name__
+
+        slow = call(H._test_on_alignments, t, c, tc, ct, reads_c, reads_t, ccs, 43)
+        fast = call(H._test_on_tables, t, c, tc, ct, H._ReadTable(len(c), reads_c), H._ReadTable(len(t), reads_t), ccs, 43)
+        if isinstance(slow, str) or isinstance(fast, str):
+            assert slow == fast, (trial, slow, fast)
+            continue
+        assert list(slow[0].items()) == list(fast[0].items())
+        assert slow[1] == fast[1] and len(slow[2]) == fast[2] and slow[3] == fast[3], (trial, slow[1:], fast[1:])
+        compared += slow[1] not in (0.0, 1.0)
+        dropped += slow[3] < len(reads)
+    assert compared > 25 and dropped > 10
