@@ -23,6 +23,11 @@ from . import functions
 from . import SW_alignment_module as SWM
 
 
+def _clamp(a, hi):
+    """a limited to [0, hi] (np.clip with less call overhead: this runs per variant and window column of every edge)"""
+    return np.minimum(np.maximum(a, 0), hi)
+
+
 class _ReadTable(object):
     """The stored alignments of one candidate's reads as flat arrays, so that the per-read quantities of a test --
     alignment column of a candidate position, error counts, window comparisons -- are computed once per round and for all
@@ -50,7 +55,7 @@ class _ReadTable(object):
             for w in range(-1, u_v + 1):
                 col = pos + w
                 valid = (col >= 0) & (col < self.len)
-                ok &= ~(valid & self.diff[np.clip(self.off0 + col, 0, self.total - 1)])
+                ok &= ~(valid & self.diff[_clamp(self.off0 + col, self.total - 1)])
         return ok
 
     def show_snippets(self, variant_coords, snippets):
@@ -64,7 +69,7 @@ class _ReadTable(object):
             hi = np.minimum(self.len, pos + after)
             match = np.maximum(hi - lo, 0) == len(snippet)
             for j in range(len(snippet)):
-                match &= self.read[np.clip(self.off0 + lo + j, 0, self.total - 1)] == snippet[j]
+                match &= self.read[_clamp(self.off0 + lo + j, self.total - 1)] == snippet[j]
             ok &= match
         return ok
 
@@ -76,7 +81,7 @@ class _ReadTable(object):
         for w in range(-1, u_v + 1):
             col = pos + w
             valid = (col >= 0) & (col < self.len)
-            ok &= ~(valid & self.diff[np.clip(self.off0 + col, 0, self.total - 1)])
+            ok &= ~(valid & self.diff[_clamp(self.off0 + col, self.total - 1)])
         return ok
 
     def window_equals(self, pos, before, after, text):
@@ -86,7 +91,7 @@ class _ReadTable(object):
         hi = np.minimum(self.len, pos + after)
         match = np.maximum(hi - lo, 0) == len(snippet)
         for j in range(len(snippet)):
-            match &= self.read[np.clip(self.off0 + lo + j, 0, self.total - 1)] == snippet[j]
+            match &= self.read[_clamp(self.off0 + lo + j, self.total - 1)] == snippet[j]
         return match
 
     def read_bases_upto(self, pos):
