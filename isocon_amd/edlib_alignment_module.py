@@ -77,6 +77,28 @@ def edlib_alignment_helper(arguments):
 
 
 def edlib_traceback(x, y, mode="NW", task="path", k=1):
-    """EAM:130-135.  Its only caller is dead code in the reference v0.3.3; edlib's CIGAR
-    tie-breaking is unpinned, so no GPU path is offered."""
-    raise NotImplementedError("edlib_traceback (edlib task='path') has no GPU implementation; dead code in IsoCon v0.3.3")
+    """EAM:130-135: (editDistance, locations, cigar) of edlib.align(x, y, mode="NW", task="path", k=k).  Its only caller
+    (isocon_statistical_test.get_nearest_neighbor_graph, :63-104) is never called in v0.3.3.  The
+    k-bounded distance comes from the GPU; above k edlib reports (-1, [], None).  The path of a hit is traced on the host
+    (functions.nw_path_cigar, O(len x * len y): this is not a hot path) with the tie rule used everywhere else (from the
+    end: I, then D, then the diagonal; "parity unpinned").  HW mode lives in end_invariant_functions.edlib_traceback."""
+    if mode != "NW" or task != "path":
+        raise NotImplementedError("edlib_alignment_module.edlib_traceback: only mode='NW', task='path' (EAM:130-135)")
+    from .store import SeqStore
+    st = SeqStore([x, y])
+    try:
+        ed = int(st.ed_pairs([0], [1], None if k is None or k < 0 else [int(k)])[0])
+    finally:
+        st.close()
+    if ed < 0:
+        return -1, [], None
+    from .functions import nw_path_cigar
+    ops = nw_path_cigar(x, y)
+    cigar, i = [], 0
+    while i < len(ops):
+        j = i
+        while j < len(ops) and ops[j] == ops[i]:
+            j += 1
+        cigar.append("%d%s" % (j - i, ops[i]))
+        i = j
+    return ed, [(0, len(y) - 1)], "".join(cigar)

@@ -41,3 +41,31 @@ def test_single_pair_helpers():
     assert NNG.edlib_ed("ACGTACGT", "TTTTTTTT", k=2) == -1
     assert NNG.edlib_ed("ACGTACGT", "ACGTACGA", k=2) == 1
     assert EAM.edlib_align_sequences({}) == {}
+
+
+@pytest.mark.gpu
+def test_edlib_traceback_nw_mode():
+    """EAM.edlib_traceback (row a11, no live caller): distance from the GPU, path by the oracle's tie rule; above k edlib's
+    (-1, [], None)."""
+    import random
+    from isocon_amd import edlib_alignment_module as EAM
+    from oracle import oracle as O
+    rng = random.Random(2)
+    for _ in range(25):
+        x = "".join(rng.choice("ACGT") for _ in range(rng.randint(5, 120)))
+        y = list(x)
+        for _ in range(rng.randint(0, 6)):
+            p = rng.randrange(len(y))
+            r = rng.random()
+            if r < 0.4:
+                y[p] = rng.choice("ACGT")
+            elif r < 0.7 and len(y) > 2:
+                del y[p]
+            else:
+                y.insert(p, rng.choice("ACGT"))
+        y = "".join(y)
+        ed, ops = O.nw_path(x, y)
+        cigar = "".join("%d%s" % o for o in ops)
+        assert EAM.edlib_traceback(x, y, mode="NW", task="path", k=10) == ((ed, [(0, len(y) - 1)], cigar) if ed <= 10 else (-1, [], None))
+    with pytest.raises(NotImplementedError):
+        EAM.edlib_traceback("ACGT", "ACGT", mode="HW")
