@@ -24,6 +24,7 @@
 namespace isocon {
 
 static constexpr int32_t HW_INF = 1 << 24;
+static constexpr int32_t HW_TPAD = 1024;       // bytes around the target in LDS: > 64 * 8 diagonals + k + 2
 
 // Cross-lane moves as DPP modifiers (VALU, no LDS round trip): a lane that has no source keeps `old`.
 template <int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ int32_t hw_dpp(int32_t old, int32_t v)
@@ -56,37 +57,42 @@ template <int NB, bool TRACE, bool EARLY>
 __device__ __forceinline__ bool hw_band_rows(const uint8_t *Q, int32_t n, bool qrev, const uint8_t *T, int32_t t0, bool trev, int32_t m,
                                              int32_t off, bool topzero, uint64_t *trace, int lane, int32_t (&cur)[NB], int32_t kstop)
 {
+    // No per-cell range checks in the loop: columns j < 0 start at "infinity" and stay there by themselves (all their
+    // predecessors are columns < 0, values are clamped), columns j > m hold junk that never reaches a column <= m
+    // (information only moves to the same or a larger column), and the callers read columns 1..m only.  T is padded on
+    // both sides (HW_TPAD bytes), so the base index t0 +- (j - 1) is always inside the buffer.
+    int32_t tix[NB];
+    const int32_t tdir = trev ? -1 : 1;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int32_t j = lane + 64 * b - off;
         cur[b] = (j >= 0 && j <= m) ? (topzero ? 0 : j) : HW_INF;
+        tix[b] = t0 + tdir * j;                                          // cell (i, c) compares target base c - 1; row 1: c - 1 = d - off
     }
+    int32_t qi = qrev ? n - 1 : 0;
+    const int32_t qdir = qrev ? -1 : 1;
     for (int32_t i = 1; i <= n; ++i) {
-        const int32_t qc = Q[qrev ? n - i : i - 1];                     // wave-uniform LDS read
+        const int32_t qc = Q[qi];                                       // wave-uniform LDS read
+        qi += qdir;
         int32_t nw[NB];
         int32_t run = HW_INF;                                           // min of a[d'] - d' over the blocks already done
         int32_t left_in = HW_INF;                                       // new value of the last diagonal of the previous block
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int32_t d = lane + 64 * b;
-            const int32_t j = i + d - off;
             const int32_t nxt0 = b + 1 < NB ? __builtin_amdgcn_readfirstlane(cur[b + 1 < NB ? b + 1 : b]) : HW_INF;
             const int32_t up = hw_dpp<0x130, 0xf, 0xf>(nxt0, cur[b]);    // wave_shl:1: lane l takes lane l + 1, lane 63 keeps nxt0
-            const bool valid = j >= 0 && j <= m;
-            int32_t tc = 255;
-            if (j >= 1 && j <= m) tc = T[trev ? t0 - (j - 1) : t0 + (j - 1)];
+            const int32_t tc = T[tix[b]];
+            tix[b] += tdir;
             const int32_t diag = cur[b] + (tc != qc ? 1 : 0);           // (i-1, j-1) is diagonal d of the previous row
-            int32_t a = diag < up + 1 ? diag : up + 1;
-            if (!valid || a > HW_INF) a = HW_INF;
-            int32_t pm = hw_prefix_min(a - d);
-            pm = pm < run ? pm : run;
-            int32_t v = pm + d;
-            if (!valid || v > HW_INF) v = HW_INF;
+            const int32_t a = hw_min(hw_min(diag, up + 1), HW_INF);
+            const int32_t pm = hw_min(hw_prefix_min(a - d), run);
+            const int32_t v = hw_min(pm + d, HW_INF);
             run = __builtin_amdgcn_readlane(pm, 63);
             if (TRACE) {
                 const int32_t left = hw_dpp<0x138, 0xf, 0xf>(left_in, v);   // wave_shr:1: lane l takes lane l - 1, lane 0 keeps left_in
-                const uint64_t m_up = __ballot(valid && up + 1 == v);
-                const uint64_t m_left = __ballot(valid && left + 1 == v);
+                const uint64_t m_up = __ballot(up + 1 == v);
+                const uint64_t m_left = __ballot(left + 1 == v);
                 if (lane == 0) {
                     trace[((size_t)i * NB + b) * 2] = m_up;
                     trace[((size_t)i * NB + b) * 2 + 1] = m_left;
@@ -101,7 +107,7 @@ __device__ __forceinline__ bool hw_band_rows(const uint8_t *Q, int32_t n, bool q
             int32_t rowmin = cur[0];
 #pragma unroll
             for (int b = 1; b < NB; ++b) rowmin = hw_min(rowmin, cur[b]);
-            if (wave_min_i32(rowmin) > kstop) return false;            // wave-uniform
+            if (wave_min_i32(rowmin) > kstop) return false;            // wave-uniform (junk columns can only delay this)
         }
     }
     return true;
@@ -110,14 +116,14 @@ __device__ __forceinline__ bool hw_band_rows(const uint8_t *Q, int32_t n, bool q
 // out[5 p ..] = distance (-1: > k, -3: band does not fit), start, end, leading insertion run, trailing insertion run.
 // NBA blocks of 64 diagonals for phase A (max(len(t) - len(q), 0) + 2 k + 1 diagonals), NB for phases B and C (2 k + 1).
 // grid = any number of 64-thread blocks (pairs are dealt round-robin); trace: (maxlen + 1) * NB * 2 words per block;
-// dynamic LDS = 2 * lds_stride bytes (lds_stride >= maxlen, multiple of 8).
+// dynamic LDS = 2 * lds_stride + 2 * HW_TPAD bytes (lds_stride >= maxlen, multiple of 8): query, pad, target, pad.
 template <int NBA, int NB>
 __global__ __launch_bounds__(64) void k_hw_path(DevStore S, const uint32_t *__restrict__ pq, const uint32_t *__restrict__ pt, const int32_t *__restrict__ pk,
                                                  uint32_t n_pairs, uint64_t *__restrict__ trace_all, uint32_t trace_rows,
                                                  uint32_t lds_stride, int32_t *__restrict__ out)
 {
     extern __shared__ uint8_t hw_lds[];
-    uint8_t *Q = hw_lds, *T = hw_lds + lds_stride;
+    uint8_t *Q = hw_lds, *T = hw_lds + lds_stride + HW_TPAD;
     const int lane = threadIdx.x;
     uint64_t *trace = trace_all + (size_t)blockIdx.x * trace_rows * NB * 2;
     const uint64_t *planes = S.planes;
