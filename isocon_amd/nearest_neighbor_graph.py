@@ -99,10 +99,25 @@ def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
     return _rows_to_dict(accs, np.ones(len(accs), dtype=bool), best, row_ptr, cols)
 
 
+_SLICED = {"key": None, "graph": None}      # the whole graph of the most recent sliced call
+
+
+def _sliced(kind, seq_to_acc_list_sorted, role, depth, compute):
+    """The sliced entry points are what the reference's Pool calls once per chunk (NNG:33-65: 10 x nr_cores chunks) on the
+    SAME list: the whole graph is computed on the first chunk and the following chunks of that list read their rows from
+    it.  Key = the strings' (cached) hashes, the accessions, the role set and the depth."""
+    key = (kind, len(seq_to_acc_list_sorted), hash(tuple(map(tuple, seq_to_acc_list_sorted))), hash(frozenset(role)), depth)
+    if _SLICED["key"] != key:
+        _SLICED["graph"] = compute()
+        _SLICED["key"] = key
+    return _SLICED["graph"]
+
+
 def get_nearest_neighbors(batch_of_queries, global_index_in_matrix, start_index, seq_to_acc_list_sorted, has_converged,
                           neighbor_search_depth):
     """NNG:110-198.  The rows of the queries [start_index, start_index+len(batch)) of the exact graph."""
-    full = _nn_1set(seq_to_acc_list_sorted, has_converged, neighbor_search_depth)
+    full = _sliced(1, seq_to_acc_list_sorted, has_converged, neighbor_search_depth,
+                   lambda: _nn_1set(seq_to_acc_list_sorted, has_converged, neighbor_search_depth))
     keep = [seq_to_acc_list_sorted[i][1] for i in range(start_index, start_index + len(batch_of_queries))]
     return {acc: full[acc] for acc in keep}
 
@@ -194,7 +209,8 @@ def _nn_2set(seq_to_acc_list_sorted_all, target_accessions, depth):
 
 def get_nearest_neighbors_2set(batch, start_index, seq_to_acc_list_sorted, target_accessions, neighbor_search_depth):
     """NNG:341-424 for the entries [start_index, start_index+len(batch))."""
-    full = _nn_2set(seq_to_acc_list_sorted, target_accessions, neighbor_search_depth)
+    full = _sliced(2, seq_to_acc_list_sorted, target_accessions, neighbor_search_depth,
+                   lambda: _nn_2set(seq_to_acc_list_sorted, target_accessions, neighbor_search_depth))
     keep = [seq_to_acc_list_sorted[i][1] for i in range(start_index, start_index + len(batch))]
     return {acc: full[acc] for acc in keep if acc in full}
 

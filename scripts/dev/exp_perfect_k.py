@@ -1,7 +1,7 @@
 """How much of the main pass is due to thresholds that are not yet final?  Main pass (nn_partial phase 1) started from
 the seed bounds (normal) vs from the FINAL best[] (an oracle nobody has), at C3 and at 200 k reads."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from isocon_amd import synth, _lib
 from isocon_amd.store import SeqStore

@@ -1,6 +1,6 @@
 """2-set search timing: n reads (C3 profile) against the true isoforms plus mutated variants."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from isocon_amd import synth
 from isocon_amd import nearest_neighbor_graph as NNG

@@ -1,6 +1,6 @@
 """Scaling checks on one GPU: 200 k CCS reads (16 x the pairs of C3) and 50 k ONT-profile reads (quarter-size C5)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from isocon_amd import synth
 from isocon_amd.store import SeqStore

@@ -1,6 +1,6 @@
 """Scaled-down config C5 (mixed-length ONT-profile reads): exercises the wide-band / un-banded fallbacks."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from isocon_amd import synth
 from isocon_amd.store import SeqStore

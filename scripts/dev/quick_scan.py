@@ -1,6 +1,6 @@
 """Prints the main-pass kernel time of the 1-set NN search at C3 (kernel experiments; set ISOCON_LIB)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from isocon_amd import synth
 from isocon_amd.store import SeqStore

@@ -1,6 +1,6 @@
 """SW batch timing at C3 scale: 8192 (centre, read) pairs of ~2.5 kb, with and without the edit-distance band hint."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from isocon_amd import synth
 from isocon_amd.edlib_alignment_module import _intern

@@ -1,7 +1,7 @@
 """Runs find_candidate_transcripts + stat_filter_candidates (default parameters) on a FASTA(.gz) file and dumps what the
 golden generator tests/golden/make_golden_stat_test.py collects.  Usage: python scripts/run_pipeline_dump.py reads.fa[.gz] out.json"""
 import glob, gzip, hashlib, json, os, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from isocon_amd import isocon_get_candidates as IGC
 from isocon_amd import isocon_statistical_test as IST
 

@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-sw}
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -- python3 $R/scripts/quick_sw.py > /dev/null 2> $R/gpurun_out/pmc_$TAG.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -- python3 $R/scripts/dev/quick_sw.py > /dev/null 2> $R/gpurun_out/pmc_$TAG.err
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob('$R/gpurun_out/pmc_$TAG/*/*_counter_collection.csv')[0]

@@ -1,11 +1,13 @@
-"""Turn gpurun_out/{prof,pmc_fetch,pmc_write}_<TAG> (written by scripts/profile_bench.sh) into the tracked files
-profiles/<TAG>_kernel_stats.csv, profiles/<TAG>_pmc_summary.txt, profiles/<TAG>_bench.json and profiles/traffic.json."""
+"""Turn gpurun_out/{prof,pmc_sq,pmc_fetch,pmc_write}_<TAG> (written by scripts/profile_bench.sh) into the tracked files
+profiles/<TAG>_kernel_stats.csv, profiles/<TAG>_pmc_summary.txt, profiles/<TAG>_sq_summary.txt, profiles/<TAG>_bench.json and
+profiles/counters.json (read by bench.py: per-dispatch SQ_INSTS_VALU and HBM bytes of the kernels its line reports)."""
 import csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out = os.path.join(ROOT, "gpurun_out")
 prof = os.path.join(ROOT, "profiles")
+
 
 def newest(pattern):
     """the most recent match (a tag's directory may hold the files of several runs)"""
@@ -20,33 +22,79 @@ if os.path.exists(b):
     shutil.copy(b, os.path.join(prof, tag + "_bench.json"))
 
 
-def rows(kind):
+def dispatches(kind):
+    """[(dispatch id, kernel name, grid, dur_ns, {counter: value})] in dispatch order, isocon kernels only"""
     f = newest(os.path.join(out, "pmc_%s_%s" % (kind, tag), "*", "*_counter_collection.csv"))
-    res = []
     if not f:
-        return res
+        return []
+    d = {}
     for r in csv.DictReader(open(f[0])):
-        if "isocon::k_" in r["Kernel_Name"]:
-            res.append((r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"]),
-                        int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-    return res
+        if "isocon::k_" not in r["Kernel_Name"]:
+            continue
+        key = int(r["Dispatch_Id"])
+        e = d.setdefault(key, [key, r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]),
+                               int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), {}])
+        e[4][r["Counter_Name"]] = e[4].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return [tuple(d[k]) for k in sorted(d)]
 
 
-lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-         "dispatches of one NN-graph step at C3 (50k x 2.5kb)"]
-fetch = rows("fetch"); write = rows("write")
-main = {}
-for name, grid, cn, val, dur in fetch + write:
-    lines.append("%s grid=%d %s=%f KiB dur_ns=%d" % (name, grid, cn, val, dur))
-    if "k_nn_scan_refill" in name or "k_nn_scan_lds" in name:
-        main[cn] = val
-        main["kernel"] = name
-lines.append("HBM traffic of the main launch = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md #HBM) + WRITE_SIZE, x 1024 B")
+def classify(rows):
+    """dispatch classes bench.py reports: first main pass, first seed pass, the two 4096-pair SW batches, the two infix batches"""
+    cls = {}
+    sg = [r for r in rows if "k_sg_forward" in r[1] and r[2] == 4096 * 64]
+    hw = [r for r in rows if "k_hw" in r[1] and r[2] >= 4096 * 64]
+    for r in rows:
+        if "k_nn_scan_refill" in r[1] and "nn_main" not in cls:
+            cls["nn_main"] = [r]
+        if "k_nn_scan_up<1>" in r[1] and "nn_seed" not in cls:
+            cls["nn_seed"] = [r]
+    if len(sg) >= 2:
+        cls["sg_full"], cls["sg_banded"] = [sg[0]], [sg[1]]
+    # one isocon_hw_pairs call may be several launches (phases / classes): split the launches of the two 4096-pair calls in half
+    if len(hw) >= 2:
+        half = len(hw) // 2
+        cls["hw_k25"], cls["hw_k63"] = hw[:half], hw[half:2 * half]
+    return cls
+
+
+sq, fetch, write = dispatches("sq"), dispatches("fetch"), dispatches("write")
+counters = {"round": tag, "command": "rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "
+                                     "(three passes: SQ_*, FETCH_SIZE, WRITE_SIZE)", "workload": "C3 (50k x 2.5kb, seed 30001)"}
+lines = [counters["command"], "dispatches of one NN-graph step at C3 (50k x 2.5kb) and of bench.py's untimed extras"]
+for kind, rows in (("sq", sq), ("fetch", fetch), ("write", write)):
+    for did, name, grid, dur, c in rows:
+        lines.append("%s grid=%d dur_ns=%d %s" % (name, grid, dur, " ".join("%s=%.6g" % kv for kv in sorted(c.items()))))
+    for key, rr in classify(rows).items():
+        e = counters.setdefault(key, {"kernel": rr[0][1], "grid": rr[0][2], "launches": len(rr)})
+        for did, name, grid, dur, c in rr:
+            for cn, v in c.items():
+                e[cn] = e.get(cn, 0.0) + v
+        e["dur_ns_%s_pass" % kind] = sum(r[3] for r in rr)
+for key, e in counters.items():
+    if isinstance(e, dict) and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        # KiB -> bytes; FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM section)
+        e["hbm_bytes"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
+bj = os.path.join(out, "bench_sq_%s.json" % tag)
+if os.path.exists(bj) and "nn_main" in counters:
+    try:
+        line = [ln for ln in open(bj) if ln.startswith("{")][-1]
+        counters["nn_main"]["wave_columns"] = json.loads(line)["roofline"]["wave_columns_per_launch"]
+    except Exception as ex:
+        print("no wave_columns:", ex)
+lines.append("HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE doubled: gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md)")
 open(os.path.join(prof, tag + "_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
-if "FETCH_SIZE" in main and "WRITE_SIZE" in main:
-    t = {"round": tag, "kernel": main["kernel"] + " main pass, C3 (50k x 2.5kb)",
-         "nn_scan_main_hbm_bytes_per_launch": (2 * main["FETCH_SIZE"] + main["WRITE_SIZE"]) * 1024.0,
-         "fetch_size_kib": main["FETCH_SIZE"], "write_size_kib": main["WRITE_SIZE"],
-         "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md #HBM); source profiles/%s_pmc_summary.txt" % tag}
-    json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
-print("\n".join(lines))
+
+PEAK = 256 * 4 * 2.4e9 / 2
+sql = ["SQ counters per dispatch class (%s); VALU peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles = %.4g wave-instr/s" % (tag, PEAK)]
+for key, e in counters.items():
+    if isinstance(e, dict) and "SQ_INSTS_VALU" in e:
+        dur = e.get("dur_ns_sq_pass", 0) or 1
+        sql.append("%-10s %s grid=%d launches=%d dur_ms=%.3f" % (key, e["kernel"], e["grid"], e["launches"], dur / 1e6))
+        sql.append("           " + " ".join("%s=%.6g" % (k, v) for k, v in sorted(e.items()) if k.startswith("SQ_")))
+        sql.append("           VALU wave-instr/s = %.4g = %.3f of peak (profiled pass; bench.py divides by the un-profiled live time)"
+                   % (e["SQ_INSTS_VALU"] / (dur / 1e9), e["SQ_INSTS_VALU"] / (dur / 1e9) / PEAK))
+        if e.get("hbm_bytes"):
+            sql.append("           HBM bytes = %.4g -> %.1f GB/s = %.4f of 8 TB/s" % (e["hbm_bytes"], e["hbm_bytes"] / dur, e["hbm_bytes"] / dur / 8000.0))
+open(os.path.join(prof, tag + "_sq_summary.txt"), "w").write("\n".join(sql) + "\n")
+json.dump(counters, open(os.path.join(prof, "counters.json"), "w"), indent=1)
+print("\n".join(sql))
