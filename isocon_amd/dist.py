@@ -121,11 +121,23 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
             if not (is_query & (best[:n] == _lib.NN_INF) & (np.asarray(store.lens)[:n] > 63)).any():
                 stats_all.append({k: 0 for k in stats_all[-1]} if stats_all else {})
                 continue
-        hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth,
-                                       q_stride=qs)
-        t = torch.from_numpy(best).to(device)
+        # A rank that fails here (out of memory, a HIP error) must not leave the others blocked in the collective: its
+        # status travels as one more word of the very reduction that follows (MIN: -1 wins), then every rank raises.
+        err = None
+        try:
+            hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth,
+                                           q_stride=qs)
+        except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
+            err, hits, stats = e, np.zeros((0, 3), np.int32), {}
+        t = torch.empty(len(best) + 1, dtype=torch.int32)
+        t[:-1] = torch.from_numpy(best)
+        t[-1] = -1 if err is not None else 0
+        t = t.to(device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)           # exchange step 1 (and 2)
-        best[:] = t.cpu().numpy()
+        t = t.cpu()
+        if int(t[-1]) != 0:
+            raise RuntimeError("sharded_nn_graph: phase %d failed on %s" % (phase, "this rank: %r" % (err,) if err is not None else "another rank"))
+        best[:] = t[:-1].numpy()
         hits_all.append(hits)
         stats_all.append(stats)
     hits = np.concatenate(hits_all, axis=0) if hits_all else np.zeros((0, 3), np.int32)

@@ -123,7 +123,7 @@ def _rejection_threshold(worst, p_value_threshold):
 def stat_filter_candidates(read_file, candidate_file, read_partition, to_realign, params):
     """isocon_statistical_test.py:152-536.  read_partition: {c_acc: {read_acc: (c_aln, read_aln, (matches, mismatches,
     indels))}} and to_realign as returned by find_candidate_transcripts.  Returns the surviving candidates {acc: seq}."""
-    if getattr(params, "ccs", None):
+    if getattr(params, "ccs", None) and not params.is_fastq:       # the reference checks is_fastq first (:177-191): a FASTQ run uses its own qualities
         raise NotImplementedError("stat_filter_candidates: CCS quality values from a BAM file are not provided")
     if params.is_fastq:
         X_original = {acc: seq for (acc, seq, qual) in fastq_parser.readfq(open(read_file, "r"))}

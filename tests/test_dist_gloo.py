@@ -97,6 +97,38 @@ def test_ranks_with_different_stores_are_rejected(tmp_path):
         assert "fingerprint mismatch" in open(tmp_path / ("mismatch%d.txt" % r)).read()
 
 
+def _worker_one_rank_fails(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isocon_amd.dist import sharded_nn_graph
+
+    class Failing(FakeStore):
+        def nn_partial(self, q_begin, q_end, phase, best, **kw):
+            if rank == 1 and phase == 1:
+                raise MemoryError("out of device memory (simulated)")
+            return FakeStore.nn_partial(self, q_begin, q_end, phase, best, **kw)
+
+    try:
+        sharded_nn_graph(Failing(["ACGTACGT", "ACGTTCGT", "ACGTTCGTA", "ACGAACGTAA"]), dist=dist, device=torch.device("cpu"))
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, "fail%d.txt" % rank), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_a_failure_on_one_rank_raises_on_every_rank(tmp_path):
+    """the failing rank's status rides on the min-reduction: nobody is left blocked in a collective"""
+    mp.spawn(_worker_one_rank_fails, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert "phase 1 failed on another rank" in open(tmp_path / "fail0.txt").read()
+    assert "phase 1 failed on this rank" in open(tmp_path / "fail1.txt").read()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
