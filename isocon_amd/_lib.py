@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("ISOCON_LIB", os.path.join(_HERE, "lib", "libisocon_hip.so"))   # override: kernel experiments
 SRC_DIR = os.path.join(_HERE, "csrc")
 _SOURCES = ["isocon_hip.hip", "band_core.hpp", "common.hpp", "ed_band.hpp", "ed_full.hpp", "nn.hpp", "nn_host.inc",
-            "sg.hpp", "sg_host.inc", "msa.hpp", "msa_host.inc", "hw.hpp", "hw_host.inc"]
+            "sg.hpp", "sg_host.inc", "msa.hpp", "msa_host.inc", "hw.hpp", "hw_core.hpp", "hw_host.inc"]
 
 ISOCON_OK = 0
 ISOCON_E_CAPACITY = -4

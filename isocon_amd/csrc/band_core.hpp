@@ -151,6 +151,42 @@ ISO_HD void band_step_eq(BandLane<W> &L, const uint64_t (&EQ)[W])
     L.VN[W - 1] = d0s & hpp;
 }
 
+// The same column step that also hands out the horizontal "+1" vector HP of the column (bit r <-> window row r of THIS
+// column, i.e. before the slide) -- what a traceback needs next to the new VP (hw_core.hpp).
+template <int W>
+ISO_HD void band_step_eq_hp(BandLane<W> &L, const uint64_t (&EQ)[W], uint64_t (&HP)[W])
+{
+    uint64_t carry = 0, d0p = 0, hpp = 0, hnp = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint64_t eq = EQ[i];
+        const uint64_t vp = L.VP[i], vn = L.VN[i];
+        const uint64_t x = eq & vp;
+        uint64_t s = x + vp;
+        if (W > 1) {
+            uint64_t c = s < x;
+            const uint64_t s2 = s + carry;
+            c |= (s2 < s);
+            s = s2;
+            carry = c;
+        }
+        const uint64_t d0 = (s ^ vp) | eq | vn;
+        if (i == 0) L.ztop += (uint32_t)d0 & 1u;
+        if (i > 0) {
+            const uint64_t d0s = (d0p >> 1) | (d0 << 63);
+            L.VP[i - 1] = or_nor(hnp, d0s, hpp);
+            L.VN[i - 1] = d0s & hpp;
+        }
+        hpp = or_nor(vn, d0, vp);
+        HP[i] = hpp;
+        hnp = d0 & vp;
+        d0p = d0;
+    }
+    const uint64_t d0s = d0p >> 1;
+    L.VP[W - 1] = or_nor(hnp, d0s, hpp);
+    L.VN[W - 1] = d0s & hpp;
+}
+
 // One text column.  NL/NH = ~pattern bit-planes of the current window (wave-uniform), VM = valid-row mask
 // (only read when MASKED), slo/shi = text base bit-planes splat to 32 bits (0 or 0xffffffff).
 template <int W, bool MASKED>

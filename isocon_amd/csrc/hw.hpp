@@ -1,214 +1,227 @@
-// hw.hpp -- infix ("HW") edit distance with location and the terminal insertion runs of its path.
+// hw.hpp -- infix ("HW") edit distance with location and the terminal insertion runs of its path,
+// bit-parallel: device side of edlib.align(q, t, mode="HW", task="path", k) as consumed by the candidate-vs-candidate graph
+// of the statistical-test phase (/root/reference/modules/end_invariant_functions.py:593-620 edlib_traceback, :622-681
+// get_all_NN).  Lane-level math and the three passes (LOCATE, START, TRACE): hw_core.hpp.
 //
-// Device side of edlib.align(q, t, mode="HW", task="path", k) as consumed by the candidate-vs-candidate graph of the
-// statistical-test phase (/root/reference/modules/end_invariant_functions.py:593-620 edlib_traceback, :622-681
-// get_all_NN): the query is aligned globally inside the target (free target prefix and suffix); wanted are the
-// distance h (<= k), locations[0] = (start, end) and whether the path starts / ends with an insertion run (and how long).
-// k is small there (10 + ignore_ends_len) and the two lengths differ by at most 10 + 2*ignore_ends_len, so every path
-// of cost <= k stays inside a fixed set of diagonals:
-//   phase A  (distance, first end)    rows = query, top row all 0, diagonals j - i in [-k, (m - n) + k]
-//   phase B  (start of that end)      reversed query against reversed target[0..end], top row j, diagonals [-k, k];
-//                                     the LAST column of the final row that equals h gives the smallest start
-//   phase C  (path)                   query against target[start..end], diagonals [-k, k], two decision bits per cell
-//                                     (vertical step optimal / horizontal step optimal), then the walk from the end with
-//                                     edlib's order: query-only step ('I'), target-only step ('D'), diagonal.
-// One wavefront per pair; lane l of block b owns diagonal 64 b + l, rows are processed one at a time:
-//   a[d]   = min(prev[d] + (q_i != t_j), prev[d + 1] + 1)              (diagonal and vertical predecessor, one lane shift)
-//   cur[d] = min over d' <= d of a[d'] + (d - d')                       (horizontal runs: a prefix-min of a[d'] - d')
-// Integer work on 32-bit lanes; both sequences sit in LDS as one byte per base.  HBM traffic = the two packed sequences in
-// and 20 B out per pair (+ 16 B per row and block of decision bits for the pairs that reach phase C), so the kernel is
-// bound by the dependent chain of cross-lane operations per row (prefix-min: 7 DPP steps; shifts: DPP wave shifts), not by memory.
+// One wavefront = one TILE = one shared query (rows; its sliding 64 W-row window is wave-uniform and lives in SGPRs, slid by
+// the scalar unit) x up to 64 lane targets (columns; two text bits per lane and column).  The candidate graph asks for every
+// candidate against the ~1 200 candidates of its length window, so tiles are full; a column of 64 pairs costs ~45 W vector
+// instructions instead of the 64 W x 27 of the cell-per-lane kernel this replaces (5.77 M C3 pairs: 1.73 s -> see DESIGN.md).
+//   k_hw_locate<W>  pass LOCATE for all pairs            -> (h or -1, end) per pair
+//   k_hw_finish<W>  passes START and TRACE + the walk for the hits -> start, leading / trailing insertion run
+// HBM traffic: the packed sequences in, 8 + 20 B per pair out, and for the hits 16 W bytes per column and pair of stored
+// VP / HP vectors (written as 512-B lines, read back once by the walk).
 #pragma once
 #include "common.hpp"
+#include "hw_core.hpp"
 
 namespace isocon {
 
-static constexpr int32_t HW_INF = 1 << 24;
-static constexpr int32_t HW_TPAD = 1024;       // bytes around the target in LDS: > 64 * 8 diagonals + k + 2
-
-// Cross-lane moves as DPP modifiers (VALU, no LDS round trip): a lane that has no source keeps `old`.
-template <int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ int32_t hw_dpp(int32_t old, int32_t v)
+// the 32 text bits of positions p .. p + 31 of one plane of sequence `id` (p may be negative or run past the end: zeros)
+__device__ __forceinline__ uint32_t hw_text32(const uint32_t *__restrict__ pw, uint32_t nseq, uint32_t nchunks, uint32_t id, int plane, int32_t p)
 {
-    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, false);
-}
-__device__ __forceinline__ int32_t hw_min(int32_t a, int32_t b) { return a < b ? a : b; }
-
-// inclusive prefix-min over the 64 lanes: three single shifts inside the 16-lane rows, shifts by 4 and 8 for the upper
-// banks, then lane 15 / lane 31 broadcast into the following rows
-__device__ __forceinline__ int32_t hw_prefix_min(int32_t v)
-{
-    constexpr int32_t I = 0x7fffffff;
-    int32_t r = hw_min(v, hw_dpp<0x111, 0xf, 0xf>(I, v));                // row_shr:1
-    r = hw_min(r, hw_dpp<0x112, 0xf, 0xf>(I, v));                        // row_shr:2
-    r = hw_min(r, hw_dpp<0x113, 0xf, 0xf>(I, v));                        // row_shr:3
-    r = hw_min(r, hw_dpp<0x114, 0xf, 0xe>(I, r));                        // row_shr:4, banks 1-3
-    r = hw_min(r, hw_dpp<0x118, 0xf, 0xc>(I, r));                        // row_shr:8, banks 2-3
-    r = hw_min(r, hw_dpp<0x142, 0xa, 0xf>(I, r));                        // row_bcast:15 into rows 1 and 3
-    r = hw_min(r, hw_dpp<0x143, 0xc, 0xf>(I, r));                        // row_bcast:31 into rows 2 and 3
-    return r;
+    if (p <= -32) return 0;
+    const int32_t pp = p < 0 ? 0 : p;
+    const uint32_t d = (uint32_t)pp >> 5;
+    auto dword = [&](uint32_t dd) -> uint32_t {
+        const uint32_t c = dd >> 1;
+        return c < nchunks ? pw[(((size_t)c * nseq + id) * 2 + (uint32_t)plane) * 2 + (dd & 1u)] : 0u;
+    };
+    const uint32_t w0 = dword(d), w1 = dword(d + 1);
+    const uint32_t s = (uint32_t)pp & 31u;
+    const uint32_t v = __builtin_amdgcn_alignbit(w1, w0, s);
+    return p < 0 ? v << (uint32_t)(-p) : v;
 }
 
-// Rows 0..n of one banded matrix.  Cell (i, j): query base i (1-based; reversed order when qrev), target base j
-// (t0 + j - 1, or t0 - (j - 1) when trev), j in [0, m].  Diagonal index d = j - i + off.  cur[b] = last row on return.
-// TRACE: trace[(i * NB + b) * 2 + {0,1}] = ballots "vertical step optimal" / "horizontal step optimal" of row i.
-// EARLY: every 32 rows the smallest value of the row is compared with kstop -- row minima never decrease from one row to
-// the next, so once a row exceeds kstop no end cell can be <= kstop: returns false at once (cur is then meaningless).
-template <int NB, bool TRACE, bool EARLY>
-__device__ __forceinline__ bool hw_band_rows(const uint8_t *Q, int32_t n, bool qrev, const uint8_t *T, int32_t t0, bool trev, int32_t m,
-                                             int32_t off, bool topzero, uint64_t *trace, int lane, int32_t (&cur)[NB], int32_t kstop)
+struct HwTileIn {
+    const uint32_t *tile_q;      // query of every tile
+    const uint32_t *lane_pair;   // [tiles][64] pair index, 0xffffffff = empty lane
+    const uint32_t *pt;          // target of every pair
+    const int32_t *pk;           // threshold of every pair
+    uint32_t n_tiles;
+};
+
+// out_he[2 p] = distance (-1: above k, -3: the tile's band does not fit W words), out_he[2 p + 1] = end
+template <int W>
+__global__ __launch_bounds__(256) void k_hw_locate(DevStore S, HwTileIn in, int32_t *__restrict__ out_he)
 {
-    // No per-cell range checks in the loop: columns j < 0 start at "infinity" and stay there by themselves (all their
-    // predecessors are columns < 0, values are clamped), columns j > m hold junk that never reaches a column <= m
-    // (information only moves to the same or a larger column), and the callers read columns 1..m only.  T is padded on
-    // both sides (HW_TPAD bytes), so the base index t0 +- (j - 1) is always inside the buffer.
-    int32_t tix[NB];
-    const int32_t tdir = trev ? -1 : 1;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int32_t j = lane + 64 * b - off;
-        cur[b] = (j >= 0 && j <= m) ? (topzero ? 0 : j) : HW_INF;
-        tix[b] = t0 + tdir * j;                                          // cell (i, c) compares target base c - 1; row 1: c - 1 = d - off
-    }
-    int32_t qi = qrev ? n - 1 : 0;
-    const int32_t qdir = qrev ? -1 : 1;
-    for (int32_t i = 1; i <= n; ++i) {
-        const int32_t qc = Q[qi];                                       // wave-uniform LDS read
-        qi += qdir;
-        int32_t nw[NB];
-        int32_t run = HW_INF;                                           // min of a[d'] - d' over the blocks already done
-        int32_t left_in = HW_INF;                                       // new value of the last diagonal of the previous block
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int32_t d = lane + 64 * b;
-            const int32_t nxt0 = b + 1 < NB ? __builtin_amdgcn_readfirstlane(cur[b + 1 < NB ? b + 1 : b]) : HW_INF;
-            const int32_t up = hw_dpp<0x130, 0xf, 0xf>(nxt0, cur[b]);    // wave_shl:1: lane l takes lane l + 1, lane 63 keeps nxt0
-            const int32_t tc = T[tix[b]];
-            tix[b] += tdir;
-            const int32_t diag = cur[b] + (tc != qc ? 1 : 0);           // (i-1, j-1) is diagonal d of the previous row
-            const int32_t a = hw_min(hw_min(diag, up + 1), HW_INF);
-            const int32_t pm = hw_min(hw_prefix_min(a - d), run);
-            const int32_t v = hw_min(pm + d, HW_INF);
-            run = __builtin_amdgcn_readlane(pm, 63);
-            if (TRACE) {
-                const int32_t left = hw_dpp<0x138, 0xf, 0xf>(left_in, v);   // wave_shr:1: lane l takes lane l - 1, lane 0 keeps left_in
-                const uint64_t m_up = __ballot(up + 1 == v);
-                const uint64_t m_left = __ballot(left + 1 == v);
-                if (lane == 0) {
-                    trace[((size_t)i * NB + b) * 2] = m_up;
-                    trace[((size_t)i * NB + b) * 2 + 1] = m_left;
-                }
-                left_in = __builtin_amdgcn_readlane(v, 63);
-            }
-            nw[b] = v;
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) cur[b] = nw[b];
-        if (EARLY && (i & 31) == 0) {
-            int32_t rowmin = cur[0];
-#pragma unroll
-            for (int b = 1; b < NB; ++b) rowmin = hw_min(rowmin, cur[b]);
-            if (wave_min_i32(rowmin) > kstop) return false;            // wave-uniform (junk columns can only delay this)
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (tile >= in.n_tiles) return;
+    const uint32_t q = (uint32_t)uniform_i32((int32_t)in.tile_q[tile]);
+    const int32_t P = uniform_i32(S.lens[q]);
+    const uint32_t pair = in.lane_pair[(size_t)tile * 64 + lane];
+    const bool has = pair != 0xffffffffu;
+    const uint32_t tid = has ? in.pt[pair] : q;
+    const int32_t k = has ? in.pk[pair] : 0;
+    const int32_t m = S.lens[tid];
+    const bool valid = has && P > 0 && m > 0 && k >= 0 && m - P >= -k;
+    const int32_t dmax = uniform_i32(wave_max_i32(valid ? m - P : -(1 << 30)));
+    const int32_t kmax = uniform_i32(wave_max_i32(valid ? k : 0));
+    const int32_t mmax = uniform_i32(wave_max_i32(valid ? m : 0));
+    int32_t r_h = -1, r_end = -1;
+    if (dmax > -(1 << 30)) {
+        if (hw_locate_rows(dmax, kmax) > 64 * W) r_h = -3;
+        else {
+            HwTile T;
+            T.P = P; T.a0 = hw_locate_a0(dmax, kmax); T.ncols_max = mmax; T.jx = P - kmax > 1 ? P - kmax : 1;
+            HwLane ln;
+            ln.ncols = valid ? m : 0; ln.k = k; ln.h = 0;
+            const uint64_t *planes = S.planes;
+            const uint32_t nseq = S.n;
+            const int32_t nchunks = (int32_t)S.nchunks;
+            auto chunk_lo = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2] : 0; };
+            auto chunk_hi = [&](int32_t ci) -> uint64_t { return ci < nchunks ? planes[((size_t)ci * nseq + q) * 2 + 1] : 0; };
+            auto plo = [&](int32_t off) { return stream64(chunk_lo, off); };
+            auto phi = [&](int32_t off) { return stream64(chunk_hi, off); };
+            const ulonglong2 *P2 = reinterpret_cast<const ulonglong2 *>(planes);
+            ulonglong2 tcur = {0, 0};
+            auto text = [&](int32_t jb, uint32_t &wl, uint32_t &wh) {
+                if ((jb & 63) == 0) tcur = P2[(size_t)(jb >> 6) * nseq + tid];       // columns <-> target positions, 64 per load
+                wl = (uint32_t)((jb & 32) ? (tcur.x >> 32) : tcur.x);
+                wh = (uint32_t)((jb & 32) ? (tcur.y >> 32) : tcur.y);
+            };
+            auto any_live = [](bool live) { return __ballot(live) != 0; };
+            auto nosink = [](int32_t, int, uint64_t, uint64_t) {};
+            hw_run<W, HW_LOCATE>(T, ln, plo, phi, text, any_live, nosink);
+            if (valid && ln.r_h <= k) { r_h = ln.r_h; r_end = ln.r_end; }
         }
     }
-    return true;
+    if (has) { out_he[(size_t)pair * 2] = r_h; out_he[(size_t)pair * 2 + 1] = r_end; }
 }
 
-// out[5 p ..] = distance (-1: > k, -3: band does not fit), start, end, leading insertion run, trailing insertion run.
-// NBA blocks of 64 diagonals for phase A (max(len(t) - len(q), 0) + 2 k + 1 diagonals), NB for phases B and C (2 k + 1).
-// grid = any number of 64-thread blocks (pairs are dealt round-robin); trace: (maxlen + 1) * NB * 2 words per block;
-// dynamic LDS = 2 * lds_stride + 2 * HW_TPAD bytes (lds_stride >= maxlen, multiple of 8): query, pad, target, pad.
-template <int NBA, int NB>
-__global__ __launch_bounds__(64) void k_hw_path(DevStore S, const uint32_t *__restrict__ pq, const uint32_t *__restrict__ pt, const int32_t *__restrict__ pk,
-                                                 uint32_t n_pairs, uint64_t *__restrict__ trace_all, uint32_t trace_rows,
-                                                 uint32_t lds_stride, int32_t *__restrict__ out)
+// Hits only: he[2 p] = h, he[2 p + 1] = end.  out[5 p ..] = h, start, end, leading insertion run, trailing insertion run
+// (h < -1: internal status).  grid = any number of 64-thread blocks (tiles are dealt round-robin); trace: per block
+// (trace_cols + 1) x 2 W x 64 words.
+template <int W>
+__global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const int32_t *__restrict__ he, uint64_t *__restrict__ trace_all,
+                                                   uint32_t trace_cols, int32_t *__restrict__ out)
 {
-    extern __shared__ uint8_t hw_lds[];
-    uint8_t *Q = hw_lds, *T = hw_lds + lds_stride + HW_TPAD;
     const int lane = threadIdx.x;
-    uint64_t *trace = trace_all + (size_t)blockIdx.x * trace_rows * NB * 2;
+    uint64_t *trace = trace_all + (size_t)blockIdx.x * ((size_t)trace_cols + 1) * 2 * W * 64;
     const uint64_t *planes = S.planes;
+    const uint32_t *pw = reinterpret_cast<const uint32_t *>(planes);
     const uint32_t nseq = S.n;
-    // pairs are dealt round-robin: blockIdx.x, blockIdx.x + gridDim.x, ... (the loop variable lives in an SGPR, every
-    // branch below is wave-uniform by construction)
-    for (uint32_t pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-        const uint32_t iq = pq[pair], it = pt[pair];
-        const int32_t n = uniform_i32(S.lens[iq]), m = uniform_i32(S.lens[it]);
-        const int32_t k = uniform_i32(pk[pair]);
-        int32_t r_h = -1, r_start = -1, r_end = -1, r_lead = 0, r_trail = 0;
-        const int32_t delta = m - n;
-        const int32_t width_a = delta + 2 * k + 1, width_b = 2 * k + 1;
-        if (n > 0 && m > 0 && k >= 0 && delta >= -k) {
-            if (width_a > 64 * NBA || width_b > 64 * NB || n + 1 > (int32_t)trace_rows || n > (int32_t)lds_stride || m > (int32_t)lds_stride) r_h = -3;
-            else {
-                __syncthreads();                                        // previous pair's readers are done with the LDS
-                for (int32_t x = lane; x < n; x += 64) {
-                    const uint64_t lo = planes[((size_t)(x >> 6) * nseq + iq) * 2], hi = planes[((size_t)(x >> 6) * nseq + iq) * 2 + 1];
-                    Q[x] = (uint8_t)(((lo >> (x & 63)) & 1) | (((hi >> (x & 63)) & 1) << 1));
-                }
-                for (int32_t x = lane; x < m; x += 64) {
-                    const uint64_t lo = planes[((size_t)(x >> 6) * nseq + it) * 2], hi = planes[((size_t)(x >> 6) * nseq + it) * 2 + 1];
-                    T[x] = (uint8_t)(((lo >> (x & 63)) & 1) | (((hi >> (x & 63)) & 1) << 1));
-                }
-                __syncthreads();
-                int32_t cur_a[NBA], cur[NB];
-                // phase A: distance and first end column
-                const bool alive = hw_band_rows<NBA, false, true>(Q, n, false, T, 0, false, m, k, true, nullptr, lane, cur_a, k);
-                int32_t h = HW_INF;
-#pragma unroll
-                for (int b = 0; b < NBA; ++b) {
-                    const int32_t j = n + lane + 64 * b - k;
-                    if (alive && j >= 1 && j <= m && cur_a[b] < h) h = cur_a[b];
-                }
-                h = wave_min_i32(h);
-                if (h <= k) {
-                    int32_t e = HW_INF;
-#pragma unroll
-                    for (int b = 0; b < NBA; ++b) {
-                        const int32_t j = n + lane + 64 * b - k;
-                        if (j >= 1 && j <= m && cur_a[b] == h && j < e) e = j;
+    const int32_t nchunks = (int32_t)S.nchunks;
+    for (uint32_t tile = blockIdx.x; tile < in.n_tiles; tile += gridDim.x) {
+        const uint32_t q = (uint32_t)uniform_i32((int32_t)in.tile_q[tile]);
+        const int32_t P = uniform_i32(S.lens[q]);
+        const uint32_t pair = in.lane_pair[(size_t)tile * 64 + lane];
+        const bool has = pair != 0xffffffffu;
+        const uint32_t tid = has ? in.pt[pair] : q;
+        const int32_t k = has ? in.pk[pair] : 0;
+        const int32_t h = has ? he[(size_t)pair * 2] : -1;
+        const int32_t end = has ? he[(size_t)pair * 2 + 1] : -1;
+        const bool valid = has && h >= 0 && end >= 0;
+        const int32_t kmax = uniform_i32(wave_max_i32(valid ? k : 0));
+        int32_t r0 = valid ? h : -1, r_start = -1, r_lead = 0, r_trail = 0;
+        auto chunk_lo = [&](int32_t ci) -> uint64_t { return ci >= 0 && ci < nchunks ? planes[((size_t)ci * nseq + q) * 2] : 0; };
+        auto chunk_hi = [&](int32_t ci) -> uint64_t { return ci >= 0 && ci < nchunks ? planes[((size_t)ci * nseq + q) * 2 + 1] : 0; };
+        auto any_live = [](bool live) { return __ballot(live) != 0; };
+        auto nosink = [](int32_t, int, uint64_t, uint64_t) {};
+        if (2 * kmax + 1 > 64 * W) r0 = valid ? -3 : r0;
+        else if (__ballot(valid) != 0) {
+            // ---- START: reversed query against the reversed prefix t[0..end] ----
+            HwTile T;
+            T.P = P; T.a0 = -kmax; T.jx = P - kmax > 1 ? P - kmax : 1;
+            HwLane ln;
+            int32_t nc = end + 1 < P + kmax ? end + 1 : P + kmax;
+            ln.ncols = valid ? nc : 0; ln.k = k; ln.h = h;
+            T.ncols_max = uniform_i32(wave_max_i32(ln.ncols));
+            {
+                auto plo = [&](int32_t off) { return stream64_rev(chunk_lo, P, off); };
+                auto phi = [&](int32_t off) { return stream64_rev(chunk_hi, P, off); };
+                auto text = [&](int32_t jb, uint32_t &wl, uint32_t &wh) {       // column c <-> target position end - c
+                    const int32_t p0 = end - jb - 31;
+                    wl = __builtin_bitreverse32(hw_text32(pw, nseq, (uint32_t)nchunks, tid, 0, p0));
+                    wh = __builtin_bitreverse32(hw_text32(pw, nseq, (uint32_t)nchunks, tid, 1, p0));
+                };
+                hw_run<W, HW_START>(T, ln, plo, phi, text, any_live, nosink);
+            }
+            const bool ok = valid && ln.r_pl >= 1;
+            if (valid && !ok) r0 = -4;
+            const int32_t start = ok ? end - (ln.r_pl - 1) : 0;
+            const int32_t ms = ok ? end - start + 1 : 0;
+            // ---- TRACE: query against t[start..end], the columns' VP / HP vectors stored ----
+            ln.ncols = ok && ms <= (int32_t)trace_cols ? ms : 0;
+            if (ok && ms > (int32_t)trace_cols) r0 = -7;
+            T.ncols_max = uniform_i32(wave_max_i32(ln.ncols));
+            T.jx = 1;
+            {
+                auto plo = [&](int32_t off) { return stream64(chunk_lo, off); };
+                auto phi = [&](int32_t off) { return stream64(chunk_hi, off); };
+                auto text = [&](int32_t jb, uint32_t &wl, uint32_t &wh) {       // column c <-> target position start + c
+                    wl = hw_text32(pw, nseq, (uint32_t)nchunks, tid, 0, start + jb);
+                    wh = hw_text32(pw, nseq, (uint32_t)nchunks, tid, 1, start + jb);
+                };
+                // A path that begins with a query-only step could trade it for a diagonal step into t[start - 1] at no extra cost,
+                // so with the SMALLEST start of distance h only start == 0 can have a leading insertion run: every other lane
+                // needs neither the stored columns nor the walk (the trailing run is read off the last column).
+                auto sink = [&](int32_t j, int w, uint64_t vp, uint64_t hp) {
+                    if (start == 0) {
+                        trace[(((size_t)j * 2) * W + w) * 64 + lane] = vp;
+                        trace[(((size_t)j * 2 + 1) * W + w) * 64 + lane] = hp;
                     }
-                    const int32_t end = wave_min_i32(e) - 1;
-                    // phase B: smallest start whose global distance to target[start..end] is h
-                    hw_band_rows<NB, false, false>(Q, n, true, T, end, true, end + 1, k, false, nullptr, lane, cur, k);
-                    int32_t pl = -1;
+                };
+                hw_run<W, HW_TRACE>(T, ln, plo, phi, text, any_live, sink);
+            }
+            if (ln.ncols > 0) {
+                if (ln.r_final != h) r0 = -5;
+                else {
+                    r_trail = ln.r_trail;
+                    r_start = start;
+                }
+            }
+            // ---- the walk: every lane reads back its OWN stores (same thread, same addresses: program order suffices, no cache
+            // maintenance); columns are visited in descending order, so the words of the next PF columns are requested
+            // together, on the assumption that the path keeps its diagonal.  Measured at C3's candidate graph (2.4 M hits):
+            // the two passes 15 ms, the column stores +22 ms, the walk +18 ms -- both are HBM traffic (16 B per column and hit).
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (ln.ncols > 0 && r0 >= 0 && start == 0) {
+                constexpr int PF = W <= 2 ? 8 : 2;
+                auto ld = [&](int32_t jj, int which, int w) -> uint64_t { return trace[(((size_t)jj * 2 + which) * W + w) * 64 + lane]; };
+                int32_t i = P, j = ms;
+                bool bad = false;
+                while (i > 0 && j > 0 && !bad) {
+                    const int32_t hb0 = i - T.a0 - j, vb0 = hb0 - 1;
+                    if (hb0 < 0 || hb0 >= 64 * W) { bad = true; break; }
+                    uint64_t pv[PF], ph[PF];
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const int32_t j = n + lane + 64 * b - k;
-                        if (j >= 1 && j <= end + 1 && cur[b] == h && j > pl) pl = j;
+                    for (int c = 0; c < PF; ++c) {
+                        const int32_t jj = j - c;
+                        pv[c] = (jj >= 1 && vb0 >= 0) ? ld(jj, 0, vb0 >> 6) : 0;
+                        ph[c] = jj >= 1 ? ld(jj, 1, hb0 >> 6) : 0;
                     }
-                    pl = wave_max_i32(pl);
-                    if (pl < 1) r_h = -4;                               // cannot happen (the optimum is attained by some start)
-                    else {
-                        const int32_t start = end - (pl - 1), ms = pl;
-                        // phase C: decision bits of the global alignment query vs target[start..end], then the walk
-                        hw_band_rows<NB, true, false>(Q, n, false, T, start, false, ms, k, false, trace, lane, cur, k);
-                        // the walk: every lane follows the same cells (uniform addresses, one broadcast load per step)
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // lane 0's decision words, read by all lanes
-                        int32_t trail = 0;
-                        int32_t i = n, j = ms;
-                        bool at_end = true;
-                        while (i > 0 && j > 0) {
-                            const int32_t d = j - i + k;
-                            const size_t w = ((size_t)i * NB + (size_t)(d >> 6)) * 2;
-                            const uint64_t mu = __hip_atomic_load(trace + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const uint64_t ml = __hip_atomic_load(trace + w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((mu >> (d & 63)) & 1) { --i; if (at_end) ++trail; }
-                            else {
-                                at_end = false;
-                                if ((ml >> (d & 63)) & 1) --j;
+                    const int32_t j0 = j;
+#pragma unroll
+                    for (int c = 0; c < PF; ++c) {
+                        if (i > 0 && j > 0 && j == j0 - c && !bad) {
+                            for (;;) {                                        // query-only steps stay in the column
+                                const int32_t hb = i - T.a0 - j, vb = hb - 1;
+                                if (hb < 0 || hb >= 64 * W) { bad = true; break; }
+                                const uint64_t wv = hb == hb0 ? pv[c] : (vb >= 0 ? ld(j, 0, vb >> 6) : 0);
+                                if (vb >= 0 && ((wv >> (vb & 63)) & 1)) {
+                                    --i;
+                                    if (i == 0) break;
+                                    continue;
+                                }
+                                const uint64_t wh2 = hb == hb0 ? ph[c] : ld(j, 1, hb >> 6);
+                                if ((wh2 >> (hb & 63)) & 1) --j;
                                 else { --i; --j; }
+                                break;
                             }
                         }
-                        r_h = h; r_start = start; r_end = end;
-                        r_lead = j == 0 ? i : 0;
-                        r_trail = trail;
                     }
                 }
+                if (bad) r0 = -6;
+                else r_lead = j == 0 ? i : 0;
             }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (compiler) the next tile's stores stay behind these loads
         }
-        if (lane == 0) {
+        if (has) {
             int32_t *o = out + (size_t)pair * 5;
-            o[0] = r_h; o[1] = r_start; o[2] = r_end; o[3] = r_lead; o[4] = r_trail;
+            const bool fine = r0 >= 0;
+            o[0] = r0; o[1] = fine ? r_start : -1; o[2] = fine ? end : -1; o[3] = fine ? r_lead : 0; o[4] = fine ? r_trail : 0;
         }
     }
 }
