@@ -29,6 +29,11 @@ struct NNParams {
     int32_t kcap;
     int32_t min_d;                 // 1: only positive distances admitted (1-set, NNG:157), 0: 2-set (NNG:388)
     uint32_t depth;                // largest admissible sorted-order offset (NNG:190)
+    // k_nn_scan_refill, few queries ("sparse" launch): one workgroup per LISTED query, which takes its neighbours on BOTH
+    // sides (a listed neighbour below it keeps the pair for its own workgroup); of those pairs a rank evaluates the ones
+    // whose lower index it owns (own_begin + i * own_stride).  q_list == nullptr: one workgroup per entry, upward scan.
+    const uint32_t *q_list;
+    uint32_t own_begin, own_stride;
 };
 
 __device__ __forceinline__ void nn_append(const NNParams &P, bool want, int32_t e, int32_t o, int32_t d)
@@ -259,21 +264,29 @@ template <int NWAVES, int W>
 __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNParams P, const uint32_t *__restrict__ text, uint32_t text_stride,
                                                                       uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t tile_begin)
 {
-    static_assert(W == 1 || W == 2 || W == 4 || W == 8, "band widths");
+    static_assert(W >= 1 && W <= 8, "band widths: 64 .. 512 rows");
     constexpr int ROWS = 64 * W;
-    constexpr int UNROLL_COLS = W == 8 ? 1 : 8;
+    constexpr int UNROLL_COLS = W >= 5 ? 1 : 8;      // 5 words and more: a real loop (VGPRs, instruction cache)
     extern __shared__ uint32_t tw[];
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_ring[NWAVES][NN_RING][2];
     typedef __attribute__((address_space(3))) const uint32_t lds_u32;
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
-    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)blockIdx.x * q_stride;
+    const bool sparse = P.q_list != nullptr;
+    const uint64_t q64 = sparse ? (uint64_t)P.q_list[blockIdx.x] : (uint64_t)q_begin + (uint64_t)blockIdx.x * q_stride;
     if (q64 >= (uint64_t)q_end) return;
     const uint32_t q = (uint32_t)q64;
     const int32_t m = S.lens[q];
-    const int64_t pbase = (int64_t)q + 1 + (int64_t)tile_begin * 64;
-    if (pbase >= (int64_t)S.n || pbase - (int64_t)q > (int64_t)P.depth || S.lens[pbase] - m > P.kcap) return;   // uniform
+    int64_t pbase = (int64_t)q + 1 + (int64_t)tile_begin * 64;
+    if (sparse) {           // first entry whose length is within kcap below (lengths ascend): wave-uniform binary search
+        uint32_t lo = 0, hi = q;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (uniform_i32(S.lens[mid]) < m - P.kcap) lo = mid + 1; else hi = mid;
+        }
+        pbase = lo;
+    } else if (pbase >= (int64_t)S.n || pbase - (int64_t)q > (int64_t)P.depth || S.lens[pbase] - m > P.kcap) return;   // uniform
     const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
     if (!q_isq && !q_ist) return;
     const int32_t E = (m + 192 * W + 31) & ~31;          // plane length in dwords
@@ -342,11 +355,21 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
             if (lane == 0) c0 = atomicAdd(&s_next, 64u);
             c0 = (uint32_t)uniform_i32((int32_t)c0);
             const int64_t p = pbase + (int64_t)c0 + lane;
-            const bool inr = p < (int64_t)S.n && p - (int64_t)q <= (int64_t)P.depth;
+            const int64_t off = p > (int64_t)q ? p - (int64_t)q : (int64_t)q - p;
+            const bool inr = p < (int64_t)S.n && (off <= (int64_t)P.depth || (sparse && p < (int64_t)q));
             const uint32_t pid = inr ? (uint32_t)p : q;
             const int32_t np = S.lens[pid];
-            const bool within = inr && np - m <= P.kcap;
+            bool within = inr && np - m <= P.kcap;
             if (__ballot(within) != ~(uint64_t)0) exhausted = true;
+            if (sparse) {
+                // entries below q that are too far in the order (depth) are skipped, not the end of the window; the pair
+                // belongs to this workgroup unless the neighbour is a listed query below q, and to this rank if it owns
+                // the pair's lower index
+                const uint32_t lowi = pid < q ? pid : q;
+                const bool mine = pid != q && off <= (int64_t)P.depth && (pid > q || P.qflag[pid] == 0) &&
+                                  lowi >= P.own_begin && (lowi - P.own_begin) % P.own_stride == 0;
+                within = within && mine;
+            }
             const bool us = within && q_isq && P.tflag[pid];
             const bool ul = within && q_ist && P.qflag[pid];
             int32_t bs = NN_INF;
@@ -445,7 +468,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                 for (int u = 0; u < 8; ++u) {
                     const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(w0, 4 * u, 3);
                     uint64_t EQ[W];
-                    if (W == 8) fetch(__umul24(code, plane_bytes) + a_blk + (uint32_t)u * 4u, 0, EQ);
+                    if (UNROLL_COLS == 1) fetch(__umul24(code, plane_bytes) + a_blk + (uint32_t)u * 4u, 0, EQ);
                     else fetch(__umul24(code, plane_bytes) + a_blk, u, EQ);
                     band_step_eq<W>(L, EQ);
                 }
