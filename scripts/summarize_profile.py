@@ -42,7 +42,18 @@ def classify(rows):
     """dispatch classes bench.py reports: first main pass, first seed pass, the two 4096-pair SW batches, the two infix batches"""
     cls = {}
     sg = [r for r in rows if "k_sg_forward" in r[1] and r[2] == 4096 * 64]
-    hw = [r for r in rows if "k_hw" in r[1] and r[2] >= 4096 * 64]
+    # isocon_hw_pairs = k_hw_locate launches (one per band class) followed by k_hw_finish launches: a call starts at the first
+    # locate after a finish; the 64-pair warm-up call (grids of at most 64 tiles) is dropped
+    calls, prev = [], "finish"
+    for r in rows:
+        if "k_hw_" not in r[1] or r[2] <= 4096:
+            continue
+        kind = "locate" if "locate" in r[1] else "finish"
+        if kind == "locate" and prev == "finish":
+            calls.append([])
+        if calls:
+            calls[-1].append(r)
+        prev = kind
     for r in rows:
         if "k_nn_scan_refill" in r[1] and "nn_main" not in cls:
             cls["nn_main"] = [r]
@@ -50,10 +61,8 @@ def classify(rows):
             cls["nn_seed"] = [r]
     if len(sg) >= 2:
         cls["sg_full"], cls["sg_banded"] = [sg[0]], [sg[1]]
-    # one isocon_hw_pairs call may be several launches (phases / classes): split the launches of the two 4096-pair calls in half
-    if len(hw) >= 2:
-        half = len(hw) // 2
-        cls["hw_k25"], cls["hw_k63"] = hw[:half], hw[half:2 * half]
+    if len(calls) >= 2:
+        cls["hw_k25"], cls["hw_k63"] = calls[0], calls[1]
     return cls
 
 

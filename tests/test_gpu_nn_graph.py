@@ -201,3 +201,47 @@ def test_2set_with_many_candidates_takes_the_scan_kernel():
     g_gpu = NNG.compute_2set_nearest_neighbor_graph(X, C, Params(1))
     g_cpu = O.compute_2set_nearest_neighbor_graph(X, C, Params(1))
     assert ordered(g_gpu) == ordered(g_cpu)
+
+
+@pytest.mark.parametrize("first_w", [3, 5, 6, 7])
+def test_every_band_width_in_steps_of_64_rows(first_w, monkeypatch):
+    """192-, 320-, 384- and 448-row lane-refill kernels (k_nn_scan_refill<16, 3|5|6|7>) forced as the first stage on reads
+    whose nearest neighbours lie 70 .. 500 edits away: queries beyond the forced band go on to 512 rows; same graph as the
+    reference loop whatever the first width."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    monkeypatch.setenv("ISOCON_NN_FIRST_W", str(first_w))
+    seqs = []
+    for length, rate, seed in ((900, 0.07, 1), (1800, 0.07, 2), (2600, 0.08, 3)):
+        accs, s, _ = synth.make_reads(90, length, 2, seed=seed, profile=dict(synth.ONT_PROFILE, rate=rate))
+        seqs += s
+    S = {"r%d" % i: s for i, s in enumerate(seqs)}
+    g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert ordered(g_gpu) == ordered(g_cpu)
+    d = sorted(v for nb in g_cpu.values() for v in nb.values())
+    assert d[0] > 63 and d[len(d) // 4] <= 64 * first_w - 1 and d[-1] > 191      # the forced band resolves some queries; 192 rows not all
+
+
+def test_sample_stage_and_one_workgroup_per_query_launches(monkeypatch):
+    """Enough unresolved queries (>= 2048) for the sampled width selection, few enough leftovers for the launches with one
+    workgroup per listed query (both directions): the graph equals the one of the plain launches, and sampled rows equal
+    the reference loop."""
+    from isocon_amd import synth
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    accs, seqs, _ = synth.make_reads(2600, 900, 3, seed=77, profile=dict(synth.ONT_PROFILE, rate=0.07))
+    seqs = sorted(dict.fromkeys(seqs), key=len)
+    st = SeqStore(seqs)
+    best, row_ptr, cols, stats = st.nn_graph()
+    assert stats["fallback_queries"] >= 2048
+    monkeypatch.setenv("ISOCON_NN_NO_SPARSE", "1")
+    b2, r2, c2, _ = st.nn_graph()
+    assert (b2 == best).all() and (r2 == row_ptr).all() and (c2 == cols).all()
+    packed = O.pack(seqs)
+    conv = np.zeros(len(seqs), np.uint8)
+    for i in np.random.default_rng(5).choice(len(seqs), 40, replace=False).tolist():
+        rp, c, e, _ = O.nn_1set(seqs, conv, i, 1, packed=packed)
+        assert cols[row_ptr[i]:row_ptr[i + 1]].tolist() == c.tolist() and (e == best[i]).all(), i
+    st.close()
