@@ -410,6 +410,27 @@ def other_kernels(store, seqs, lens, last, true_isoforms, ctr):
     store.hw_pairs(t[:64], q[:64], 25)
     hw25, hw25_ms = store.hw_pairs(t, q, 25, return_ms=True)
     hw63, hw63_ms = store.hw_pairs(t, q, 63, return_ms=True)
+    # the shape isocon_hw_pairs is built for: the candidate-vs-candidate graph of the statistical test (get_all_NN,
+    # end_invariant_functions.py:622-681) -- ~4 900 near-identical candidates of the 10 isoforms (a few residual errors, ragged
+    # ends), every candidate against its length window 10 + 2 x 15, k = 25: millions of pairs, full tiles
+    from isocon_amd import end_invariant_functions as END
+    from isocon_amd import synth
+    grng = np.random.Generator(np.random.PCG64(77))
+    cset = set()
+    for iso in true_isoforms:
+        arr = np.frombuffer(iso.encode("ascii"), dtype=np.uint8)
+        for _ in range(490):
+            v = synth.mutate(grng, arr, dict(rate=0.0012, ins=0.4, dele=0.4, sub=0.2))
+            a, b = int(grng.integers(0, 12)), int(grng.integers(0, 12))
+            cset.add(v[a:len(v) - b].tobytes().decode())
+    cseqs = sorted(cset, key=len)
+    clens = np.fromiter((len(x) for x in cseqs), dtype=np.int64, count=len(cseqs))
+    gq, gt = END._window_pairs(clens, 0, len(cseqs), 40, 2 ** 32)
+    stg = SeqStore(cseqs)
+    gk = np.full(len(gq), 25, dtype=np.int32)
+    stg.hw_pairs(gq[:4096], gt[:4096], gk[:4096])
+    t0 = time.perf_counter(); gres, g_ms = stg.hw_pairs(gq, gt, gk, return_ms=True); g_wall = time.perf_counter() - t0
+    stg.close()
     # the read -> candidate (2-set) search of the pipeline's last steps: all reads against the true isoforms
     cands = [c for c in dict.fromkeys(true_isoforms) if c not in set(seqs)]
     merged = sorted([(s, 0) for s in seqs] + [(c, 1) for c in cands], key=lambda x: len(x[0]))
@@ -435,7 +456,10 @@ def other_kernels(store, seqs, lens, last, true_isoforms, ctr):
         "sw_full": dict(kernel="k_sg_forward (4096 pairs, full matrix)", kernel_ms=sw_ms, **_fracs(ctr, "sg_full", sw_ms)),
         "sw_banded": dict(kernel="k_sg_forward (4096 pairs, edit-distance band hints)", kernel_ms=swb_ms, **_fracs(ctr, "sg_banded", swb_ms)),
         "hw_k25": dict(kernel="infix kernel, 4096 pairs, k = 25", kernel_ms=hw25_ms, **_fracs(ctr, "hw_k25", hw25_ms)),
-        "hw_k63": dict(kernel="infix kernel, 4096 pairs, k = 63", kernel_ms=hw63_ms, **_fracs(ctr, "hw_k63", hw63_ms))}
+        "hw_k63": dict(kernel="infix kernel, 4096 pairs, k = 63", kernel_ms=hw63_ms, **_fracs(ctr, "hw_k63", hw63_ms)),
+        "hw_graph": dict(kernel="k_hw_locate + k_hw_finish, candidate-vs-candidate graph (%d candidates, k = 25)" % len(cseqs), pairs=int(len(gq)),
+                         hits=int((gres[:, 0] >= 0).sum()), wall_ms=g_wall * 1e3, kernel_ms=g_ms, pairs_per_s_kernel=len(gq) / (g_ms / 1e3) if g_ms > 0 else None,
+                         pairs_per_s_wall=len(gq) / g_wall, **_fracs(ctr, "hw_graph", g_ms))}
     return out
 
 

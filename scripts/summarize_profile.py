@@ -43,10 +43,10 @@ def classify(rows):
     cls = {}
     sg = [r for r in rows if "k_sg_forward" in r[1] and r[2] == 4096 * 64]
     # isocon_hw_pairs = k_hw_locate launches (one per band class) followed by k_hw_finish launches: a call starts at the first
-    # locate after a finish; the 64-pair warm-up call (grids of at most 64 tiles) is dropped
+    # locate after a finish; bench.py's first call is its 64-pair warm-up
     calls, prev = [], "finish"
     for r in rows:
-        if "k_hw_" not in r[1] or r[2] <= 4096:
+        if "k_hw_" not in r[1]:
             continue
         kind = "locate" if "locate" in r[1] else "finish"
         if kind == "locate" and prev == "finish":
@@ -61,8 +61,10 @@ def classify(rows):
             cls["nn_seed"] = [r]
     if len(sg) >= 2:
         cls["sg_full"], cls["sg_banded"] = [sg[0]], [sg[1]]
-    if len(calls) >= 2:
-        cls["hw_k25"], cls["hw_k63"] = calls[0], calls[1]
+    if len(calls) >= 3:
+        cls["hw_k25"], cls["hw_k63"] = calls[1], calls[2]
+    if len(calls) >= 5:
+        cls["hw_graph"] = calls[4]         # (calls[3] = the graph's own 4096-pair warm-up)
     return cls
 
 
