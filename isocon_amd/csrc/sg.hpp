@@ -11,6 +11,7 @@
 // 32*R-byte block (coalesced HBM writes; this kernel is HBM-write bound: ~ m*n/2 bytes per pair).
 // Walk kernel: one thread per pair follows the codes back from the end cell and emits run-length CIGAR ops.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace isocon {
@@ -43,7 +44,11 @@ struct SgPair {            // per pair of the batch
     uint64_t bound_off;    // first int2 of this pair's pass-boundary row (capacity n)
     int32_t dhi;
     int32_t steps;         // steps per pass (window columns + 63), the same for every pass of the pair
+    int32_t mode;          // 0: strips of 512 query rows (k_sg_forward); 1: the band's diagonals on the lanes (k_sg_band)
+    int32_t pad_;
 };
+
+static constexpr int SG_BAND_DIAGS = 256;      // k_sg_band: 64 lanes x 4 diagonals
 
 // Column window of one pass (64*R query rows starting at prow0) for the band [dlo, dhi]: every cell of the band lies
 // inside, the window starts on a multiple of 64 (text chunks) at least one column left of the band.  Cells of the
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
     const uint32_t pidx = blockIdx.x;
     const int lane = threadIdx.x;
     const SgPair pr = pairs[pidx];
+    if (uniform_i32(pr.mode) != 0) return;          // the pair belongs to k_sg_band
     const uint32_t ia = (uint32_t)uniform_i32((int32_t)pr.a), ib = (uint32_t)uniform_i32((int32_t)pr.b);
     const int32_t m = uniform_i32(S.lens[ia]), n = uniform_i32(S.lens[ib]);
     const int32_t match = prm.match, mism = uniform_i32(pr.mismatch), open = prm.open, ext = prm.ext;
@@ -279,6 +285,201 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
     }
 }
 
+// Forward pass for pairs with a certified band of at most 256 diagonals (SW_alignment_module hands the pairs' edit distances
+// down: ed = 25 at 2.5 kb means +-77 diagonals).  The strip kernel above computes such a band as 512-row strips of
+// 512 + band + 64 columns -- 5x the cells of the band -- because a diagonal band offers only `band` cells of parallelism at
+// any time.  Here the band's DIAGONALS sit on the lanes (lane l: diagonals dlo + 4 l .. + 3) and the wavefront sweeps the
+// anti-diagonals a = i + j: a diagonal d has a cell on a iff a = d (mod 2), so every step updates two of a lane's four cells.
+// Predecessors: diagonal (i-1, j-1) = the same slot two steps ago; up (i-1, j) = slot + 1 and left (i, j-1) = slot - 1, both
+// one step ago -- in the lane, or one DPP wave shift away (slot 0 <- lane - 1's slot 3, slot 3 <- lane + 1's slot 0).  A
+// slot that has not reached the matrix yet holds H = 0, E = F = -inf, which IS the free boundary row / column its
+// neighbours read; beyond the two outermost diagonals lies -inf (0 where that cell is the boundary row / column).
+// Match bits: per slot a 64-cell mask ~(q ^ t) of its diagonal, refilled every 128 steps (per-lane unaligned plane fetches).
+// Trace: the two nibbles of a step form a byte, four steps a dword: ((a >> 2) * 64 + lane) * 4 bytes -- one 256-B line per
+// four steps, (m + n) * 64 bytes per pair instead of ~ m * (512 + band) / 2.
+template <bool POL0, bool EXT0>
+__global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__restrict__ pairs, SgParams prm,
+                                                   uint8_t *__restrict__ trace, int32_t *__restrict__ endinfo)
+{
+    const uint32_t pidx = blockIdx.x;
+    const int lane = threadIdx.x;
+    const SgPair pr = pairs[pidx];
+    if (uniform_i32(pr.mode) != 1) return;
+    const uint32_t ia = (uint32_t)uniform_i32((int32_t)pr.a), ib = (uint32_t)uniform_i32((int32_t)pr.b);
+    const int32_t m = uniform_i32(S.lens[ia]), n = uniform_i32(S.lens[ib]);
+    const int32_t match = prm.match, mism = uniform_i32(pr.mismatch), open = prm.open, ext = prm.ext;
+    const int32_t policy = prm.policy;
+    const int32_t c_open = (policy & SG_POL_OPEN_ON_TIE) ? 1 : 0, c_gap = (policy & SG_POL_GAP_FIRST) ? 1 : 0, c_ef = (policy & SG_POL_E_BEFORE_F) ? 1 : 0;
+    int32_t open_v, ext_v, mism_v, delta_v, c_open_v, c_gap_v, c_ef_v;      // per-cell constants in VGPRs (issue cost, see k_sg_forward)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(open_v) : "s"(open));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ext_v) : "s"(ext));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(mism_v) : "s"(mism));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(delta_v) : "s"(match - mism));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c_open_v) : "s"(c_open));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c_gap_v) : "s"(c_gap));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c_ef_v) : "s"(c_ef));
+    const uint64_t *planes = S.planes;
+    const uint32_t nseq = S.n;
+    const int32_t nchunks = (int32_t)S.nchunks;
+    uint32_t *tw_base = reinterpret_cast<uint32_t *>(trace + pr.trace_off);
+    const int32_t dlo = uniform_i32(pr.dlo);
+    const int32_t d0 = dlo + 4 * lane;
+    int32_t H[4], E[4], F[4];
+    uint32_t Mlo[4], Mhi[4], Mcur[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { H[s] = 0; E[s] = SG_NEG; F[s] = SG_NEG; Mlo[s] = Mhi[s] = Mcur[s] = 0; }
+    int32_t rowbest = SG_NEG, rowj_first = -1, rowj_last = -1;      // last query row, over this lane's columns (ascending)
+    int32_t colbest = SG_NEG, coli_first = -1, coli_last = -1;      // last ref column, over this lane's rows (ascending)
+    const int32_t a_end = m + n - 2;
+    const int32_t row_from = 2 * (m - 1) + dlo, col_from = 2 * (n - 1) - dlo - (SG_BAND_DIAGS - 1);
+    // steps at which EVERY lane's two cells lie inside the matrix and off its last row / column: no range checks there
+    const int32_t dtop = dlo + SG_BAND_DIAGS - 1;
+    const int32_t in_from = (dtop > -dlo ? dtop : -dlo) + 1;
+    const int32_t in_to = (2 * (m - 1) + dlo < 2 * (n - 1) - dtop ? 2 * (m - 1) + dlo : 2 * (n - 1) - dtop) - 1;      // inclusive
+    uint32_t tw = 0;
+
+    // one cell of the recurrences; the 4 decision sign bits come back in t_f, t_e, t_g, t_x
+    auto core = [&](int32_t &Hs, int32_t &Es, int32_t &Fs, int32_t Hup, int32_t Fup, int32_t Hl, int32_t El, uint32_t mbits, int32_t kbit,
+                    uint32_t &t_f, uint32_t &t_e, uint32_t &t_g, uint32_t &t_x) {
+        const int32_t e = __builtin_amdgcn_sbfe((int32_t)mbits, kbit, 1);      // -1 where the bases are equal
+        const int32_t Fopn = Hup - open_v, Fext = EXT0 ? Fup : Fup - ext_v;
+        const int32_t Eopn = Hl - open_v, Eext = EXT0 ? El : El - ext_v;
+        const int32_t Fv = Fopn > Fext ? Fopn : Fext;
+        const int32_t Ev = Eopn > Eext ? Eopn : Eext;
+        const int32_t Hd = Hs + mism_v + (e & delta_v);
+        const int32_t g = Fv > Ev ? Fv : Ev;
+        const int32_t Hv = Hd > g ? Hd : g;
+        int32_t d_f, d_e, d_g, d_x;
+        if (POL0) { d_f = Fext - Fopn; d_e = Eext - Eopn; d_g = Hd - Hv; d_x = Fv - Ev; }
+        else { d_f = Fext - Fopn - c_open_v; d_e = Eext - Eopn - c_open_v; d_g = Hd - g - c_gap_v; d_x = Fv - Ev - c_ef_v; }
+        t_f = (uint32_t)d_f; t_e = (uint32_t)d_e; t_g = (uint32_t)d_g;
+        t_x = __builtin_amdgcn_bitop3_b32((uint32_t)d_g, (uint32_t)d_x, (uint32_t)e, 0xC5);     // gap ? E-rather-than-F : mismatch
+        Hs = Hv; Es = Ev; Fs = Fv;
+    };
+    // the same for a cell that may lie outside the matrix (then nothing happens), with the end-cell candidates
+    auto cell = [&](int32_t a, int32_t d, int32_t &Hs, int32_t &Es, int32_t &Fs, int32_t Hup, int32_t Fup, int32_t Hl, int32_t El, uint32_t mbits, int32_t kbit,
+                    uint32_t &t_f, uint32_t &t_e, uint32_t &t_g, uint32_t &t_x) {
+        const int32_t i = (a - d) >> 1, j = i + d;
+        t_f = t_e = t_g = t_x = 0;
+        if ((uint32_t)i < (uint32_t)m && (uint32_t)j < (uint32_t)n) {
+            core(Hs, Es, Fs, Hup, Fup, Hl, El, mbits, kbit, t_f, t_e, t_g, t_x);
+            if (a >= row_from && i == m - 1) {
+                if (Hs > rowbest) { rowbest = Hs; rowj_first = j; rowj_last = j; }
+                else if (Hs == rowbest) rowj_last = j;
+            }
+            if (a >= col_from && j == n - 1) {      // (a lane meets the last column on its largest diagonal first: ascending rows)
+                if (Hs > colbest) { colbest = Hs; coli_first = i; coli_last = i; }
+                else if (Hs == colbest) coli_last = i;
+            }
+        }
+    };
+    auto push = [&](uint32_t t_f, uint32_t t_e, uint32_t t_g, uint32_t t_x) {
+        tw = __builtin_amdgcn_alignbit(tw, t_f, 31);
+        tw = __builtin_amdgcn_alignbit(tw, t_e, 31);
+        tw = __builtin_amdgcn_alignbit(tw, t_g, 31);
+        tw = __builtin_amdgcn_alignbit(tw, t_x, 31);
+    };
+
+    // One step = one anti-diagonal.  PAR = 0: slots 0 and 2, PAR = 1: slots 1 and 3 -- compile-time, and the loop below runs an
+    // even and an odd step per iteration, so that no register shuffling is left at the control-flow joins (a loop over
+    // single steps with a run-time parity cost ~25 v_mov per step).
+    auto step = [&](int32_t a, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        if ((a & 127) == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int32_t d = d0 + s;
+                const int32_t ifirst = (a + ((a - d) & 1) - d) >> 1;            // row of the slot's first cell at or after step a
+                const uint64_t ql = plane_bits64(planes, nseq, nchunks, ia, 0, ifirst), qh = plane_bits64(planes, nseq, nchunks, ia, 1, ifirst);
+                const uint64_t tl = plane_bits64(planes, nseq, nchunks, ib, 0, ifirst + d), th = plane_bits64(planes, nseq, nchunks, ib, 1, ifirst + d);
+                const uint64_t mk = ~(ql ^ tl) & ~(qh ^ th);
+                Mlo[s] = (uint32_t)mk; Mhi[s] = (uint32_t)(mk >> 32);
+                // -inf must not drift towards the end of the int32 range along a long band edge (ext per step)
+                E[s] = E[s] > SG_NEG ? E[s] : SG_NEG;
+                F[s] = F[s] > SG_NEG ? F[s] : SG_NEG;
+            }
+        }
+        if ((a & 63) == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Mcur[s] = (a & 64) ? Mhi[s] : Mlo[s];
+        }
+        const int32_t kbit = (a & 63) >> 1;
+        uint32_t f0, e0, g0, x0, f1, e1, g1, x1;
+        const bool interior = a >= in_from && a <= in_to;      // wave-uniform: both cells of every lane are plain matrix cells
+        if (PAR == 0) {
+            const int32_t edge = (interior || a + dlo != 0) ? SG_NEG : 0;      // left of the band: -inf, or the boundary column of cell (i, 0)
+            const int32_t Hl = __builtin_amdgcn_update_dpp(edge, H[3], 0x138, 0xf, 0xf, false);      // wave_shr:1: lane l takes lane l - 1
+            const int32_t El = __builtin_amdgcn_update_dpp(SG_NEG, E[3], 0x138, 0xf, 0xf, false);
+            const int32_t h1 = H[1], e1s = E[1], f1s = F[1], h3 = H[3], f3 = F[3];
+            if (interior) {
+                core(H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
+                core(H[2], E[2], F[2], h3, f3, h1, e1s, Mcur[2], kbit, f1, e1, g1, x1);
+            } else {
+                cell(a, d0, H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
+                cell(a, d0 + 2, H[2], E[2], F[2], h3, f3, h1, e1s, Mcur[2], kbit, f1, e1, g1, x1);
+            }
+        } else {
+            const int32_t edge = (interior || a - dlo - (SG_BAND_DIAGS - 1) != 0) ? SG_NEG : 0;   // above the band: -inf, or the boundary row of cell (0, j)
+            const int32_t Hu = __builtin_amdgcn_update_dpp(edge, H[0], 0x130, 0xf, 0xf, false);      // wave_shl:1: lane l takes lane l + 1
+            const int32_t Fu = __builtin_amdgcn_update_dpp(SG_NEG, F[0], 0x130, 0xf, 0xf, false);
+            const int32_t h0 = H[0], e0s = E[0], h2 = H[2], e2s = E[2], f2s = F[2];
+            if (interior) {
+                core(H[1], E[1], F[1], h2, f2s, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
+                core(H[3], E[3], F[3], Hu, Fu, h2, e2s, Mcur[3], kbit, f1, e1, g1, x1);
+            } else {
+                cell(a, d0 + 1, H[1], E[1], F[1], h2, f2s, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
+                cell(a, d0 + 3, H[3], E[3], F[3], Hu, Fu, h2, e2s, Mcur[3], kbit, f1, e1, g1, x1);
+            }
+        }
+        push(f0, e0, g0, x0);
+        push(f1, e1, g1, x1);
+        if ((a & 3) == 3 && a >= 0) tw_base[(size_t)(a >> 2) * 64 + lane] = tw;
+    };
+    // the first step of a pair is the "even" kind: start one anti-diagonal early if dlo is odd (no cell lives there; its
+    // byte is shifted out of the trace word before the first store), and the pair's last half may lie beyond a_end
+    const int32_t a_start = -(dlo & 1);
+    int32_t a = a_start;
+#pragma unroll 1
+    for (; a <= a_end; a += 2) {
+        step(a, std::integral_constant<int, 0>());
+        step(a + 1, std::integral_constant<int, 1>());
+    }
+    const int32_t a_done = a - 1;                 // last step taken (a_end or a_end + 1)
+    if (((a_done + 1) & 3) != 0) tw_base[(size_t)(a_done >> 2) * 64 + lane] = tw << (8 * (4 - ((a_done + 1) & 3)));
+    // reduce the candidates over lanes: maximum; smallest (first) / largest (last) column resp. row on ties
+    int32_t rb = rowbest, rf = rowj_first, rl = rowj_last, cb = colbest, cf = coli_first, cl = coli_last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t ob = __shfl_xor(rb, o, 64), of = __shfl_xor(rf, o, 64), ol = __shfl_xor(rl, o, 64);
+        if (ob > rb) { rb = ob; rf = of; rl = ol; }
+        else if (ob == rb) {
+            if (of >= 0 && (rf < 0 || of < rf)) rf = of;
+            if (ol > rl) rl = ol;
+        }
+        const int32_t pb = __shfl_xor(cb, o, 64), pf = __shfl_xor(cf, o, 64), pl = __shfl_xor(cl, o, 64);
+        if (pb > cb) { cb = pb; cf = pf; cl = pl; }
+        else if (pb == cb) {
+            if (pf >= 0 && (cf < 0 || pf < cf)) cf = pf;
+            if (pl > cl) cl = pl;
+        }
+    }
+    if (lane == 0) {
+        const bool last = (policy & SG_POL_LAST_MAX) != 0, col_first = (policy & SG_POL_COL_FIRST) != 0;
+        int32_t score, eq, er;
+        const int32_t rj = last ? rl : rf, ci = last ? cl : cf;
+        if (!col_first) {
+            score = rb; eq = m - 1; er = rj;
+            if (cb > score || (last && cb == score)) { score = cb; eq = ci; er = n - 1; }
+        } else {
+            score = cb; eq = ci; er = n - 1;
+            if (rb > score || (last && rb == score)) { score = rb; eq = m - 1; er = rj; }
+        }
+        endinfo[(size_t)pidx * 4 + 0] = score;
+        endinfo[(size_t)pidx * 4 + 1] = eq;
+        endinfo[(size_t)pidx * 4 + 2] = er;
+    }
+}
+
 // One thread per pair: follow the trace back from the end cell, emit run-length ops (front-to-back order) into the
 // pair's ops region [ops_off, ops_off + m + n + 2), right-aligned; res = score,end_q,end_r,matches,mismatches,indels;
 // opcount[p] = number of ops.
@@ -297,6 +498,8 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     const int32_t steps = pr.steps;
     const int32_t score = endinfo[(size_t)p * 4], eq = endinfo[(size_t)p * 4 + 1], er = endinfo[(size_t)p * 4 + 2];
     bool left_window = false;       // the path stepped on a cell that was never computed (cannot happen inside a certified band)
+    int32_t c_lane = -1, c_top = -1 << 30;      // k_sg_band traces: the four cached dwords c_top .. c_top - 3 of lane column c_lane
+    uint32_t c_w[4] = {0, 0, 0, 0};
     const uint64_t cap = (uint64_t)m + n + 2;
     uint32_t *region = ops + pr.ops_off;
     uint64_t pos = cap;
@@ -313,13 +516,31 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     int32_t nmatch = 0, nmis = 0;
     int64_t alen = (int64_t)(n - 1 - er) + (m - 1 - eq);
     while (i >= 0 && j >= 0) {
-        const int32_t pass = i / (64 * R), ip = i - pass * 64 * R;
-        const int32_t l = ip / R, r = ip - l * R;
-        int32_t jlo, jhi;
-        sg_window(pass * 64 * R, 64 * R, pr.dlo, pr.dhi, n, jlo, jhi);
-        if (j < jlo || j > jhi) { left_window = true; break; }
-        const uint32_t word = *reinterpret_cast<const uint32_t *>(tb + (((size_t)pass * steps + (size_t)(j - jlo + l)) * 64 + l) * (size_t)(R / 2));
-        const uint32_t tr = (word >> (28 - 4 * r)) & 15u;
+        uint32_t tr;
+        if (pr.mode == 1) {       // k_sg_band: byte of step a = i + j in dword a / 4 of the lane that owns the diagonal
+            const int32_t sl = (j - i) - pr.dlo;
+            if (sl < 0 || sl >= SG_BAND_DIAGS) { left_window = true; break; }
+            const int32_t a = i + j, q = a >> 2, lc = sl >> 2;
+            // the walk moves to smaller a on (mostly) the same diagonal: fetch four dwords of the lane's column at a time
+            if (lc != c_lane || q > c_top || q < c_top - 3) {
+                const uint32_t *col = reinterpret_cast<const uint32_t *>(tb) + lc;
+                c_lane = lc; c_top = q;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) c_w[x] = q - x >= 0 ? col[(size_t)(q - x) * 64] : 0u;
+            }
+            const int32_t back = c_top - q;
+            const uint32_t word = back == 0 ? c_w[0] : back == 1 ? c_w[1] : back == 2 ? c_w[2] : c_w[3];
+            const uint32_t byte = (word >> (8 * (3 - (a & 3)))) & 255u;
+            tr = (sl & 2) ? (byte & 15u) : (byte >> 4);
+        } else {
+            const int32_t pass = i / (64 * R), ip = i - pass * 64 * R;
+            const int32_t l = ip / R, r = ip - l * R;
+            int32_t jlo, jhi;
+            sg_window(pass * 64 * R, 64 * R, pr.dlo, pr.dhi, n, jlo, jhi);
+            if (j < jlo || j > jhi) { left_window = true; break; }
+            const uint32_t word = *reinterpret_cast<const uint32_t *>(tb + (((size_t)pass * steps + (size_t)(j - jlo + l)) * 64 + l) * (size_t)(R / 2));
+            tr = (word >> (28 - 4 * r)) & 15u;
+        }
         if (where == 0) {
             if (!(tr & SG_BIT_GAP)) {
                 if (tr & SG_BIT_X) { emit(1, 1); ++nmis; } else { emit(0, 1); ++nmatch; }

@@ -184,3 +184,36 @@ def test_wrappers_use_the_hint_and_stay_identical():
     reads = [_mut(rng, centre, 0.01) for _ in range(30)] + [_mut(rng, centre[:700] + centre[900:], 0.01) for _ in range(4)]
     matches = {centre: {r: O.ed_bounded(centre, r, -1) for r in reads}}
     assert SWM.sw_align_sequences(matches) == O.sw_align_sequences(matches)
+
+
+def test_diagonal_band_kernel_equals_strip_kernel(monkeypatch):
+    """Certified bands of at most 256 diagonals run with the diagonals on the lanes (k_sg_band); ISOCON_SW_STRIPS=1 sends them
+    through the strip kernel instead.  Read-sized pairs at CCS and at ONT error rates (bands of ~100 .. ~800 diagonals, so
+    both kernels are in the default run), every tie policy class, both gap models: identical ops and results."""
+    from isocon_amd import synth
+    from isocon_amd.store import SeqStore
+    rng = np.random.Generator(np.random.PCG64(9))
+    seqs, a, b = [], [], []
+    for it in range(48):
+        L = int(rng.integers(900, 2700))
+        base = synth._rand_seq(rng, L)
+        rate = [0.004, 0.01, 0.02, 0.05][it % 4]
+        x = synth.mutate(rng, base, dict(synth.CCS_PROFILE, rate=rate))
+        y = synth.mutate(rng, base, dict(synth.ONT_PROFILE, rate=rate))
+        if it % 5 == 0:
+            y = y[int(rng.integers(0, 30)):len(y) - int(rng.integers(0, 30))]
+        seqs += [x.tobytes().decode(), y.tobytes().decode()]
+        a.append(2 * it); b.append(2 * it + 1)
+    st = SeqStore(seqs)
+    ed = st.ed_pairs(a, b, None)
+    mm = np.array([[-1, -2, -4][i % 3] for i in range(len(a))], dtype=np.int8)
+    for policy, open_, ext in ((0, 2, 0), (3, 2, 0), (8, 2, 0), (21, 2, 0), (0, 3, 1)):
+        monkeypatch.delenv("ISOCON_SW_STRIPS", raising=False)
+        o1, p1, r1 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy, ed_upper=ed)
+        monkeypatch.setenv("ISOCON_SW_STRIPS", "1")
+        o2, p2, r2 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy, ed_upper=ed)
+        monkeypatch.delenv("ISOCON_SW_STRIPS", raising=False)
+        o3, p3, r3 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy)          # no hints: the full matrix
+        assert (r1 == r2).all() and (p1 == p2).all() and (o1 == o2).all(), (policy, open_, ext)
+        assert (r1 == r3).all() and (p1 == p3).all() and (o1 == o3).all(), (policy, open_, ext)
+    st.close()
