@@ -17,11 +17,16 @@ SRC = os.path.join(HERE, "emul", "hw_emul.cpp")
 CORES = [os.path.join(os.path.dirname(HERE), "isocon_amd", "csrc", f) for f in ("band_core.hpp", "hw_core.hpp")]
 
 
-@pytest.fixture(scope="module")
-def emul():
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(f) for f in [SRC] + CORES):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", SO, SRC])
-    return ctypes.CDLL(SO)
+# Every case runs twice: on the plain build and on a -fsanitize=undefined build of the same sources (the lane-level headers
+# are full of shifts by computed amounts; an out-of-range shift is undefined in C++ and MASKED on the GPU, so it has to be
+# absent, not merely harmless here).  The sanitizer aborts the process at the first finding.
+@pytest.fixture(scope="module", params=["plain", "ubsan"])
+def emul(request):
+    so = SO if request.param == "plain" else SO.replace(".so", "_ubsan.so")
+    flags = ["-O2"] if request.param == "plain" else ["-O1", "-g", "-fsanitize=undefined", "-fno-sanitize-recover=all", "-static-libubsan"]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [SRC] + CORES):
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, SRC])
+    return ctypes.CDLL(so)
 
 
 def run_tile(L, W, q, targets, ks):
