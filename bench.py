@@ -454,7 +454,7 @@ def other_kernels(store, seqs, lens, last, true_isoforms, ctr):
         "sw_banded_equals_full": same,
         # VALU-issue / HBM fractions of the profiled dispatches of THIS batch (profiles/counters.json), at the live kernel times
         "sw_full": dict(kernel="k_sg_forward (4096 pairs, full matrix)", kernel_ms=sw_ms, **_fracs(ctr, "sg_full", sw_ms)),
-        "sw_banded": dict(kernel="k_sg_forward (4096 pairs, edit-distance band hints)", kernel_ms=swb_ms, **_fracs(ctr, "sg_banded", swb_ms)),
+        "sw_banded": dict(kernel="k_sg_band (4096 pairs, edit-distance band hints: the band's diagonals on the lanes)", kernel_ms=swb_ms, **_fracs(ctr, "sg_banded", swb_ms)),
         "hw_k25": dict(kernel="infix kernel, 4096 pairs, k = 25", kernel_ms=hw25_ms, **_fracs(ctr, "hw_k25", hw25_ms)),
         "hw_k63": dict(kernel="infix kernel, 4096 pairs, k = 63", kernel_ms=hw63_ms, **_fracs(ctr, "hw_k63", hw63_ms)),
         "hw_graph": dict(kernel="k_hw_locate + k_hw_finish, candidate-vs-candidate graph (%d candidates, k = 25)" % len(cseqs), pairs=int(len(gq)),

@@ -41,7 +41,16 @@ def dispatches(kind):
 def classify(rows):
     """dispatch classes bench.py reports: first main pass, first seed pass, the two 4096-pair SW batches, the two infix batches"""
     cls = {}
-    sg = [r for r in rows if "k_sg_forward" in r[1] and r[2] == 4096 * 64]
+    # bench.py's two 4096-pair alignment batches: the full matrices (k_sg_forward), then the same pairs with band hints
+    # (k_sg_band, plus a k_sg_forward launch right before it when some bands are wider than 256 diagonals)
+    sg_full = [r for r in rows if "k_sg_forward" in r[1] and r[2] == 4096 * 64][:1]
+    sg_banded = []
+    for x, r in enumerate(rows):
+        if "k_sg_band" in r[1] and r[2] == 4096 * 64:
+            sg_banded = [r]
+            if x and "k_sg_forward" in rows[x - 1][1] and rows[x - 1][2] == 4096 * 64 and rows[x - 1] not in sg_full:
+                sg_banded.insert(0, rows[x - 1])
+            break
     # isocon_hw_pairs = k_hw_locate launches (one per band class) followed by k_hw_finish launches: a call starts at the first
     # locate after a finish; bench.py's first call is its 64-pair warm-up
     calls, prev = [], "finish"
@@ -59,8 +68,10 @@ def classify(rows):
             cls["nn_main"] = [r]
         if "k_nn_scan_up<1>" in r[1] and "nn_seed" not in cls:
             cls["nn_seed"] = [r]
-    if len(sg) >= 2:
-        cls["sg_full"], cls["sg_banded"] = [sg[0]], [sg[1]]
+    if sg_full:
+        cls["sg_full"] = sg_full
+    if sg_banded:
+        cls["sg_banded"] = sg_banded
     if len(calls) >= 3:
         cls["hw_k25"], cls["hw_k63"] = calls[1], calls[2]
     if len(calls) >= 5:
