@@ -56,6 +56,15 @@ def window_pairs(lens, best):
     return int(((hi - lo - 1) * has).sum())
 
 
+def graph_digest(best, row_ptr, cols):
+    """identity of a graph (bounds, row pointers, neighbour order): equal across N = 1, 2, 4, 8 runs of the same workload"""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for x, t in ((best, np.int32), (row_ptr, np.int64), (cols, np.uint32)):
+        h.update(np.ascontiguousarray(x, dtype=t).tobytes())
+    return h.hexdigest()
+
+
 def usable_cores():
     """Threads this process may actually run concurrently: min(cpu_count, affinity, cgroup CPU quota)."""
     c = os.cpu_count() or 1
@@ -354,6 +363,7 @@ def main():
                                % (args.reads, len(seqs), args.length, args.isoforms, args.seed),
                    "alignments_per_step": n_align, "nn_graph_wall_ms": ms_per_step, "edges": int(last["edges"]),
                    "median_nn_distance": float(np.median(last["best"][last["best"] >= 0])) if (last["best"] >= 0).any() else None,
+                   "graph_digest": graph_digest(last["best"], last["row_ptr"], last["cols"]),
                    "parallelism": "1 process/GPU; pairs sharded by lower index; all_reduce(MIN)+all_gather over RCCL" if world > 1 else "single GPU"},
         "roofline": roofline,
         "rccl_ranks": dist.get_world_size() if dist is not None else 1,

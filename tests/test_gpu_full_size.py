@@ -71,6 +71,9 @@ def test_c3_alignments_roundtrip(c3):
     t = cols[row_ptr[q]]
     mm = np.full(len(q), -2, dtype=np.int8)
     ops, ptr, res = st.sg_trace(t, q, mm)
+    # the same pairs with their distances as band hints (what sw_align_sequences hands down): the diagonal-band kernel
+    ops_b, ptr_b, res_b = st.sg_trace(t, q, mm, ed_upper=best[q])
+    assert (res_b == res).all() and (ptr_b == ptr).all() and (ops_b == ops).all()
     for p in range(len(q)):
         s1, s2 = seqs[int(t[p])], seqs[int(q[p])]
         a1, a2 = SWM._ops_to_alignment(ops[ptr[p]:ptr[p + 1]].tolist(), s1, s2)
