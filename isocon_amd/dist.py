@@ -88,23 +88,37 @@ def _digest(*arrays):
     return int.from_bytes(h.digest(), "little") >> 1
 
 
-def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, dist=None, device=None, return_stats=False):
+def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, dist=None, device=None, return_stats=False, laps=None):
     """Exact NN graph of `store` (length-sorted) computed by all ranks of the default process group.
 
     `store` needs .n, .lens and .nn_partial(q_begin, q_end, phase, best, is_converged=, is_target=, depth=, q_stride=).
-    Every rank returns the full (best, row_ptr, cols)."""
+    Every rank returns the full (best, row_ptr, cols).  laps: optional dict that receives the seconds spent per protocol part."""
+    import time
     import torch
+
+    def lap(name, t0):
+        if laps is not None:
+            laps[name] = laps.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
     if dist is None:
         import torch.distributed as dist  # noqa: PLC0415
     world, rank = dist.get_world_size(), dist.get_rank()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     n = store.n
+    tl = time.perf_counter()
     fp = getattr(store, "fingerprint", None)
-    if fp is not None:      # every rank must have packed the very same sequences in the very same order
+    if fp is not None and getattr(store, "_fingerprint_agreed", None) != (world, fp):
+        # every rank must have packed the very same sequences in the very same order (checked once per store)
         if not same_everywhere(fp, dist, device):
             raise RuntimeError("sharded_nn_graph: the ranks hold different sequence sets / orders (fingerprint mismatch); "
                                "build the store from a deterministic order (not from set())")
+        try:
+            store._fingerprint_agreed = (world, fp)
+        except AttributeError:
+            pass
+    tl = lap("fingerprint", tl)
     qb, qe, qs = rank, n, world          # cyclic ownership
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
@@ -124,11 +138,13 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         # A rank that fails here (out of memory, a HIP error) must not leave the others blocked in the collective: its
         # status travels as one more word of the very reduction that follows (MIN: -1 wins), then every rank raises.
         err = None
+        tl = time.perf_counter()
         try:
             hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth,
                                            q_stride=qs)
         except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
             err, hits, stats = e, np.zeros((0, 3), np.int32), {}
+        tl = lap("nn_partial_phase%d" % phase, tl)
         t = torch.empty(len(best) + 1, dtype=torch.int32)
         t[:-1] = torch.from_numpy(best)
         t[-1] = -1 if err is not None else 0
@@ -138,14 +154,18 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         if int(t[-1]) != 0:
             raise RuntimeError("sharded_nn_graph: phase %d failed on %s" % (phase, "this rank: %r" % (err,) if err is not None else "another rank"))
         best[:] = t[:-1].numpy()
+        tl = lap("reduce_min", tl)
         hits_all.append(hits)
         stats_all.append(stats)
     hits = np.concatenate(hits_all, axis=0) if hits_all else np.zeros((0, 3), np.int32)
     if len(hits):   # only edges that attain the global minimum of their endpoint travel
         keep = (hits[:, 2] >= 0) & (hits[:, 2] == best[np.clip(hits[:, 0], 0, max(n - 1, 0))])
         hits = hits[keep]
+    tl = time.perf_counter()
     gathered = _all_gather_rows(dist, hits.astype(np.int32), device)    # exchange step 3
+    tl = lap("gather_edges", tl)
     out = nn_finalize(n, best[:n], gathered)
+    tl = lap("finalize", tl)
     return out + (stats_all,) if return_stats else out
 
 
