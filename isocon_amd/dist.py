@@ -9,8 +9,10 @@ pairs; phase 2 = 128/256/512-row bands (only entries still unresolved after the 
 un-banded kernel for the owned queries whose neighbour is further than 511 edits.  Exchange steps (the only data-path
 collectives):
     all_reduce(MIN) of best[n]   after each phase (tight thresholds everywhere; phase 2 and its
-                                 reduction are skipped when no query is left unresolved)          (4 B x n)
-    all_gather of the candidate edges that attain best[] on their rank                         (12 B x edges)
+                                 reduction are skipped when no query is left unresolved); the same tensor carries every
+                                 rank's status word and edge count                               (4 B x (n + 1 + N))
+    all_gather of the candidate edges that attain best[] on their rank, in fixed-size blocks of the largest count
+    known from the last reduction (no size exchange)                                           (12 B x edges)
 The reference has no distributed path (its Pool chunking: /root/reference/modules/nearest_neighbor_graph.py:33-35).
 """
 from __future__ import annotations
@@ -145,24 +147,38 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
             err, hits, stats = e, np.zeros((0, 3), np.int32), {}
         tl = lap("nn_partial_phase%d" % phase, tl)
-        t = torch.empty(len(best) + 1, dtype=torch.int32)
-        t[:-1] = torch.from_numpy(best)
-        t[-1] = -1 if err is not None else 0
+        hits_all.append(hits)
+        stats_all.append(stats)
+        # one reduction carries: best[n] | this rank's status | -(edges this rank holds so far) in its own slot (0 in the
+        # others' slots): after MIN every rank knows every rank's edge count, so the gather below needs no size exchange
+        nb = len(best)
+        t = torch.zeros(nb + 1 + world, dtype=torch.int32)
+        t[:nb] = torch.from_numpy(best)
+        t[nb] = -1 if err is not None else 0
+        t[nb + 1 + rank] = -sum(len(h) for h in hits_all)
         t = t.to(device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)           # exchange step 1 (and 2)
         t = t.cpu()
-        if int(t[-1]) != 0:
+        if int(t[nb]) != 0:
             raise RuntimeError("sharded_nn_graph: phase %d failed on %s" % (phase, "this rank: %r" % (err,) if err is not None else "another rank"))
-        best[:] = t[:-1].numpy()
+        best[:] = t[:nb].numpy()
+        counts = (-t[nb + 1:]).numpy()
         tl = lap("reduce_min", tl)
-        hits_all.append(hits)
-        stats_all.append(stats)
     hits = np.concatenate(hits_all, axis=0) if hits_all else np.zeros((0, 3), np.int32)
     if len(hits):   # only edges that attain the global minimum of their endpoint travel
         keep = (hits[:, 2] >= 0) & (hits[:, 2] == best[np.clip(hits[:, 0], 0, max(n - 1, 0))])
         hits = hits[keep]
     tl = time.perf_counter()
-    gathered = _all_gather_rows(dist, hits.astype(np.int32), device)    # exchange step 3
+    # exchange step 3: ONE all_gather of fixed-size blocks (the largest count of the reduction above; unused rows are -1)
+    kmax = int(counts.max()) if len(counts) else 0
+    buf = torch.full((max(kmax, 1), 3), -1, dtype=torch.int32)
+    if len(hits):
+        buf[:len(hits)] = torch.from_numpy(np.ascontiguousarray(hits, dtype=np.int32))
+    buf = buf.to(device)
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    gathered = torch.cat(outs, dim=0).cpu().numpy()
+    gathered = gathered[gathered[:, 2] >= 0]
     tl = lap("gather_edges", tl)
     out = nn_finalize(n, best[:n], gathered)
     tl = lap("finalize", tl)
