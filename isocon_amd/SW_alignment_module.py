@@ -78,6 +78,11 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0, e
         raise ValueError("empty sequence in an alignment pair")
     st, a, b, owned = store_for_pairs(pairs)
     try:
+        if ed_upper is None and len(pairs) >= 64:
+            # callers without distances (hypothesis_test_module's candidate pairs, parasail_alignment batches): the device
+            # computes them first (isocon_ed_pairs, ~1e7 pairs/s) -- with a bound the alignment runs inside its certified band
+            # (4-9x less work for related sequences) and comes out identical; unrelated pairs fall back to the full matrix
+            ed_upper = st.ed_pairs(a, b, None)
         aln_a, aln_b, ptr, res, ops, ops_ptr = st.sg_strings(a, b, np.asarray(mismatch, dtype=np.int8), match=match_score,
                                                              open_=opening_penalty, ext=gap_ext, tie_policy=TIE_POLICY,
                                                              return_ops=True, ed_upper=ed_upper)
