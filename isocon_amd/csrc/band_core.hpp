@@ -108,6 +108,30 @@ ISO_HD void band_init(BandLane<W> &L, int32_t nv /* = -a0 */, int32_t bstar)
     L.ztop = 0;
 }
 
+// 64 W-bit addition x + vp, word by word.  Device, W > 1: the carry travels as a LANE MASK in an SGPR pair through
+// v_add_co / v_addc_co (two 4-cycle instructions per word); recomputing it from 64-bit compares (c = s < x, ...) cost two
+// 64-bit adds, two 64-bit compares, a mask OR and a select per word -- a third of the column at 6 words.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t band_add_first(uint64_t x, uint64_t vp, uint64_t &cmask)
+{
+    uint32_t lo, hi;
+    asm("v_add_co_u32_e64 %0, %2, %3, %5\n\tv_addc_co_u32_e64 %1, %2, %4, %6, %2"
+        : "=&v"(lo), "=&v"(hi), "=&s"(cmask)
+        : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"((uint32_t)vp), "v"((uint32_t)(vp >> 32)));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t band_add_next(uint64_t x, uint64_t vp, uint64_t &cmask)
+{
+    uint32_t lo, hi;
+    uint64_t cout;
+    asm("v_addc_co_u32_e64 %0, %2, %3, %5, %7\n\tv_addc_co_u32_e64 %1, %2, %4, %6, %2"
+        : "=&v"(lo), "=&v"(hi), "=&s"(cout)
+        : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"((uint32_t)vp), "v"((uint32_t)(vp >> 32)), "s"(cmask));
+    cmask = cout;
+    return ((uint64_t)hi << 32) | lo;
+}
+#endif
+
 // One text column given the match vectors: EQ[i] bit r = 1 iff the pattern row of window bit r (word i) equals the
 // column's text base (0 on virtual rows).
 template <int W>
@@ -121,6 +145,11 @@ ISO_HD void band_step_eq(BandLane<W> &L, const uint64_t (&EQ)[W])
         const uint64_t eq = EQ[i];
         const uint64_t vp = L.VP[i], vn = L.VN[i];
         const uint64_t x = eq & vp;
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t s;
+        if (W > 1) s = i == 0 ? band_add_first(x, vp, carry) : band_add_next(x, vp, carry);     // carry: lane mask (SGPR pair)
+        else s = x + vp;
+#else
         uint64_t s = x + vp;
         if (W > 1) {
             uint64_t c = s < x;
@@ -129,12 +158,17 @@ ISO_HD void band_step_eq(BandLane<W> &L, const uint64_t (&EQ)[W])
             s = s2;
             carry = c;
         }
+#endif
         const uint64_t d0 = (s ^ vp) | eq | vn;
         if (i == 0) L.ztop += (uint32_t)d0 & 1u;
         if (i > 0) {
-            uint64_t d0s = (d0p >> 1) | (d0 << 63);
 #if defined(__HIP_DEVICE_COMPILE__)
-            asm("" : "+v"(d0s));             // one 64-bit shift feeding both uses (else the halves get re-derived)
+            // two funnel shifts (v_alignbit_b32) instead of a 64-bit shift + v_lshlrev + v_or
+            const uint32_t s_lo = __builtin_amdgcn_alignbit((uint32_t)(d0p >> 32), (uint32_t)d0p, 1);
+            const uint32_t s_hi = __builtin_amdgcn_alignbit((uint32_t)d0, (uint32_t)(d0p >> 32), 1);
+            const uint64_t d0s = ((uint64_t)s_hi << 32) | s_lo;
+#else
+            const uint64_t d0s = (d0p >> 1) | (d0 << 63);
 #endif
             L.VP[i - 1] = or_nor(hnp, d0s, hpp);
             L.VN[i - 1] = d0s & hpp;
@@ -162,6 +196,11 @@ ISO_HD void band_step_eq_hp(BandLane<W> &L, const uint64_t (&EQ)[W], uint64_t (&
         const uint64_t eq = EQ[i];
         const uint64_t vp = L.VP[i], vn = L.VN[i];
         const uint64_t x = eq & vp;
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t s;
+        if (W > 1) s = i == 0 ? band_add_first(x, vp, carry) : band_add_next(x, vp, carry);     // carry: lane mask (SGPR pair)
+        else s = x + vp;
+#else
         uint64_t s = x + vp;
         if (W > 1) {
             uint64_t c = s < x;
@@ -170,10 +209,18 @@ ISO_HD void band_step_eq_hp(BandLane<W> &L, const uint64_t (&EQ)[W], uint64_t (&
             s = s2;
             carry = c;
         }
+#endif
         const uint64_t d0 = (s ^ vp) | eq | vn;
         if (i == 0) L.ztop += (uint32_t)d0 & 1u;
         if (i > 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // two funnel shifts (v_alignbit_b32) instead of a 64-bit shift + v_lshlrev + v_or
+            const uint32_t s_lo = __builtin_amdgcn_alignbit((uint32_t)(d0p >> 32), (uint32_t)d0p, 1);
+            const uint32_t s_hi = __builtin_amdgcn_alignbit((uint32_t)d0, (uint32_t)(d0p >> 32), 1);
+            const uint64_t d0s = ((uint64_t)s_hi << 32) | s_lo;
+#else
             const uint64_t d0s = (d0p >> 1) | (d0 << 63);
+#endif
             L.VP[i - 1] = or_nor(hnp, d0s, hpp);
             L.VN[i - 1] = d0s & hpp;
         }
