@@ -492,14 +492,13 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     const uint32_t p = blockIdx.x * 64u + threadIdx.x;
     if (p >= n_pairs) return;
     const SgPair pr = pairs[p];
+    if (pr.mode == 1) return;                // k_sg_band's trace layout: k_sg_walk_band
     const int32_t m = S.lens[pr.a], n = S.lens[pr.b];
     const int32_t R = Rs[p];
     const uint8_t *tb = trace + pr.trace_off;
     const int32_t steps = pr.steps;
     const int32_t score = endinfo[(size_t)p * 4], eq = endinfo[(size_t)p * 4 + 1], er = endinfo[(size_t)p * 4 + 2];
     bool left_window = false;       // the path stepped on a cell that was never computed (cannot happen inside a certified band)
-    int32_t c_lane = -1, c_top = -1 << 30;      // k_sg_band traces: the four cached dwords c_top .. c_top - 3 of lane column c_lane
-    uint32_t c_w[4] = {0, 0, 0, 0};
     const uint64_t cap = (uint64_t)m + n + 2;
     uint32_t *region = ops + pr.ops_off;
     uint64_t pos = cap;
@@ -516,31 +515,13 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     int32_t nmatch = 0, nmis = 0;
     int64_t alen = (int64_t)(n - 1 - er) + (m - 1 - eq);
     while (i >= 0 && j >= 0) {
-        uint32_t tr;
-        if (pr.mode == 1) {       // k_sg_band: byte of step a = i + j in dword a / 4 of the lane that owns the diagonal
-            const int32_t sl = (j - i) - pr.dlo;
-            if (sl < 0 || sl >= SG_BAND_DIAGS) { left_window = true; break; }
-            const int32_t a = i + j, q = a >> 2, lc = sl >> 2;
-            // the walk moves to smaller a on (mostly) the same diagonal: fetch four dwords of the lane's column at a time
-            if (lc != c_lane || q > c_top || q < c_top - 3) {
-                const uint32_t *col = reinterpret_cast<const uint32_t *>(tb) + lc;
-                c_lane = lc; c_top = q;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) c_w[x] = q - x >= 0 ? col[(size_t)(q - x) * 64] : 0u;
-            }
-            const int32_t back = c_top - q;
-            const uint32_t word = back == 0 ? c_w[0] : back == 1 ? c_w[1] : back == 2 ? c_w[2] : c_w[3];
-            const uint32_t byte = (word >> (8 * (3 - (a & 3)))) & 255u;
-            tr = (sl & 2) ? (byte & 15u) : (byte >> 4);
-        } else {
-            const int32_t pass = i / (64 * R), ip = i - pass * 64 * R;
-            const int32_t l = ip / R, r = ip - l * R;
-            int32_t jlo, jhi;
-            sg_window(pass * 64 * R, 64 * R, pr.dlo, pr.dhi, n, jlo, jhi);
-            if (j < jlo || j > jhi) { left_window = true; break; }
-            const uint32_t word = *reinterpret_cast<const uint32_t *>(tb + (((size_t)pass * steps + (size_t)(j - jlo + l)) * 64 + l) * (size_t)(R / 2));
-            tr = (word >> (28 - 4 * r)) & 15u;
-        }
+        const int32_t pass = i / (64 * R), ip = i - pass * 64 * R;
+        const int32_t l = ip / R, r = ip - l * R;
+        int32_t jlo, jhi;
+        sg_window(pass * 64 * R, 64 * R, pr.dlo, pr.dhi, n, jlo, jhi);
+        if (j < jlo || j > jhi) { left_window = true; break; }
+        const uint32_t word = *reinterpret_cast<const uint32_t *>(tb + (((size_t)pass * steps + (size_t)(j - jlo + l)) * 64 + l) * (size_t)(R / 2));
+        const uint32_t tr = (word >> (28 - 4 * r)) & 15u;
         if (where == 0) {
             if (!(tr & SG_BIT_GAP)) {
                 if (tr & SG_BIT_X) { emit(1, 1); ++nmis; } else { emit(0, 1); ++nmatch; }
@@ -554,6 +535,86 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
             emit(3, 1); ++alen;
             where = (tr & SG_BIT_EOPEN) ? 0 : 2;
             --j;
+        }
+    }
+    if (i >= 0) { emit(2, (uint32_t)(i + 1)); alen += i + 1; }
+    if (j >= 0) { emit(3, (uint32_t)(j + 1)); alen += j + 1; }
+    if (run_len) region[--pos] = (run_len << 4) | run_code;
+    opcount[p] = (uint32_t)(cap - pos);
+    int32_t *o = res + (size_t)p * 6;
+    o[0] = left_window ? SG_NEG : score; o[1] = eq; o[2] = er; o[3] = nmatch; o[4] = nmis; o[5] = (int32_t)(alen - nmatch - nmis);
+}
+
+// The same walk over k_sg_band's trace (byte of step a = i + j in dword a / 4 of the lane that owns the diagonal): one thread
+// per pair, the state machine written with selects (64 pairs in 64 different states share the wave: every branch body is paid
+// by all of them), four dwords of the diagonal's lane column fetched at a time.
+__global__ __launch_bounds__(64) void k_sg_walk_band(DevStore S, const SgPair *__restrict__ pairs, const uint8_t *__restrict__ trace,
+                                                      const int32_t *__restrict__ endinfo, uint32_t *__restrict__ ops,
+                                                      uint32_t *__restrict__ opcount, int32_t *__restrict__ res, uint32_t n_pairs)
+{
+    const uint32_t p = blockIdx.x * 64u + threadIdx.x;
+    if (p >= n_pairs) return;
+    const SgPair pr = pairs[p];
+    if (pr.mode != 1) return;
+    const int32_t m = S.lens[pr.a], n = S.lens[pr.b];
+    const uint32_t *tb = reinterpret_cast<const uint32_t *>(trace + pr.trace_off);
+    const int32_t score = endinfo[(size_t)p * 4], eq = endinfo[(size_t)p * 4 + 1], er = endinfo[(size_t)p * 4 + 2];
+    const uint64_t cap = (uint64_t)m + n + 2;
+    uint32_t *region = ops + pr.ops_off;
+    uint64_t pos = cap;
+    uint32_t run_code = 0xffffffffu, run_len = 0;
+    auto emit = [&](uint32_t code, uint32_t cnt) {
+        if (cnt == 0) return;
+        if (code == run_code) { run_len += cnt; return; }
+        if (run_len) region[--pos] = (run_len << 4) | run_code;
+        run_code = code; run_len = cnt;
+    };
+    emit(3, (uint32_t)(n - 1 - er));   // trailing ref bases 'D'
+    emit(2, (uint32_t)(m - 1 - eq));   // trailing query bases 'I'
+    int32_t i = eq, j = er;
+    uint32_t where = 0;
+    int32_t nmatch = 0, nmis = 0;
+    int64_t alen = (int64_t)(n - 1 - er) + (m - 1 - eq);
+    bool left_window = false;
+    // Trace cache: 32 dwords (128 anti-diagonals = 64 diagonal steps) of the diagonal's lane column per thread, in LDS -- the walk
+    // moves towards smaller a on (mostly) the same four diagonals; with one thread per pair nothing hides a dependent HBM /
+    // Infinity-Cache load, so they are taken 32 at a time (unconditional addresses, one wait) and then read back from LDS
+    // (row stride 33: the 64 threads of the wave spread over the banks whatever their positions are).
+    __shared__ uint32_t s_cache[64][33];
+    uint32_t *my = s_cache[threadIdx.x];
+    int32_t c_lane = -1, c_top = -(1 << 30);
+    const int32_t dlo = pr.dlo;
+    while (i >= 0 && j >= 0) {
+        const int32_t sl = (j - i) - dlo;
+        if ((uint32_t)sl >= (uint32_t)SG_BAND_DIAGS) { left_window = true; break; }
+        const int32_t a = i + j, q = a >> 2, lc = sl >> 2;
+        if (lc != c_lane || q > c_top || q < c_top - 31) {
+            const uint32_t *col = tb + lc;
+            c_lane = lc; c_top = q;
+            uint32_t w[32];
+#pragma unroll
+            for (int x = 0; x < 32; ++x) { const int32_t qq = q - x > 0 ? q - x : 0; w[x] = col[(size_t)qq * 64]; }
+#pragma unroll
+            for (int x = 0; x < 32; ++x) my[x] = w[x];
+        }
+        const uint32_t word = my[c_top - q];
+        const uint32_t tr = (word >> (8 * (3 - (a & 3)) + ((sl & 2) ? 0 : 4))) & 15u;
+        const uint32_t gap = (tr >> 1) & 1u, xbit = tr & 1u, fopen = (tr >> 3) & 1u, eopen = (tr >> 2) & 1u;
+        const bool w0 = where == 0, w1 = where == 1;
+        const bool prod = w0 ? gap == 0 : true;                                   // this step emits one alignment column
+        const uint32_t code = w0 ? xbit : (w1 ? 2u : 3u);                         // 0 '=', 1 'X', 2 'I', 3 'D'
+        where = w0 ? (gap ? 1u + xbit : 0u) : (w1 ? (fopen ? 0u : 1u) : (eopen ? 0u : 2u));
+        if (prod) {
+            if (code == run_code) ++run_len;
+            else {
+                if (run_len) region[--pos] = (run_len << 4) | run_code;
+                run_code = code; run_len = 1;
+            }
+            i -= code != 3u;
+            j -= code != 2u;
+            nmatch += code == 0u;
+            nmis += code == 1u;
+            ++alen;
         }
     }
     if (i >= 0) { emit(2, (uint32_t)(i + 1)); alen += i + 1; }
