@@ -89,8 +89,8 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0, e
     finally:
         if owned:
             st.close()
-    aln_a = aln_a.decode("ascii")
-    aln_b = aln_b.decode("ascii")
+    aln_a = str(aln_a, "ascii")
+    aln_b = str(aln_b, "ascii")
     ptr = ptr.tolist()
     counts = res[:, 3:6].tolist()
     out = [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], tuple(counts[p])) for p in range(len(pairs))]

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "common.hpp"

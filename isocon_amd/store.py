@@ -13,6 +13,11 @@ def _ptr(a, t):
     return a.ctypes.data_as(t) if a is not None else None
 
 
+_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
+_utf8.restype = ctypes.c_void_p
+_utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
+
+
 class SeqStore(object):
     """Uploads a list of ACGT strings once; ids are positions in that list."""
 
@@ -23,12 +28,18 @@ class SeqStore(object):
         self.lens = lens.astype(np.int64)
         off = np.zeros(self.n + 1, dtype=np.uint64)
         np.cumsum(lens, out=off[1:])
-        buf = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8) if self.n else np.zeros(1, np.uint8)
-        if buf.size == 0:
-            buf = np.zeros(1, np.uint8)
+        # One join, no second copy: CPython keeps an all-ASCII str as one byte per character, and PyUnicode_AsUTF8AndSize hands
+        # out that very buffer (any non-ASCII symbol makes the sizes differ -- and is outside the alphabet anyway).
+        joined = "".join(seqs)
+        size = ctypes.c_ssize_t(0)
+        addr = _utf8(ctypes.py_object(joined), ctypes.byref(size)) if joined else None
+        if joined and (not addr or size.value != int(off[self.n])):
+            raise _lib.IsoconError("isocon_store_create failed: sequence contains a symbol outside ACGT (non-ASCII character)")
+        dummy = (ctypes.c_uint8 * 1)()
         h = ctypes.c_void_p()
-        _lib.check(L.isocon_store_create(_ptr(buf, _lib.u8p), _ptr(off, _lib.u64p), self.n, ctypes.byref(h)),
+        _lib.check(L.isocon_store_create(ctypes.cast(addr, _lib.u8p) if addr else dummy, _ptr(off, _lib.u64p), self.n, ctypes.byref(h)),
                    "isocon_store_create")
+        del joined
         self._h = h
         self._L = L
         self._fingerprint = None
@@ -190,7 +201,8 @@ def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ret
             continue
         _lib.check(rc, "isocon_sg_strings_batch")
         end = int(aln_ptr[n])
-        out = (aln_a[:end].tobytes(), aln_b[:end].tobytes(), aln_ptr.astype(np.int64), res[:n])
+        # (views, not copies: the caller decodes them once -- a 50 k x 2.5 kb batch is 2 x 130 MB)
+        out = (memoryview(aln_a[:end]), memoryview(aln_b[:end]), aln_ptr.astype(np.int64), res[:n])
         if return_ops:
             out = out + (ops[:int(ops_ptr[n])].copy(), ops_ptr.astype(np.int64))
         return out
@@ -221,12 +233,25 @@ def nn_finalize(n, best, hits):
 _RECENT = {"store": None, "index": None}
 
 
+class _LazyIndex(object):
+    """sequence -> id of the remembered store, built on first use (a caller that only wants the graph never pays for it)"""
+
+    def __init__(self, seqs):
+        self._seqs = seqs
+        self._d = None
+
+    def __getitem__(self, s):
+        if self._d is None:
+            self._d = {x: i for i, x in enumerate(self._seqs)}
+        return self._d[s]
+
+
 def remember(store, seqs):
     old = _RECENT["store"]
     if old is not None and old is not store:
         old.close()
     _RECENT["store"] = store
-    _RECENT["index"] = {s: i for i, s in enumerate(seqs)}
+    _RECENT["index"] = _LazyIndex(seqs)
 
 
 def forget():
