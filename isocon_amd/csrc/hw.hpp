@@ -142,6 +142,8 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
             if (valid && !ok) r0 = -4;
             const int32_t start = ok ? end - (ln.r_pl - 1) : 0;
             const int32_t ms = ok ? end - start + 1 : 0;
+            const bool packed = hw_packable(W, h, kmax);           // (per lane: its own distance decides)
+            const int32_t pshift = kmax - h - 1;
             // ---- TRACE: query against t[start..end], the columns' VP / HP vectors stored ----
             ln.ncols = ok && ms <= (int32_t)trace_cols ? ms : 0;
             if (ok && ms > (int32_t)trace_cols) r0 = -7;
@@ -159,8 +161,11 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
                 // needs neither the stored columns nor the walk (the trailing run is read off the last column).
                 auto sink = [&](int32_t j, int w, uint64_t vp, uint64_t hp) {
                     if (start == 0) {
-                        trace[(((size_t)j * 2) * W + w) * 64 + lane] = vp;
-                        trace[(((size_t)j * 2 + 1) * W + w) * 64 + lane] = hp;
+                        if (packed) trace[(((size_t)j * 2) * W + w) * 64 + lane] = hw_pack(vp, hp, pshift);
+                        else {
+                            trace[(((size_t)j * 2) * W + w) * 64 + lane] = vp;
+                            trace[(((size_t)j * 2 + 1) * W + w) * 64 + lane] = hp;
+                        }
                     }
                 };
                 hw_run<W, HW_TRACE>(T, ln, plo, phi, text, any_live, sink);
@@ -179,7 +184,10 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             if (ln.ncols > 0 && r0 >= 0 && start == 0) {
                 constexpr int PF = W <= 2 ? 8 : 2;
-                auto ld = [&](int32_t jj, int which, int w) -> uint64_t { return trace[(((size_t)jj * 2 + which) * W + w) * 64 + lane]; };
+                auto ld = [&](int32_t jj, int which, int w) -> uint64_t {
+                    if (packed) return hw_unpack(trace[(((size_t)jj * 2) * W + w) * 64 + lane], which, pshift);
+                    return trace[(((size_t)jj * 2 + which) * W + w) * 64 + lane];
+                };
                 int32_t i = P, j = ms;
                 bool bad = false;
                 while (i > 0 && j > 0 && !bad) {

@@ -208,6 +208,19 @@ ISO_HD void hw_run(const HwTile &T, HwLane &ln, PLo plo, PHi phi, Text text, Any
     ln.r_pl = pl;
 }
 
+// Packed column store (one word of band, pairs at distance h <= 14): the walk only visits cells whose diagonal offset j - i lies
+// in [-h, h], i.e. window bits kmax - h - 1 .. kmax + h of VP and HP -- at most 32 of each, so both fit ONE 64-bit word
+// (VP part low, HP part high) instead of two: half the bytes of the column store, which is what the finish kernel is bound by.
+ISO_HD bool hw_packable(int W, int32_t h, int32_t kmax) { return W == 1 && h <= 14 && kmax - h - 1 >= 0; }
+ISO_HD uint64_t hw_pack(uint64_t vp, uint64_t hp, int32_t shift)
+{
+    return (uint64_t)(uint32_t)(vp >> shift) | ((uint64_t)(uint32_t)(hp >> shift) << 32);
+}
+ISO_HD uint64_t hw_unpack(uint64_t word, int which, int32_t shift)
+{
+    return (uint64_t)(which == 0 ? (uint32_t)word : (uint32_t)(word >> 32)) << shift;
+}
+
 // The walk of the TRACE pass.  load(j, which, word): which = 0 the column's new VP (bit r: the vertical step INTO window row
 // r + 1 of column j is optimal), 1 its HP (bit r: the horizontal step into window row r is optimal).  Returns the leading
 // insertion run (rows left when column 0 is reached).

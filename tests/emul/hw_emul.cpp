@@ -101,10 +101,18 @@ static void tile(const char *q, int P, int nl, const char **ts, const int *tl, c
             wl = wh = 0;
             for (int x = 0; x < 32; ++x) { wl |= T[l].bit(T[l].lo, s0 + jb + x) << x; wh |= T[l].bit(T[l].hi, s0 + jb + x) << x; }
         };
-        auto sink = [&](int32_t j, int w, uint64_t vp, uint64_t hp) { tr[((size_t)j * 2) * W + w] = vp; tr[((size_t)j * 2 + 1) * W + w] = hp; };
+        const bool packed = hw_packable(W, h[l], hk);
+        const int32_t pshift = hk - h[l] - 1;
+        auto sink = [&](int32_t j, int w, uint64_t vp, uint64_t hp) {
+            if (packed) tr[((size_t)j * 2) * W + w] = hw_pack(vp, hp, pshift);
+            else { tr[((size_t)j * 2) * W + w] = vp; tr[((size_t)j * 2 + 1) * W + w] = hp; }
+        };
         hw_run<W, HW_TRACE>(C, ln, f_lo, f_hi, text, alone, sink);
         if (ln.r_final != h[l]) { out[5 * l] = -5; continue; }
-        auto load = [&](int32_t j, int which, int w) { return tr[((size_t)j * 2 + which) * W + w]; };
+        auto load = [&](int32_t j, int which, int w) -> uint64_t {
+            if (packed) return hw_unpack(tr[((size_t)j * 2) * W + w], which, pshift);
+            return tr[((size_t)j * 2 + which) * W + w];
+        };
         const int32_t lead = start[l] == 0 ? hw_walk<W>(P, C.a0, ms, load) : 0;     // smallest start > 0: no leading insertion run (hw.hpp)
         if (lead < 0) { out[5 * l] = -6; continue; }
         out[5 * l] = h[l]; out[5 * l + 1] = start[l]; out[5 * l + 2] = end[l]; out[5 * l + 3] = lead; out[5 * l + 4] = ln.r_trail;
