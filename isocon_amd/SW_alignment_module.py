@@ -76,6 +76,12 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0, e
         return []
     if any(len(s1) == 0 or len(s2) == 0 for s1, s2 in pairs):
         raise ValueError("empty sequence in an alignment pair")
+    from . import perf_log
+    with perf_log.call("SW_alignment_module.alignments", pairs=len(pairs), open=opening_penalty, ext=gap_ext, hints=ed_upper is not None):
+        return _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed_upper)
+
+
+def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed_upper):
     st, a, b, owned = store_for_pairs(pairs)
     try:
         if ed_upper is None and len(pairs) >= 64:

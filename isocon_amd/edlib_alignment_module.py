@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import perf_log
 from .store import SeqStore, store_for_pairs
 
 
@@ -31,12 +32,14 @@ def _intern(pairs):
 def _distances(pairs):
     if not pairs:
         return np.zeros(0, dtype=np.int32)
-    st, a, b, owned = store_for_pairs(pairs)
-    try:
-        ed = st.ed_pairs(a, b, None)
-    finally:
-        if owned:
-            st.close()
+    with perf_log.call("edlib_alignment_module.distances", pairs=len(pairs)) as rec:
+        st, a, b, owned = store_for_pairs(pairs)
+        try:
+            ed, ms = st.ed_pairs(a, b, None, return_ms=True)
+            rec.add(kernel_ms=ms)
+        finally:
+            if owned:
+                st.close()
     assert (ed >= 0).all()  # EAM:113
     return ed
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import perf_log
 from .store import SeqStore, remember
 
 LAST_STATS = {}  # statistics block of the most recent device call (bench / tests)
@@ -86,12 +87,14 @@ def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
     seqs = [s for s, _ in seq_to_acc_list_sorted]
     accs = [a for _, a in seq_to_acc_list_sorted]
     conv = np.fromiter((1 if s in has_converged else 0 for s in seqs), dtype=np.uint8, count=len(seqs))
-    st = SeqStore(seqs)
-    try:
-        best, row_ptr, cols, stats = _graph(st, seqs, is_converged=conv, depth=depth)
-    except Exception:
-        st.close()
-        raise
+    with perf_log.call("nearest_neighbor_graph.1set", sequences=len(seqs)) as rec:
+        st = SeqStore(seqs)
+        try:
+            best, row_ptr, cols, stats = _graph(st, seqs, is_converged=conv, depth=depth)
+        except Exception:
+            st.close()
+            raise
+        rec.add(edges=int(len(cols)), **{k: v for k, v in stats.items()})
     remember(st, seqs)      # EAM / SWM are called next on pairs of these very sequences
     LAST_STATS.clear()
     LAST_STATS.update(stats)
@@ -195,13 +198,15 @@ def _nn_2set(seq_to_acc_list_sorted_all, target_accessions, depth):
     seqs = [s for s, _ in seq_to_acc_list_sorted_all]
     accs = [a for _, a in seq_to_acc_list_sorted_all]
     is_t = np.fromiter((acc in target_accessions for acc in accs), dtype=bool, count=len(accs))
-    st = SeqStore(seqs)
-    try:
-        if depth < int(is_t.sum()):
-            return _replay_2set_depth(seqs, accs, is_t, depth, st)
-        best, row_ptr, cols, stats = _graph(st, seqs, is_target=is_t.astype(np.uint8), depth=depth)
-    finally:
-        st.close()
+    with perf_log.call("nearest_neighbor_graph.2set", sequences=len(seqs), targets=int(is_t.sum())) as rec:
+        st = SeqStore(seqs)
+        try:
+            if depth < int(is_t.sum()):
+                return _replay_2set_depth(seqs, accs, is_t, depth, st)
+            best, row_ptr, cols, stats = _graph(st, seqs, is_target=is_t.astype(np.uint8), depth=depth)
+        finally:
+            st.close()
+        rec.add(edges=int(len(cols)), **{k: v for k, v in stats.items()})
     LAST_STATS.clear()
     LAST_STATS.update(stats)
     return _rows_to_dict(accs, ~is_t, best, row_ptr, cols)
