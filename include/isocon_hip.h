@@ -69,6 +69,14 @@ uint64_t isocon_store_device_bytes(const isocon_store *s);
 int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const int32_t *k, uint64_t n_pairs,
                     int32_t *out_ed, float *kernel_ms);
 
+/*
+ * Lower bounds of the pairs' edit distances from 6-gram count profiles (isocon_amd/csrc/qgram.hpp):
+ * out_bound[p] <= ed(a[p], b[p]) always.  The main pass of the nearest-neighbour search skips a pair whose bound exceeds its
+ * threshold -- the pair edlib would have answered with -1 (modules/nearest_neighbor_graph.py:156-162).  The reference has no
+ * counterpart; exposed so that the bound can be tested by itself.
+ */
+int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound);
+
 /* statistics block filled by the nearest-neighbour entry points (all counters are for the one call) */
 typedef struct {
     uint64_t pairs_evaluated;     /* (shared,lane) pairs the banded kernels actually ran */
@@ -82,6 +90,9 @@ typedef struct {
     float scan_kernel_ms;         /* ... of the dominant kernel launch (64-row band scan, main pass) */
     float seed_kernel_ms;         /* ... of the seed pass that precedes it (1-set only) */
     uint32_t scan_launches;       /* launches summed into scan_kernel_ms */
+    uint64_t pairs_prefiltered;   /* pairs of the main pass whose q-gram bound exceeded their threshold (never aligned) */
+    float bound_kernel_ms;        /* HIP-event time of the q-gram profile + bound kernels (part of kernel_ms) */
+    uint32_t reserved_;
 } isocon_nn_stats;
 
 /*

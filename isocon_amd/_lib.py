@@ -12,8 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("ISOCON_LIB", os.path.join(_HERE, "lib", "libisocon_hip.so"))   # override: kernel experiments
 SRC_DIR = os.path.join(_HERE, "csrc")
-_SOURCES = ["isocon_hip.hip", "band_core.hpp", "common.hpp", "ed_band.hpp", "ed_full.hpp", "nn.hpp", "nn_host.inc",
-            "sg.hpp", "sg_host.inc", "msa.hpp", "msa_host.inc", "hw.hpp", "hw_core.hpp", "hw_host.inc"]
+_SOURCES = sorted(f for f in os.listdir(SRC_DIR) if f.endswith((".hip", ".hpp", ".inc"))) if os.path.isdir(SRC_DIR) else []
 
 ISOCON_OK = 0
 ISOCON_E_CAPACITY = -4
@@ -31,7 +30,8 @@ class NNStats(ctypes.Structure):
     _fields_ = [("pairs_evaluated", ctypes.c_uint64), ("cells_columns", ctypes.c_uint64), ("live_columns", ctypes.c_uint64), ("tiles", ctypes.c_uint64),
                 ("hits", ctypes.c_uint64), ("fallback_queries", ctypes.c_uint64), ("full_pairs", ctypes.c_uint64),
                 ("kernel_ms", ctypes.c_float), ("scan_kernel_ms", ctypes.c_float), ("seed_kernel_ms", ctypes.c_float),
-                ("scan_launches", ctypes.c_uint32)]
+                ("scan_launches", ctypes.c_uint32), ("pairs_prefiltered", ctypes.c_uint64), ("bound_kernel_ms", ctypes.c_float),
+                ("reserved_", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -50,6 +50,7 @@ SYMBOLS = {
     "isocon_store_device_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
     "isocon_store_digest": (ctypes.c_int, [ctypes.c_void_p, u64p]),
     "isocon_ed_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, i32p, ctypes.c_uint64, i32p, f32p]),
+    "isocon_qgram_bound_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, i32p]),
     "isocon_nn_graph": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, i32p, u64p, u32p, ctypes.c_uint64,
                                        u64p, ctypes.POINTER(NNStats)]),
     "isocon_nn_partial": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,

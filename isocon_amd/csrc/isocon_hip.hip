@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "ed_band.hpp"
 #include "ed_full.hpp"
+#include "qgram.hpp"
 #include "nn.hpp"
 #include "sg.hpp"
 #include "msa.hpp"
@@ -51,7 +52,7 @@ struct ScratchPool {
 
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
-    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2,
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES,
@@ -521,6 +522,30 @@ extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_
     if (kernel_ms) *kernel_ms = 0.f;
     if (!n_pairs) return ISOCON_OK;
     return ed_pairs_impl(s, a, b, k, n_pairs, out_ed, kernel_ms, nullptr);
+}
+
+// q-gram lower bounds of explicit pairs (qgram.hpp): what the main pass of the NN search consults, exposed for tests
+extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound)
+{
+    if (!s || (n_pairs && (!a || !b || !out_bound))) return ISOCON_E_ARG;
+    if (!n_pairs) return ISOCON_OK;
+    const uint32_t n = s->dev.n;
+    for (uint64_t i = 0; i < n_pairs; ++i)
+        if (a[i] >= n || b[i] >= n) { g_last_error = "pair index out of range"; return ISOCON_E_ARG; }
+    DevBuf d_prof(&s->pool, SLOT_NN_QPROF), d_sum(&s->pool, SLOT_NN_QSUM), d_a(&s->pool, SLOT_ED_TS), d_b(&s->pool, SLOT_ED_IDS), d_out(&s->pool, SLOT_ED_OUT);
+    int rc;
+    if ((rc = d_prof.alloc((size_t)n * QG_BINS)) || (rc = d_sum.alloc((size_t)n * 4)) || (rc = d_a.alloc(n_pairs * 4)) || (rc = d_b.alloc(n_pairs * 4)) ||
+        (rc = d_out.alloc(n_pairs * 4)))
+        return rc;
+    ISO_HIP_CHECK(copy_h2d(d_a.p, a, n_pairs * 4));
+    ISO_HIP_CHECK(copy_h2d(d_b.p, b, n_pairs * 4));
+    hipLaunchKernelGGL(k_qgram_profile, dim3(n), dim3(256), 0, 0, s->dev, d_prof.as<uint32_t>(), d_sum.as<uint32_t>());
+    ISO_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_qgram_lb_pairs, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, d_prof.as<uint32_t>(), d_sum.as<uint32_t>(), d_a.as<uint32_t>(),
+                       d_b.as<uint32_t>(), n_pairs, d_out.as<int32_t>());
+    ISO_HIP_CHECK(hipGetLastError());
+    ISO_HIP_CHECK(copy_d2h(out_bound, d_out.p, n_pairs * 4));
+    return ISOCON_OK;
 }
 
 #include "nn_host.inc"

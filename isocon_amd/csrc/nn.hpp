@@ -34,6 +34,9 @@ struct NNParams {
     // whose lower index it owns (own_begin + i * own_stride).  q_list == nullptr: one workgroup per entry, upward scan.
     const uint32_t *q_list;
     uint32_t own_begin, own_stride;
+    // q-gram lower bounds of the main pass' pairs (qgram.hpp; nullptr = none): lb[lb_row[launch slot] + (p - q - 1)]
+    const uint8_t *lb;
+    const unsigned long long *lb_row;
 };
 
 __device__ __forceinline__ void nn_append(const NNParams &P, bool want, int32_t e, int32_t o, int32_t d)
@@ -289,6 +292,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     } else if (pbase >= (int64_t)S.n || pbase - (int64_t)q > (int64_t)P.depth || S.lens[pbase] - m > P.kcap) return;   // uniform
     const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
     if (!q_isq && !q_ist) return;
+    const bool bounded = P.lb != nullptr && !sparse;
+    const unsigned long long lb_base = bounded ? P.lb_row[blockIdx.x] : 0ull;
     const int32_t E = (m + 192 * W + 31) & ~31;          // plane length in dwords
     {
         const uint64_t *planes = S.planes;
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     L.ztop = 0;
     uint32_t qhead = 0, qcount = 0;
     bool exhausted = false;
-    uint32_t n_pairs = 0, n_batches = 0, n_blocks = 0, n_live = 0;
+    uint32_t n_pairs = 0, n_batches = 0, n_blocks = 0, n_live = 0, n_filtered = 0;
 
     auto load5 = [](const uint32_t *p, uint32_t (&d)[5]) {
         const TextQuad t4 = *reinterpret_cast<const TextQuad *>(p);
@@ -381,6 +386,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
             if (k > P.kcap) k = P.kcap;
             const int32_t d = m - np, ad = d < 0 ? -d : d;
             bool accept = within && k >= 0 && ad <= k;
+            if (bounded) {
+                // the pair's q-gram bound proves d > k: exactly the pairs the band would have abandoned
+                const bool cand = accept;
+                if (accept) accept = (int32_t)P.lb[lb_base + (unsigned long long)(p - (int64_t)q - 1)] <= k;
+                n_filtered += (uint32_t)__popcll(__ballot(cand && !accept));
+            }
             const bool triv = accept && (m == 0 || np == 0);
             if (__ballot(triv) != 0) {
                 bool hs = false, hl = false;
@@ -516,6 +527,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     WaveAcc acc;
     acc.pairs = n_pairs; acc.tiles = n_batches; acc.cols = (unsigned long long)n_blocks * 2048ull; acc.live = (unsigned long long)n_live * 32ull;
     nn_flush_acc(P, acc);
+    if (lane == 0 && n_filtered) atomicAdd(P.stats + (size_t)NN_COUNTER_SLOTS * 4, (unsigned long long)n_filtered);
 }
 
 // Nibble store for k_nn_scan_refill: row i = [4 dwords of code 4][ceil(len_i / 8) dwords, base j at bits 4(j%8)..][zeros].

@@ -1,0 +1,156 @@
+// qgram.hpp -- q-gram count profiles and the lower bound of the edit distance they give; the main pass of the nearest-
+// neighbour search asks it before a pair gets a lane (nn.hpp, k_nn_scan_refill).
+//
+// Lemma (Ukkonen 1992, one-sided form).  G_x(g) = number of occurrences of the q-gram g in x.  One edit operation destroys at
+// most q q-gram occurrences of the string it is applied to (the q windows that contain the position; q - 1 for an insertion)
+// and creates at most q, hence with S+(x, y) = sum_g max(0, G_x(g) - G_y(g)):  S+(x, y) <= q * ed(x, y) and S+(y, x) <= q * ed(x, y)
+// (S+ obeys the triangle inequality).  With L1 = S+(x, y) + S+(y, x) and S+(x, y) - S+(y, x) = |G_x| - |G_y|:
+//        ed(x, y) >= ceil( (L1 + | |G_x| - |G_y| |) / (2 q) ).
+// Counts saturate at 255 and may be merged into fewer bins: both only shrink S+ (max(0, min(a, c) - min(b, c)) <= max(0, a - b)),
+// the identity above holds for the stored vectors, so the bound stays a bound.
+//
+// q = 6: 4096 bins, one byte each, 4 KB per sequence.  Measured on C3 (50 k reads of 2.5 kb at 1 % errors, thresholds = the
+// final nearest-neighbour distances, median 32): same-isoform pairs sit at distance ~50 and their bound at ~0.76 of it, reads of
+// other isoforms inside the +-63 length window are hundreds of edits away -- 89 % of the pairs the main pass would align have a
+// bound above their threshold.  (Presence bitsets of the same size: 0.43; q = 8 hashed into 16 K bins: 0.81 at four times the work.)
+//
+// L1 of byte vectors is v_sad_u8: four bins per lane and instruction with the accumulator as third operand.
+#pragma once
+#include "common.hpp"
+
+namespace isocon {
+
+static constexpr int QG_Q = 6;
+static constexpr int QG_BINS = 1 << (2 * QG_Q);
+static constexpr int QG_DWORDS = QG_BINS / 4;
+static constexpr int QG_QT = 32;          // entries (rows of the bound matrix) per wave of k_qgram_lb
+static constexpr int QG_CHUNK = 16;       // dwords of a profile per step
+
+// prof[i][QG_DWORDS]: byte b of dword e = min(255, occurrences of gram 4e + b in sequence i); gram index = the low code bits of
+// its q bases (bits 0..q-1) | the high code bits (bits q..2q-1).  psum[i] = sum of the stored counts.
+__global__ __launch_bounds__(256) void k_qgram_profile(DevStore S, uint32_t *__restrict__ prof, uint32_t *__restrict__ psum)
+{
+    __shared__ uint32_t hist[QG_BINS];
+    __shared__ uint32_t s_sum;
+    const uint32_t i = blockIdx.x;
+    if (i >= S.n) return;
+    for (int e = threadIdx.x; e < QG_BINS; e += 256) hist[e] = 0;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    const int32_t ngrams = S.lens[i] - QG_Q + 1;
+    for (int32_t j = threadIdx.x; j < ngrams; j += 256) {
+        const int32_t c = j >> 6, o = j & 63;
+        const size_t at = ((size_t)c * S.n + i) * 2;
+        uint64_t lo = S.planes[at] >> o, hi = S.planes[at + 1] >> o;
+        if (o > 64 - QG_Q) {
+            const size_t at2 = ((size_t)(c + 1) * S.n + i) * 2;
+            lo |= S.planes[at2] << (64 - o);
+            hi |= S.planes[at2 + 1] << (64 - o);
+        }
+        const uint32_t mask = (1u << QG_Q) - 1u;
+        atomicAdd(&hist[((uint32_t)lo & mask) | (((uint32_t)hi & mask) << QG_Q)], 1u);
+    }
+    __syncthreads();
+    uint32_t local = 0;
+    for (int e = threadIdx.x; e < QG_DWORDS; e += 256) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t c = hist[4 * e + b] < 255u ? hist[4 * e + b] : 255u;
+            v |= c << (8 * b);
+            local += c;
+        }
+        prof[(size_t)i * QG_DWORDS + e] = v;
+    }
+    atomicAdd(&s_sum, local);
+    __syncthreads();
+    if (threadIdx.x == 0) psum[i] = s_sum;
+}
+
+// Bound matrix in the main pass' own shape: row s belongs to the entry q = q_begin + s * q_stride (launch slot s of
+// k_nn_scan_refill), element e to its neighbour p = q + 1 + e, e < row_len[s]; lb[row_off[s] + e] = min(255, bound).
+// One wave = QG_QT consecutive rows x 64 neighbours (the lanes): the lane's profile goes through VGPRs QG_CHUNK dwords at a time,
+// the rows' profiles are wave-uniform (scalar loads), one accumulator per row.  The four waves of a workgroup take four
+// neighbouring lane blocks of the same rows, so the rows' chunks are in the scalar cache for three of them.
+__global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ prof, const uint32_t *__restrict__ psum,
+                                                   const unsigned long long *__restrict__ row_off, const uint32_t *__restrict__ row_len,
+                                                   uint8_t *__restrict__ lb, uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t s0 = blockIdx.x * (uint32_t)QG_QT;                     // grid: x = block of rows, y = four lane blocks
+    const uint32_t tb = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (s0 >= nq) return;
+    const uint32_t s_last = s0 + QG_QT - 1 < nq ? s0 + QG_QT - 1 : nq - 1;
+    // neighbours of the block: from the first row's first neighbour to the furthest neighbour of any row
+    const uint64_t pmin = (uint64_t)q_begin + (uint64_t)s0 * q_stride + 1;
+    uint64_t pend;              // exclusive
+    {
+        const uint32_t sl = s0 + (uint32_t)(lane & (QG_QT - 1));
+        const uint32_t s = sl <= s_last ? sl : s_last;
+        pend = (uint64_t)q_begin + (uint64_t)s * q_stride + 1 + row_len[s];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t w = ((uint64_t)(uint32_t)__shfl_xor((int)(pend >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)pend, o, 64);
+            pend = w > pend ? w : pend;
+        }
+    }
+    const uint64_t p0 = pmin + (uint64_t)tb * 64u;
+    if (p0 >= pend) return;                                   // wave-uniform
+    const uint64_t p = p0 + (uint64_t)lane;
+    const uint32_t pc = p < (uint64_t)n ? (uint32_t)p : n - 1;
+    const uint4 *trow = reinterpret_cast<const uint4 *>(prof + (size_t)pc * QG_DWORDS);
+    uint32_t acc[QG_QT];
+#pragma unroll
+    for (int qi = 0; qi < QG_QT; ++qi) acc[qi] = 0;
+    for (int c = 0; c < QG_DWORDS / QG_CHUNK; ++c) {
+        uint32_t tv[QG_CHUNK];
+#pragma unroll
+        for (int j = 0; j < QG_CHUNK / 4; ++j) {
+            const uint4 t4 = trow[c * (QG_CHUNK / 4) + j];
+            tv[4 * j] = t4.x; tv[4 * j + 1] = t4.y; tv[4 * j + 2] = t4.z; tv[4 * j + 3] = t4.w;
+        }
+#pragma unroll
+        for (int qi = 0; qi < QG_QT; ++qi) {
+            const uint32_t s = s0 + (uint32_t)qi <= s_last ? s0 + (uint32_t)qi : s_last;
+            const uint32_t *qrow = prof + ((size_t)q_begin + (size_t)s * q_stride) * QG_DWORDS + (size_t)c * QG_CHUNK;     // wave-uniform
+#pragma unroll
+            for (int j = 0; j < QG_CHUNK; ++j) acc[qi] = __builtin_amdgcn_sad_u8(tv[j], qrow[j], acc[qi]);
+        }
+    }
+    if (p >= (uint64_t)n) return;
+    const uint32_t sp = psum[p];
+#pragma unroll
+    for (int qi = 0; qi < QG_QT; ++qi) {
+        const uint32_t s = s0 + (uint32_t)qi;
+        if (s > s_last) break;
+        const uint64_t qq = (uint64_t)q_begin + (uint64_t)s * q_stride;
+        if (p <= qq) continue;
+        const uint64_t e = p - qq - 1;
+        if (e >= (uint64_t)row_len[s]) continue;
+        const uint32_t sq = psum[qq];
+        const uint32_t ds = sq > sp ? sq - sp : sp - sq;
+        const uint32_t v = (acc[qi] + ds + 2u * QG_Q - 1u) / (2u * QG_Q);
+        lb[row_off[s] + e] = (uint8_t)(v < 255u ? v : 255u);
+    }
+}
+
+// The same bound for an explicit pair list (one wave per pair; tests and diagnostics: isocon_qgram_bound_pairs).
+__global__ __launch_bounds__(256) void k_qgram_lb_pairs(const uint32_t *__restrict__ prof, const uint32_t *__restrict__ psum,
+                                                         const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n_pairs,
+                                                         int32_t *__restrict__ out)
+{
+    const uint64_t pr = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pr >= n_pairs) return;
+    const uint32_t x = a[pr], y = b[pr];
+    uint32_t acc = 0;
+    for (int e = lane; e < QG_DWORDS; e += 64) acc = __builtin_amdgcn_sad_u8(prof[(size_t)x * QG_DWORDS + e], prof[(size_t)y * QG_DWORDS + e], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, 64);
+    if (lane == 0) {
+        const uint32_t sx = psum[x], sy = psum[y];
+        out[pr] = (int32_t)((acc + (sx > sy ? sx - sy : sy - sx) + 2u * QG_Q - 1u) / (2u * QG_Q));
+    }
+}
+
+}  // namespace isocon

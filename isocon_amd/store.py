@@ -85,6 +85,17 @@ class SeqStore(object):
                                            _ptr(out, _lib.i32p), ctypes.byref(ms)), "isocon_ed_pairs")
         return (out, ms.value) if return_ms else out
 
+    def qgram_bound_pairs(self, a, b):
+        """Lower bounds of ed(a[i], b[i]) from 6-gram count profiles (csrc/qgram.hpp) -- the pre-filter of the NN main pass."""
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        if len(a) != len(b):
+            raise ValueError("pair arrays differ in length")
+        out = np.zeros(len(a), dtype=np.int32)
+        _lib.check(self._L.isocon_qgram_bound_pairs(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), len(a), _ptr(out, _lib.i32p)),
+                   "isocon_qgram_bound_pairs")
+        return out
+
     def hw_pairs(self, q, t, k, return_ms=False):
         """Infix (edlib "HW", task="path") alignment of sequence q[p] inside sequence t[p] with threshold k[p]:
         int32 [n, 5] = distance (-1 if > k), start, end, leading insertion run, trailing insertion run
