@@ -18,6 +18,7 @@
 #include "sg.hpp"
 #include "msa.hpp"
 #include "hw.hpp"
+#include "ed_lanes.hpp"
 
 namespace isocon {
 thread_local std::string g_last_error;
@@ -29,7 +30,7 @@ using namespace isocon;
 // hipMalloc/hipFree (tens of ms for the multi-GB trace scratch) every time.
 struct ScratchPool {
     struct Slot { void *p = nullptr; size_t cap = 0; };
-    Slot slots[64];
+    Slot slots[80];
     void *get(int idx, size_t bytes)
     {
         Slot &s = slots[idx];
@@ -52,14 +53,14 @@ struct ScratchPool {
 
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
-    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN,
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES,
     SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD,
     SLOT_COUNT
 };
-static_assert(SLOT_COUNT <= 64, "ScratchPool::slots too small");
+static_assert(SLOT_COUNT <= 80, "ScratchPool::slots too small");
 
 // One pool per process (one process drives one GPU): scratch outlives the individual stores, because the Python
 // wrappers create a fresh store per call (the reference's functions are stateless).
@@ -422,6 +423,53 @@ int ed_pairs_impl(isocon_store *st, const uint32_t *a, const uint32_t *b, const 
             return x < y;
         });
         std::vector<uint64_t> todo = pending, next;
+        if (W == 1) {
+            // Pairs that share their sequence with fewer than 16 others would leave most lanes of a tile empty: one pair per
+            // lane instead (ed_lanes.hpp; ~1.7x the column cost, every lane busy).  ISOCON_ED_LANES=1 / =0: all / none.
+            const char *e = getenv("ISOCON_ED_LANES");
+            const size_t min_group = e ? (atoi(e) ? (size_t)-1 : 0) : 16;
+            std::vector<uint64_t> lanes_p, tiles_p;
+            for (size_t i = 0; i < todo.size();) {
+                size_t j = i;
+                while (j < todo.size() && sh(todo[j]) == sh(todo[i])) ++j;
+                std::vector<uint64_t> &dst = (j - i) < min_group ? lanes_p : tiles_p;
+                dst.insert(dst.end(), todo.begin() + i, todo.begin() + j);
+                i = j;
+            }
+            if (!lanes_p.empty()) {
+                const size_t np = lanes_p.size();
+                std::vector<uint32_t> la(np), lb2(np);
+                std::vector<int32_t> lk(np), res(np, -1);
+                for (size_t i = 0; i < np; ++i) {
+                    const uint64_t p = lanes_p[i];
+                    la[i] = a[p]; lb2[i] = b[p];
+                    const int32_t kr = k ? k[p] : -1;
+                    lk[i] = kr < 0 ? kcap : std::min(kr, kcap);
+                }
+                DevBuf d_a(&st->pool, SLOT_ED_TS), d_b(&st->pool, SLOT_ED_IDS), d_k(&st->pool, SLOT_ED_K), d_out(&st->pool, SLOT_ED_OUT);
+                int rc;
+                if ((rc = d_a.alloc(np * 4)) || (rc = d_b.alloc(np * 4)) || (rc = d_k.alloc(np * 4)) || (rc = d_out.alloc(np * 4))) return rc;
+                ISO_HIP_CHECK(copy_h2d(d_a.p, la.data(), np * 4));
+                ISO_HIP_CHECK(copy_h2d(d_b.p, lb2.data(), np * 4));
+                ISO_HIP_CHECK(copy_h2d(d_k.p, lk.data(), np * 4));
+                NNParams none;
+                memset(&none, 0, sizeof(none));
+                tm.start();
+                hipLaunchKernelGGL(k_ed_lanes<false>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, 0, st->dev, none, d_a.as<uint32_t>(), d_b.as<uint32_t>(),
+                                   d_k.as<int32_t>(), (uint64_t)np, d_out.as<int32_t>());
+                ISO_HIP_CHECK(hipGetLastError());
+                tm.stop();
+                ISO_HIP_CHECK(copy_d2h(res.data(), d_out.p, np * 4));
+                for (size_t i = 0; i < np; ++i) {
+                    const uint64_t p = lanes_p[i];
+                    const int32_t kr = k ? k[p] : -1;
+                    if (res[i] >= 0) out_ed[p] = res[i];
+                    else if (kr >= 0 && kr <= kcap) out_ed[p] = -1;
+                    else next.push_back(p);
+                }
+            }
+            todo.swap(tiles_p);
+        }
         for (int round = 0; round < 2 && !todo.empty(); ++round) {
             // round 0: tiles of up to 64 lanes per shared sequence; round 1: one lane per tile for pairs whose
             // tile could not certify the threshold (heterogeneous length differences)

@@ -72,9 +72,15 @@ __global__ __launch_bounds__(256) void k_qgram_profile(DevStore S, uint32_t *__r
 // One wave = QG_QT consecutive rows x 64 neighbours (the lanes): the lane's profile goes through VGPRs QG_CHUNK dwords at a time,
 // the rows' profiles are wave-uniform (scalar loads), one accumulator per row.  The four waves of a workgroup take four
 // neighbouring lane blocks of the same rows, so the rows' chunks are in the scalar cache for three of them.
+//
+// rowmin / colmin (optional): the smallest bound of every row / of every neighbour column over the pairs whose roles admit an
+// edge (row entry queries the neighbour: qflag[q] && tflag[p]; the neighbour queries the row entry: qflag[p] && tflag[q]), as
+// keys (bound << 32 | e) resp. (bound << 32 | q) under atomicMin -- the seeds of the search (ed_lanes.hpp).
 __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ prof, const uint32_t *__restrict__ psum,
                                                    const unsigned long long *__restrict__ row_off, const uint32_t *__restrict__ row_len,
-                                                   uint8_t *__restrict__ lb, uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq)
+                                                   uint8_t *__restrict__ lb, uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
+                                                   const uint8_t *__restrict__ qflag, const uint8_t *__restrict__ tflag,
+                                                   unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t s0 = blockIdx.x * (uint32_t)QG_QT;                     // grid: x = block of rows, y = four lane blocks
@@ -117,21 +123,66 @@ __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ p
             for (int j = 0; j < QG_CHUNK; ++j) acc[qi] = __builtin_amdgcn_sad_u8(tv[j], qrow[j], acc[qi]);
         }
     }
-    if (p >= (uint64_t)n) return;
-    const uint32_t sp = psum[p];
+    const bool inside = p < (uint64_t)n;
+    const uint32_t sp = psum[pc];
+    const bool seeds = rowmin != nullptr;
+    const bool p_isq = seeds && inside && qflag[pc] != 0, p_ist = seeds && inside && tflag[pc] != 0;
+    unsigned long long cbest = ~0ull;
 #pragma unroll
     for (int qi = 0; qi < QG_QT; ++qi) {
         const uint32_t s = s0 + (uint32_t)qi;
-        if (s > s_last) break;
+        if (s > s_last) break;                                      // wave-uniform
         const uint64_t qq = (uint64_t)q_begin + (uint64_t)s * q_stride;
-        if (p <= qq) continue;
-        const uint64_t e = p - qq - 1;
-        if (e >= (uint64_t)row_len[s]) continue;
+        const uint64_t e = p - qq - 1;                              // wraps for p <= qq: fails the range test
+        const bool in_row = inside && p > qq && e < (uint64_t)row_len[s];
         const uint32_t sq = psum[qq];
         const uint32_t ds = sq > sp ? sq - sp : sp - sq;
-        const uint32_t v = (acc[qi] + ds + 2u * QG_Q - 1u) / (2u * QG_Q);
-        lb[row_off[s] + e] = (uint8_t)(v < 255u ? v : 255u);
+        uint32_t v = (acc[qi] + ds + 2u * QG_Q - 1u) / (2u * QG_Q);
+        v = v < 255u ? v : 255u;
+        if (in_row) lb[row_off[s] + e] = (uint8_t)v;
+        if (seeds) {
+            const bool q_isq = qflag[qq] != 0, q_ist = tflag[qq] != 0;
+            // row side: smallest (bound, lane) of the wave, then one atomic
+            uint32_t key = (in_row && q_isq && p_ist) ? ((v << 6) | (uint32_t)lane) : 0xffffffffu;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t w = (uint32_t)__shfl_xor((int)key, o, 64);
+                key = w < key ? w : key;
+            }
+            if (key != 0xffffffffu && lane == 0) {
+                const uint64_t ee = p0 + (key & 63u) - qq - 1;
+                atomicMin(rowmin + s, ((unsigned long long)(key >> 6) << 32) | (unsigned long long)ee);
+            }
+            if (in_row && p_isq && q_ist) {
+                const unsigned long long ck = ((unsigned long long)v << 32) | (unsigned long long)qq;
+                cbest = ck < cbest ? ck : cbest;
+            }
+        }
     }
+    if (seeds && cbest != ~0ull) atomicMin(colmin + p, cbest);
+}
+
+// Seed pairs from the smallest bounds: entry x with the neighbour of its row minimum (if x owns a row) and with the row entry of
+// its column minimum, unless that row's own minimum is this very pair.  pa / pb hold 2 n slots, 0xffffffff = none.
+__global__ __launch_bounds__(256) void k_qgram_seed_pairs(const unsigned long long *__restrict__ rowmin, const unsigned long long *__restrict__ colmin,
+                                                           uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
+                                                           uint32_t *__restrict__ pa, uint32_t *__restrict__ pb)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= n) return;
+    uint32_t a0 = 0xffffffffu, b0 = 0xffffffffu, a1 = 0xffffffffu, b1 = 0xffffffffu;
+    if (x >= q_begin && (x - q_begin) % q_stride == 0 && (x - q_begin) / q_stride < nq) {
+        const unsigned long long kr = rowmin[(x - q_begin) / q_stride];
+        if (kr != ~0ull) { a0 = x; b0 = x + 1u + (uint32_t)kr; }
+    }
+    const unsigned long long kc = colmin[x];
+    if (kc != ~0ull) {
+        const uint32_t q = (uint32_t)kc;               // a row entry: q = q_begin + s * q_stride by construction
+        const unsigned long long kq = rowmin[(q - q_begin) / q_stride];
+        if (kq == ~0ull || q + 1u + (uint32_t)kq != x) { a1 = q; b1 = x; }
+    }
+    pa[2 * (size_t)x] = a0; pb[2 * (size_t)x] = b0;
+    pa[2 * (size_t)x + 1] = a1; pb[2 * (size_t)x + 1] = b1;
 }
 
 // The same bound for an explicit pair list (one wave per pair; tests and diagnostics: isocon_qgram_bound_pairs).

@@ -101,3 +101,57 @@ def test_empty_and_tiny():
     assert st.ed_pairs([], [], None).tolist() == []
     assert st.ed_pairs([0, 0, 0, 2, 3], [0, 1, 2, 3, 3], None).tolist() == [0, 1, 1, 78, 0]
     assert st.ed_pairs([0, 2], [1, 3], [0, 10]).tolist() == [-1, -1]
+
+
+def test_one_pair_per_lane_kernel_equals_the_oracle(monkeypatch):
+    """k_ed_lanes (csrc/ed_lanes.hpp): scattered pairs, every threshold 0..63 and unbounded, lengths from 0 to 3 kb, both
+    orientations of the length difference, pairs far beyond the threshold."""
+    import random
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    rng = random.Random(17)
+
+    def mutate(s, e):
+        s = list(s)
+        for _ in range(e):
+            r = rng.random()
+            p = rng.randrange(len(s) + 1)
+            if r < 0.4 and s:
+                s[min(p, len(s) - 1)] = rng.choice("ACGT")
+            elif r < 0.7:
+                s.insert(p, rng.choice("ACGT"))
+            elif s:
+                del s[min(p, len(s) - 1)]
+        return "".join(s)
+
+    seqs = ["", "A", "C", "ACGT", "ACGTACGTAC"]
+    for L in (30, 63, 64, 65, 130, 700, 1500, 3000):
+        base = "".join(rng.choice("ACGT") for _ in range(L))
+        seqs.append(base)
+        for e in (0, 1, 2, 5, 17, 40, 62, 63, 64, 90):
+            seqs.append(mutate(base, e))
+    n = len(seqs)
+    a = np.array([rng.randrange(n) for _ in range(6000)], dtype=np.uint32)
+    b = np.array([rng.randrange(n) for _ in range(6000)], dtype=np.uint32)
+    # bias towards related pairs (same base block)
+    for i in range(0, 6000, 2):
+        blk = 5 + 11 * rng.randrange(8)
+        a[i] = blk + rng.randrange(11); b[i] = blk + rng.randrange(11)
+    k = np.array([rng.choice([-1, -1, 0, 1, 2, 3, 7, 20, 31, 32, 33, 50, 62, 63]) for _ in range(6000)], dtype=np.int32)
+    monkeypatch.setenv("ISOCON_ED_LANES", "1")
+    st = SeqStore(seqs)
+    try:
+        got = st.ed_pairs(a, b, k)
+        got_u = st.ed_pairs(a, b, None)
+    finally:
+        st.close()
+    want = O.ed_pairs(seqs, a, b, k)
+    want_u = O.ed_pairs(seqs, a, b, None)
+    assert (got == want).all(), np.nonzero(got != want)[0][:10]
+    assert (got_u == want_u).all()
+    monkeypatch.setenv("ISOCON_ED_LANES", "0")
+    st = SeqStore(seqs)
+    try:
+        assert (st.ed_pairs(a, b, k) == want).all()
+    finally:
+        st.close()
