@@ -25,6 +25,7 @@ static constexpr int QG_BINS = 1 << (2 * QG_Q);
 static constexpr int QG_DWORDS = QG_BINS / 4;
 static constexpr int QG_QT = 32;          // entries (rows of the bound matrix) per wave of k_qgram_lb
 static constexpr int QG_CHUNK = 16;       // dwords of a profile per step
+static constexpr unsigned QG_RUN = 4;     // consecutive row blocks per XCD (k_qgram_lb)
 
 // prof[i][QG_DWORDS]: byte b of dword e = min(255, occurrences of gram 4e + b in sequence i); gram index = the low code bits of
 // its q bases (bits 0..q-1) | the high code bits (bits q..2q-1).  psum[i] = sum of the stored counts.
@@ -76,14 +77,22 @@ __global__ __launch_bounds__(256) void k_qgram_profile(DevStore S, uint32_t *__r
 // rowmin / colmin (optional): the smallest bound of every row / of every neighbour column over the pairs whose roles admit an
 // edge (row entry queries the neighbour: qflag[q] && tflag[p]; the neighbour queries the row entry: qflag[p] && tflag[q]), as
 // keys (bound << 32 | e) resp. (bound << 32 | q) under atomicMin -- the seeds of the search (ed_lanes.hpp).
+//
+// Workgroup order: the hardware deals consecutive workgroups to the 8 XCDs in turn (each with its own L2).  Row blocks that
+// follow each other share 7/8 of their lanes' profiles, so an XCD gets RUNS of consecutive row blocks (what one workgroup pulled
+// into that L2 is what the next ones on the same XCD need), the runs dealt round robin (one contiguous range per XCD was 1.6x
+// slower: the windows, hence the work per row block, differ too much along the length order).  grid.x is a multiple of 8 * QG_RUN.
 __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ prof, const uint32_t *__restrict__ psum,
                                                    const unsigned long long *__restrict__ row_off, const uint32_t *__restrict__ row_len,
                                                    uint8_t *__restrict__ lb, uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
                                                    const uint8_t *__restrict__ qflag, const uint8_t *__restrict__ tflag,
-                                                   unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin)
+                                                   unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin, uint32_t run)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t s0 = blockIdx.x * (uint32_t)QG_QT;                     // grid: x = block of rows, y = four lane blocks
+    // grid: x = block of rows, y = four lane blocks.  XCD x takes runs of QG_RUN consecutive row blocks, the runs dealt round robin
+    const uint32_t wi = blockIdx.x >> 3;
+    const uint32_t sb = ((wi / run) * 8u + (blockIdx.x & 7u)) * run + wi % run;
+    const uint32_t s0 = sb * (uint32_t)QG_QT;
     const uint32_t tb = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (s0 >= nq) return;
     const uint32_t s_last = s0 + QG_QT - 1 < nq ? s0 + QG_QT - 1 : nq - 1;
@@ -104,23 +113,55 @@ __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ p
     if (p0 >= pend) return;                                   // wave-uniform
     const uint64_t p = p0 + (uint64_t)lane;
     const uint32_t pc = p < (uint64_t)n ? (uint32_t)p : n - 1;
-    const uint4 *trow = reinterpret_cast<const uint4 *>(prof + (size_t)pc * QG_DWORDS);
     uint32_t acc[QG_QT];
 #pragma unroll
     for (int qi = 0; qi < QG_QT; ++qi) acc[qi] = 0;
+    // The rows' chunks are scalar loads.  Scalar loads return out of order, the only wait there is is "all of them", and the
+    // compiler puts that wait right behind every load.  Hand-placed instead: the chunk of the NEXT row is requested before the
+    // 16 v_sad_u8 of the current row and waited for after them (the asm operands only pin that order).
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    static_assert(QG_CHUNK == 16, "one s_load_dwordx16 per row and step");
+    auto row_ptr = [&](int c, int qi) -> const uint32_t * {
+        const uint32_t s = s0 + (uint32_t)qi <= s_last ? s0 + (uint32_t)qi : s_last;
+        return prof + ((size_t)q_begin + (size_t)s * q_stride) * QG_DWORDS + (size_t)c * QG_CHUNK;                  // wave-uniform
+    };
+    // rows two at a time, their instructions interleaved: consecutive v_sad_u8 never wait for each other's result
+    u32x16 cur0, cur1;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(cur0), "=&s"(cur1) : "s"(row_ptr(0, 0)), "s"(row_ptr(0, 1)) : "memory");
+    // the lane's own profile: 64 contiguous bytes per step (a 16-byte-interleaved layout that makes the wave's loads contiguous
+    // was 20 % slower), the next step's bytes requested before this step's arithmetic
+    const uint4 *trow = reinterpret_cast<const uint4 *>(prof + (size_t)pc * QG_DWORDS);
+    uint4 tn[QG_CHUNK / 4];
+#pragma unroll
+    for (int j = 0; j < QG_CHUNK / 4; ++j) tn[j] = trow[j];
     for (int c = 0; c < QG_DWORDS / QG_CHUNK; ++c) {
         uint32_t tv[QG_CHUNK];
 #pragma unroll
-        for (int j = 0; j < QG_CHUNK / 4; ++j) {
-            const uint4 t4 = trow[c * (QG_CHUNK / 4) + j];
-            tv[4 * j] = t4.x; tv[4 * j + 1] = t4.y; tv[4 * j + 2] = t4.z; tv[4 * j + 3] = t4.w;
+        for (int j = 0; j < QG_CHUNK / 4; ++j) { tv[4 * j] = tn[j].x; tv[4 * j + 1] = tn[j].y; tv[4 * j + 2] = tn[j].z; tv[4 * j + 3] = tn[j].w; }
+        if (c + 1 < QG_DWORDS / QG_CHUNK) {
+#pragma unroll
+            for (int j = 0; j < QG_CHUNK / 4; ++j) tn[j] = trow[(c + 1) * (QG_CHUNK / 4) + j];
         }
 #pragma unroll
-        for (int qi = 0; qi < QG_QT; ++qi) {
-            const uint32_t s = s0 + (uint32_t)qi <= s_last ? s0 + (uint32_t)qi : s_last;
-            const uint32_t *qrow = prof + ((size_t)q_begin + (size_t)s * q_stride) * QG_DWORDS + (size_t)c * QG_CHUNK;     // wave-uniform
+        for (int qi = 0; qi < QG_QT; qi += 2) {
+            const int cn = qi + 2 < QG_QT ? c : (c + 1 < QG_DWORDS / QG_CHUNK ? c + 1 : c);
+            const int qn = qi + 2 < QG_QT ? qi + 2 : 0;
+            u32x16 nxt0, nxt1;
+            asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0"
+                         : "=&s"(nxt0), "=&s"(nxt1), "+v"(tv[0]) : "s"(row_ptr(cn, qn)), "s"(row_ptr(cn, qn + 1)) : "memory");
+            uint32_t a = acc[qi], b = acc[qi + 1], a2 = 0, b2 = 0;      // four independent chains
 #pragma unroll
-            for (int j = 0; j < QG_CHUNK; ++j) acc[qi] = __builtin_amdgcn_sad_u8(tv[j], qrow[j], acc[qi]);
+            for (int j = 0; j < QG_CHUNK; j += 2) {
+                a = __builtin_amdgcn_sad_u8(tv[j], cur0[j], a);
+                b = __builtin_amdgcn_sad_u8(tv[j], cur1[j], b);
+                a2 = __builtin_amdgcn_sad_u8(tv[j + 1], cur0[j + 1], a2);
+                b2 = __builtin_amdgcn_sad_u8(tv[j + 1], cur1[j + 1], b2);
+            }
+            a += a2; b += b2;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt0), "+s"(nxt1), "+v"(a), "+v"(b));
+            acc[qi] = a; acc[qi + 1] = b;
+            cur0 = nxt0; cur1 = nxt1;
         }
     }
     const bool inside = p < (uint64_t)n;

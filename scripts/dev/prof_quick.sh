@@ -1,0 +1,9 @@
+#!/bin/bash
+# quick look: kernel-trace stats + SQ counters of a short bench run (GPU box)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-q}
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pq_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/pq_$TAG.json 2> $R/gpurun_out/pq_$TAG.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $R/gpurun_out/pqc_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pqc_$TAG.err
+find $R/gpurun_out/pq_$TAG -name "*kernel_stats.csv" | head -1 | xargs cat | cut -c1-200 | head -12
