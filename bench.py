@@ -16,7 +16,8 @@ value depends on nr_cores through the chunk-local seed dictionary, NNG:112,125-1
 baseline and the GPU, and is computable from the result alone.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel k_nn_scan_refill (main pass).  Integer bit-vector DP with the query in LDS and the
+  roofline      dominant kernel k_nn_scan_refill (main pass: the pairs that survive the q-gram bound; `bound_pass` = the
+                kernel that computes the bounds, k_qgram_lb, with the same two fractions).  Integer bit-vector DP with the query in LDS and the
                 neighbours in L2 / Infinity Cache: neither HBM nor MFMA binds it, VALU issue does.  `frac` = VALU
                 wave-instructions / s (SQ_INSTS_VALU of the dispatch, profiles/counters.json, scaled to this run by the
                 kernel's own wave-column counter, divided by the live HIP-event time of the launch) against the
@@ -298,11 +299,12 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    main_ms, seed_ms, all_ms = [], [], []
+    main_ms, seed_ms, all_ms, bound_ms = [], [], [], []
     for _ in range(args.steps):
         step()
         main_ms.append(sum(x.get("scan_kernel_ms", 0.0) for x in last["stats"]))      # HIP events on the kernels' own stream (EventTimer, csrc/common.hpp)
         seed_ms.append(sum(x.get("seed_kernel_ms", 0.0) for x in last["stats"]))
+        bound_ms.append(sum(x.get("bound_kernel_ms", 0.0) for x in last["stats"]))
         all_ms.append(sum(x.get("kernel_ms", 0.0) for x in last["stats"]))
     sync()
     dt = time.perf_counter() - t0
@@ -320,14 +322,23 @@ def main():
     value = n_align / (ms_per_step / 1e3)
 
     # ---- roofline of the dominant kernel on this rank --------------------------------------------------------------
-    st0 = {k: sum(x.get(k, 0) for x in last["stats"]) for k in ("pairs_evaluated", "cells_columns")}   # this rank, all phases
+    st0 = {k: sum(x.get(k, 0) for x in last["stats"]) for k in ("pairs_evaluated", "cells_columns", "pairs_prefiltered")}   # this rank, all phases
     pairs_eval = int(st0["pairs_evaluated"])
     wave_cols = float(st0["cells_columns"]) / 64.0            # 64-lane DP columns executed (main + seed pass)
     mean_len = float(lens.mean())
     k_ms = float(np.mean(main_ms)) if main_ms else 0.0
     s_ms = float(np.mean(seed_ms)) if seed_ms else 0.0
+    b_ms = float(np.mean(bound_ms)) if bound_ms else 0.0
     is_default = (args.reads, args.length, args.isoforms, args.seed) == (50000, 2500, 10, 30001)
     ctr = load_counters()
+    # second kernel of the step: q-gram bounds of every pair of the length window (k_qgram_lb), same two fractions
+    cb = ctr.get("nn_bound", {})
+    bound_pass = None
+    if cb.get("SQ_INSTS_VALU") and b_ms > 0 and is_default and world == 1:
+        bound_pass = {"kernel": cb.get("kernel", "k_qgram_lb")[:40], "valu_insts_per_launch": float(cb["SQ_INSTS_VALU"]),
+                      "valu_frac": float(cb["SQ_INSTS_VALU"]) / (b_ms / 1e3) / VALU_PEAK_WAVE_INSTR,
+                      "hbm_frac": (float(cb["hbm_bytes"]) / (b_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if cb.get("hbm_bytes") else None,
+                      "note": "bound_pass_ms also holds the profile kernel (0.3 ms)"}
     cm = ctr.get("nn_main", {})
     insts = traffic = None
     if cm.get("SQ_INSTS_VALU") and cm.get("wave_columns"):
@@ -343,7 +354,8 @@ def main():
     roofline = {"bound": "valu", "kernel": cm.get("kernel", "k_nn_scan_refill<8,1>") + " (main pass of one step)",
                 "achieved": achieved, "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instr/s",
                 "frac": achieved / VALU_PEAK_WAVE_INSTR if achieved else None, "traffic": traffic,
-                "kernel_ms": k_ms, "seed_pass_ms": s_ms, "valu_insts_per_launch": insts,
+                "kernel_ms": k_ms, "seed_pass_ms": s_ms, "bound_pass_ms": b_ms, "bound_pass": bound_pass, "valu_insts_per_launch": insts,
+                "pairs_aligned": pairs_eval, "pairs_rejected_by_qgram_bound": int(st0["pairs_prefiltered"]),
                 "valu_insts_source": "profiles/counters.json (rocprofv3 --pmc SQ_INSTS_VALU, %s)%s" % (ctr.get("round", "?"), "" if (is_default and world == 1) else " scaled by this run's wave-columns"),
                 "wave_columns_per_launch": wave_cols, "wave_columns_per_s": wave_cols / ((k_ms + s_ms) / 1e3) if (k_ms + s_ms) > 0 else None,
                 "hbm": {"achieved": traffic / (k_ms / 1e3) / 1e9 if traffic and k_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -12,7 +12,7 @@ def show(tag, stats, wall):
     print("%-34s wall %6.1f ms  main %6.1f  seed %5.1f  bounds %5.1f | pairs %.3e prefiltered %.3e | wave-cols %.3e live %.3f"
           % (tag, wall, stats["scan_kernel_ms"], stats["seed_kernel_ms"], stats["bound_kernel_ms"], stats["pairs_evaluated"], stats["pairs_prefiltered"],
              stats["cells_columns"] / 64.0, stats["live_columns"] / max(stats["cells_columns"], 1)), flush=True)
-for waves in ("8", "4", "2"):
+for waves in sys.argv[1:] or ("8", "4", "2"):
     os.environ["ISOCON_NN_WAVES"] = waves
     for rep in range(2):
         t0 = time.perf_counter(); best, rp, cols, stats = st.nn_graph(); wall = (time.perf_counter() - t0) * 1e3

@@ -66,8 +66,10 @@ def classify(rows):
     for r in rows:
         if "k_nn_scan_refill" in r[1] and "nn_main" not in cls:
             cls["nn_main"] = [r]
-        if "k_nn_scan_up<1>" in r[1] and "nn_seed" not in cls:
+        if ("k_ed_lanes<true>" in r[1] or "k_nn_scan_up<1>" in r[1]) and "nn_seed" not in cls:
             cls["nn_seed"] = [r]
+        if "k_qgram_lb" in r[1] and "k_qgram_lb_pairs" not in r[1] and "nn_bound" not in cls:
+            cls["nn_bound"] = [r]
     if sg_full:
         cls["sg_full"] = sg_full
     if sg_banded:
