@@ -61,3 +61,16 @@ for q, bins in ((6, 4096), (7, 8192), (7, 16384), (8, 8192), (8, 16384), (8, 327
     print("q=%2d bits=%5d  LB/d median (d<=80) %.2f;  of pairs with 36<d<=80: LB>32: %.2f  LB>36: %.2f  LB>40: %.2f ; of d>80: LB>40: %.2f  LB>63: %.2f"
           % (q, bins, np.median((lb / np.maximum(d, 1))[near]),
              (lb[near & (d > 36)] > 32).mean(), (lb[near & (d > 36)] > 36).mean(), (lb[near & (d > 36)] > 40).mean(), (lb[~near] > 40).mean(), (lb[~near] > 63).mean()))
+
+print("capped counts (thermometer-coded bit planes, XOR + popcount):")
+for cap in (255, 4, 3, 2, 1):
+    prof = {}
+    for idx in set(rows[:, 0]) | set(rows[:, 1]):
+        prof[idx] = np.minimum(profile(seqs[idx], 6, 4096), cap)
+    lb = np.array([np.abs(prof[i] - prof[j]).sum() + abs(int(prof[i].sum()) - int(prof[j].sum())) for i, j, _ in rows]) / 12.0
+    lb = np.ceil(lb - 1e-9)
+    d = rows[:, 2]
+    assert (lb <= d).all()
+    near = d <= 80
+    print("cap=%3d  LB/d median (d<=80) %.3f;  of pairs with 36<d<=80: LB>32: %.2f  LB>36: %.2f  LB>40: %.2f" %
+          (cap, np.median((lb / np.maximum(d, 1))[near]), (lb[near & (d > 36)] > 32).mean(), (lb[near & (d > 36)] > 36).mean(), (lb[near & (d > 36)] > 40).mean()))
