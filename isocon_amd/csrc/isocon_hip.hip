@@ -53,7 +53,7 @@ struct ScratchPool {
 
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
-    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B,
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_SLOTORDER, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES,
@@ -66,7 +66,20 @@ static_assert(SLOT_COUNT <= 80, "ScratchPool::slots too small");
 // wrappers create a fresh store per call (the reference's functions are stateless).
 static ScratchPool g_scratch;
 
+// The q-gram bound matrix of the last isocon_nn_partial seed phase (slots SLOT_NN_LB / SLOT_NN_LBROW of the scratch pool): the main
+// phase of the SAME store and shard that follows uses it instead of computing it again.  Identified by the store's serial number (not
+// its address), overwritten by every build, dropped with the scratch.
+struct BoundTag {
+    bool valid = false;
+    uint64_t serial = 0;
+    uint32_t q_begin = 0, q_end = 0, q_stride = 0, depth = 0;
+    int32_t kcap = 0;
+};
+static BoundTag g_bound_tag;
+static uint64_t g_store_serial = 0;
+
 struct isocon_store {
+    uint64_t serial = ++g_store_serial;
     DevStore dev;
     ScratchPool &pool = g_scratch;
     std::vector<int32_t> lens;   // host copy
@@ -222,7 +235,7 @@ int isocon_device_count(void)
     return n;
 }
 
-void isocon_release_scratch(void) { g_scratch.release(); g_stage.release(); }
+void isocon_release_scratch(void) { g_scratch.release(); g_stage.release(); g_bound_tag.valid = false; }
 
 int isocon_init(int device_ordinal)
 {

@@ -37,6 +37,7 @@ struct NNParams {
     // q-gram lower bounds of the main pass' pairs (qgram.hpp; nullptr = none): lb[lb_row[launch slot] + (p - q - 1)]
     const uint8_t *lb;
     const unsigned long long *lb_row;
+    const uint32_t *slot_order;    // launch slot handled by workgroup i (nullptr: i itself): entries with the widest windows first
 };
 
 __device__ __forceinline__ void nn_append(const NNParams &P, bool want, int32_t e, int32_t o, int32_t d)
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
     const bool sparse = P.q_list != nullptr;
-    const uint64_t q64 = sparse ? (uint64_t)P.q_list[blockIdx.x] : (uint64_t)q_begin + (uint64_t)blockIdx.x * q_stride;
+    const uint32_t slot = (!sparse && P.slot_order != nullptr) ? P.slot_order[blockIdx.x] : blockIdx.x;
+    const uint64_t q64 = sparse ? (uint64_t)P.q_list[blockIdx.x] : (uint64_t)q_begin + (uint64_t)slot * q_stride;
     if (q64 >= (uint64_t)q_end) return;
     const uint32_t q = (uint32_t)q64;
     const int32_t m = S.lens[q];
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
     if (!q_isq && !q_ist) return;
     const bool bounded = P.lb != nullptr && !sparse;
-    const unsigned long long lb_base = bounded ? P.lb_row[blockIdx.x] : 0ull;
+    const unsigned long long lb_base = bounded ? P.lb_row[slot] : 0ull;
     const int32_t E = (m + 192 * W + 31) & ~31;          // plane length in dwords
     {
         const uint64_t *planes = S.planes;

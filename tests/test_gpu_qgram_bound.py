@@ -108,14 +108,18 @@ def test_sharded_phases_with_the_filter():
         best = np.full(n, _lib.NN_INF, np.int32)
         hits_all = []
         filtered = 0
+        reused = 0
         for phase in (0, 1, 2):
             parts = []
-            for r in range(3):
+            for r in ((0, 1, 2) if phase != 1 else (2, 0, 1)):
                 b = best.copy()
                 hits, stats = st.nn_partial(r, n, phase, b, depth=400, q_stride=3)
                 filtered += stats.get("pairs_prefiltered", 0)
+                # the main phase that directly follows its own shard's seed phase finds the bound matrix still in place
+                reused += phase == 1 and stats["pairs_prefiltered"] > 0 and stats["bound_kernel_ms"] == 0
                 hits_all.append(hits); parts.append(b)
             best = np.minimum.reduce(parts)
+        assert reused == 1
         hits = np.concatenate(hits_all)
         out = nn_finalize(n, best, hits)
         assert filtered > 0
