@@ -83,6 +83,16 @@ def test_graph_with_the_filter_is_the_graph_without_it_and_the_filter_is_used():
         assert stats0["pairs_prefiltered"] == 0
         assert stats["pairs_evaluated"] < stats0["pairs_evaluated"]
         assert (best == best0).all() and (row_ptr == row_ptr0).all() and (cols == cols0).all()
+        # the bounds with the 64-neighbour seed pass instead of the smallest-bound seeds, and the other workgroup shapes / orders
+        for env in ({"ISOCON_NN_OLD_SEED": "1"}, {"ISOCON_NN_WAVES": "8"}, {"ISOCON_NN_ORDER": "0"}, {"ISOCON_NN_ORDER": "1", "ISOCON_QG_RUN": "1"}):
+            os.environ.update(env)
+            try:
+                b2, r2, c2, s2 = st.nn_graph(is_converged=conv)
+            finally:
+                for k in env:
+                    del os.environ[k]
+            assert s2["pairs_prefiltered"] > 0
+            assert (best == b2).all() and (row_ptr == r2).all() and (cols == c2).all(), env
         # the same with a finite depth and a strided shard (the row layout follows the launch slots)
         is_t = np.zeros(len(seqs), np.uint8); is_t[::5] = 1
         g1 = st.nn_graph(is_target=is_t)
