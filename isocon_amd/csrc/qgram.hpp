@@ -25,7 +25,6 @@ static constexpr int QG_BINS = 1 << (2 * QG_Q);
 static constexpr int QG_DWORDS = QG_BINS / 4;
 static constexpr int QG_QT = 32;          // entries (rows of the bound matrix) per wave of k_qgram_lb
 static constexpr int QG_CHUNK = 16;       // dwords of a profile per step
-static constexpr unsigned QG_RUN = 4;     // consecutive row blocks per XCD (k_qgram_lb)
 
 // prof[i][QG_DWORDS]: byte b of dword e = min(255, occurrences of gram 4e + b in sequence i); gram index = the low code bits of
 // its q bases (bits 0..q-1) | the high code bits (bits q..2q-1).  psum[i] = sum of the stored counts.
@@ -77,23 +76,26 @@ __global__ __launch_bounds__(256) void k_qgram_profile(DevStore S, uint32_t *__r
 // rowmin / colmin (optional): the smallest bound of every row / of every neighbour column over the pairs whose roles admit an
 // edge (row entry queries the neighbour: qflag[q] && tflag[p]; the neighbour queries the row entry: qflag[p] && tflag[q]), as
 // keys (bound << 32 | e) resp. (bound << 32 | q) under atomicMin -- the seeds of the search (ed_lanes.hpp).
-//
-// Workgroup order: the hardware deals consecutive workgroups to the 8 XCDs in turn (each with its own L2).  Row blocks that
-// follow each other share 7/8 of their lanes' profiles, so an XCD gets RUNS of consecutive row blocks (what one workgroup pulled
-// into that L2 is what the next ones on the same XCD need), the runs dealt round robin (one contiguous range per XCD was 1.6x
-// slower: the windows, hence the work per row block, differ too much along the length order).  grid.x is a multiple of 8 * QG_RUN.
 __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ prof, const uint32_t *__restrict__ psum,
                                                    const unsigned long long *__restrict__ row_off, const uint32_t *__restrict__ row_len,
                                                    uint8_t *__restrict__ lb, uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
                                                    const uint8_t *__restrict__ qflag, const uint8_t *__restrict__ tflag,
-                                                   unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin, uint32_t run)
+                                                   unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin,
+                                                   const uint32_t *__restrict__ chunk_off, uint32_t n_chunks)
 {
     const int lane = threadIdx.x & 63;
-    // grid: x = block of rows, y = four lane blocks.  XCD x takes runs of QG_RUN consecutive row blocks, the runs dealt round robin
-    const uint32_t wi = blockIdx.x >> 3;
-    const uint32_t sb = ((wi / run) * 8u + (blockIdx.x & 7u)) * run + wi % run;
+    // 1-D grid over the workgroups that have work: row blocks in chunks of 8, chunk c owns the ids [chunk_off[c], chunk_off[c + 1]),
+    // id - chunk_off[c] = 8 * (group of four lane blocks) + (row block inside the chunk).  The hardware deals consecutive ids to the 8
+    // XCDs in turn, so XCD j works through the lane blocks of ONE row block of the chunk (its rows stay in that L2 / scalar cache).
+    uint32_t lo = 0, hi = n_chunks;                          // chunk_off[lo] <= id < chunk_off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk_off[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const uint32_t rid = blockIdx.x - chunk_off[lo];
+    const uint32_t sb = lo * 8u + (rid & 7u);
     const uint32_t s0 = sb * (uint32_t)QG_QT;
-    const uint32_t tb = blockIdx.y * 4u + (threadIdx.x >> 6);
+    const uint32_t tb = (rid >> 3) * 4u + (threadIdx.x >> 6);
     if (s0 >= nq) return;
     const uint32_t s_last = s0 + QG_QT - 1 < nq ? s0 + QG_QT - 1 : nq - 1;
     // neighbours of the block: from the first row's first neighbour to the furthest neighbour of any row
