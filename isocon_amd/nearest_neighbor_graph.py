@@ -72,14 +72,18 @@ def _graph(st, seqs, is_converged=None, is_target=None, depth=2 ** 32):
 
 def _rows_to_dict(accs, is_query, best, row_ptr, cols):
     out = {}
-    cols = cols.tolist()
+    nbr = [accs[c] for c in cols.tolist()]            # neighbour accessions in CSR order: rows are slices of it
     row_ptr = row_ptr.tolist()
     best = best.tolist()
+    fromkeys = dict.fromkeys
+    if bool(np.all(is_query)):
+        for i, acc in enumerate(accs):
+            out[acc] = fromkeys(nbr[row_ptr[i]:row_ptr[i + 1]], best[i])
+        return out
     for i, acc in enumerate(accs):
         if not is_query[i]:
             continue
-        d = best[i]
-        out[acc] = {accs[c]: d for c in cols[row_ptr[i]:row_ptr[i + 1]]}
+        out[acc] = fromkeys(nbr[row_ptr[i]:row_ptr[i + 1]], best[i])
     return out
 
 

@@ -24,7 +24,7 @@ class SeqStore(object):
     def __init__(self, seqs):
         L = _lib.lib()
         self.n = len(seqs)
-        lens = np.fromiter((len(s) for s in seqs), dtype=np.uint64, count=self.n)
+        lens = np.fromiter(map(len, seqs), dtype=np.uint64, count=self.n)
         self.lens = lens.astype(np.int64)
         off = np.zeros(self.n + 1, dtype=np.uint64)
         np.cumsum(lens, out=off[1:])
