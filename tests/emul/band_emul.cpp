@@ -108,3 +108,19 @@ extern "C" void emul_band_tile(int W, const char *pat, int m, int nl, const char
     default: for (int l = 0; l < nl; ++l) out[l] = -99;
     }
 }
+
+// One pair per lane (isocon_amd/csrc/ed_lanes_core.hpp, the routine of k_ed_lanes): pattern x, text y, threshold 0 <= k <= 63.
+// Returns what the kernel's lane would: the distance if <= k, else -1 (|m - n| > k and empty sequences are the caller's cases).
+#include "../../isocon_amd/csrc/ed_lanes_core.hpp"
+
+extern "C" int32_t emul_ed_lane(const char *x, int m, const char *y, int n, int k)
+{
+    const int d = m - n, ad = d < 0 ? -d : d;
+    if (k < 0 || ad > k) return -1;
+    if (m == 0 || n == 0) return ad;
+    std::vector<uint64_t> xl, xh, yl, yh;
+    pack(x, m, xl, xh);
+    pack(y, n, yl, yh);
+    auto f = [](const std::vector<uint64_t> &v) { return [&v](int32_t ci) -> uint64_t { return ci >= 0 && ci < (int)v.size() ? v[ci] : 0; }; };
+    return lane_pair_distance(f(xl), f(xh), f(yl), f(yh), m, n, k > 63 ? 63 : k, true, [](bool b) { return b; });
+}

@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "emul", "_band_emul.so")
 SRC = os.path.join(HERE, "emul", "band_emul.cpp")
 CORE = os.path.join(os.path.dirname(HERE), "isocon_amd", "csrc", "band_core.hpp")
+CORE2 = os.path.join(os.path.dirname(HERE), "isocon_amd", "csrc", "ed_lanes_core.hpp")
 
 
 # Every case runs twice: on the plain build and on a -fsanitize=undefined build of the same sources (the lane-level headers
@@ -23,7 +24,7 @@ CORE = os.path.join(os.path.dirname(HERE), "isocon_amd", "csrc", "band_core.hpp"
 def emul(request):
     so = SO if request.param == "plain" else SO.replace(".so", "_ubsan.so")
     flags = ["-O2"] if request.param == "plain" else ["-O1", "-g", "-fsanitize=undefined", "-fno-sanitize-recover=all", "-static-libubsan"]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [SRC, CORE]):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [SRC, CORE, CORE2]):
         subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, SRC])
     return ctypes.CDLL(so)
 
@@ -93,3 +94,25 @@ def test_single_lane_tiles_are_always_determined(emul):
         r = run_tile(emul, W, pat, [t], [k])[0]
         d = O.ed_dp(pat, t)
         assert r == (d if d <= k else -1)
+
+
+def test_one_pair_per_lane_routine_against_dp(emul):
+    """lane_pair_distance (csrc/ed_lanes_core.hpp, what k_ed_lanes runs per lane): 96-bit plane registers, per-lane band origin,
+    masked first blocks and text tails -- every threshold 0..63, lengths around the 32- and 64-column boundaries, both signs of the
+    length difference."""
+    emul.emul_ed_lane.restype = ctypes.c_int32
+    rng = random.Random(29)
+    cases = 0
+    for L in (1, 2, 5, 31, 32, 33, 63, 64, 65, 95, 96, 97, 128, 200, 700):
+        for _ in range(40):
+            x = "".join(rng.choice("ACGT") for _ in range(L))
+            y = _mut(rng, x, rng.choice([0.0, 0.02, 0.1, 0.3]))
+            if rng.random() < 0.3:
+                x, y = y, x
+            if rng.random() < 0.1:
+                y = "".join(rng.choice("ACGT") for _ in range(max(1, len(x) + rng.randint(-5, 5))))
+            for k in (0, 1, 2, 7, 31, 32, 33, 62, 63, rng.randint(0, 63)):
+                got = emul.emul_ed_lane(x.encode(), len(x), y.encode(), len(y), k)
+                assert got == O.ed_bounded(x, y, k), (x, y, k, got)
+                cases += 1
+    assert cases > 5000
