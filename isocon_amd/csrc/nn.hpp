@@ -237,8 +237,10 @@ __global__ __launch_bounds__(256) void k_filter_hits(const int32_t *__restrict__
 // sequence, 32 virtual codes in front of every sequence, zeros behind it): a block is 5 consecutive dwords funnel-
 // shifted by the lane's constant nibble phase.
 //
-// Neighbours are drawn 64 at a time from a workgroup-wide counter, filtered (roles, |length difference| <= threshold)
-// with coalesced loads, and queued in a small per-wave ring in LDS.
+// Neighbours are drawn 64 at a time from a workgroup-wide counter, filtered (roles, |length difference| <= threshold and,
+// when the launch comes with them, the pair's q-gram lower bound <= threshold: qgram.hpp) with coalesced loads, and queued
+// in a small per-wave ring in LDS.  With the bounds the host launches 4 waves per table instead of 8 (nn_host.inc) and may
+// hand the workgroups their entries widest window first (P.slot_order).
 static constexpr int NN_RING = 96;       // entries per wave (8 B each)
 static constexpr int NN_TEXT_PAD_FRONT = 4, NN_TEXT_PAD_BACK = 6;     // dwords around each sequence of the nibble store
 
