@@ -70,7 +70,7 @@ static ScratchPool g_scratch;
 // phase of the SAME store and shard that follows uses it instead of computing it again.  Identified by the store's serial number (not
 // its address), overwritten by every build, dropped with the scratch.
 struct BoundTag {
-    bool valid = false;
+    bool valid = false, has_order = false;
     uint64_t serial = 0;
     uint32_t q_begin = 0, q_end = 0, q_stride = 0, depth = 0;
     int32_t kcap = 0;
