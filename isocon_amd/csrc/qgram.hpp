@@ -123,14 +123,16 @@ __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ p
     // 16 v_sad_u8 of the current row and waited for after them (the asm operands only pin that order).
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
     static_assert(QG_CHUNK == 16, "one s_load_dwordx16 per row and step");
-    auto row_ptr = [&](int c, int qi) -> const uint32_t * {
-        const uint32_t s = s0 + (uint32_t)qi <= s_last ? s0 + (uint32_t)qi : s_last;
-        return prof + ((size_t)q_begin + (size_t)s * q_stride) * QG_DWORDS + (size_t)c * QG_CHUNK;                  // wave-uniform
-    };
+    // Row addresses are base + row * stride, with no clamp at the last row block (prof is allocated QG_QT * q_stride rows beyond the
+    // last sequence; what is read there is never used): a table of 32 clamped addresses cost 64 SGPRs, spilled the row chunks into
+    // VGPRs (a v_mov per dword and row) and their addresses into VGPR lanes -- a fifth of the kernel's VALU instructions.
+    // The address walks with the loads (one running pointer, kept opaque so that it is not turned back into a table).
+    const uint32_t *rp = prof + ((size_t)q_begin + (size_t)s0 * q_stride) * QG_DWORDS;             // row 0 of the block, chunk 0
+    const size_t rstride = (size_t)q_stride * QG_DWORDS;
     // rows two at a time, their instructions interleaved: consecutive v_sad_u8 never wait for each other's result
     u32x16 cur0, cur1;
     asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(cur0), "=&s"(cur1) : "s"(row_ptr(0, 0)), "s"(row_ptr(0, 1)) : "memory");
+                 : "=&s"(cur0), "=&s"(cur1) : "s"(rp), "s"(rp + rstride) : "memory");
     // the lane's own profile: 64 contiguous bytes per step (a 16-byte-interleaved layout that makes the wave's loads contiguous
     // was 20 % slower), the next step's bytes requested before this step's arithmetic
     const uint4 *trow = reinterpret_cast<const uint4 *>(prof + (size_t)pc * QG_DWORDS);
@@ -147,11 +149,13 @@ __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ p
         }
 #pragma unroll
         for (int qi = 0; qi < QG_QT; qi += 2) {
-            const int cn = qi + 2 < QG_QT ? c : (c + 1 < QG_DWORDS / QG_CHUNK ? c + 1 : c);
-            const int qn = qi + 2 < QG_QT ? qi + 2 : 0;
+            // next: the following two rows of this chunk, after the block's last rows the first two rows of the next chunk
+            if (qi + 2 < QG_QT) rp += 2 * rstride;
+            else rp = rp - (size_t)(QG_QT - 2) * rstride + (c + 1 < QG_DWORDS / QG_CHUNK ? QG_CHUNK : 0);
+            asm volatile("" : "+s"(rp));
             u32x16 nxt0, nxt1;
             asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %4, 0x0"
-                         : "=&s"(nxt0), "=&s"(nxt1), "+v"(tv[0]) : "s"(row_ptr(cn, qn)), "s"(row_ptr(cn, qn + 1)) : "memory");
+                         : "=&s"(nxt0), "=&s"(nxt1), "+v"(tv[0]) : "s"(rp), "s"(rp + rstride) : "memory");
             uint32_t a = acc[qi], b = acc[qi + 1], a2 = 0, b2 = 0;      // four independent chains
 #pragma unroll
             for (int j = 0; j < QG_CHUNK; j += 2) {
