@@ -178,7 +178,7 @@ ISO_HD void band_step_eq(BandLane<W> &L, const uint64_t (&EQ)[W])
         d0p = d0;
     }
     uint64_t d0s = d0p >> 1;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ISOCON_NO_SHIFT_PIN)
     asm("" : "+v"(d0s));
 #endif
     L.VP[W - 1] = or_nor(hnp, d0s, hpp);
