@@ -67,6 +67,22 @@ __global__ __launch_bounds__(256) void k_qgram_profile(DevStore S, uint32_t *__r
     if (threadIdx.x == 0) psum[i] = s_sum;
 }
 
+// min over the 64 lanes, in every lane: the DPP row shifts / row broadcasts of gfx9 (VALU only; six ds_bpermute round trips per
+// reduction through __shfl_xor otherwise, 32 reductions per tile)
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v0)
+{
+    const int id = -1;                                          // 0xffffffff: neutral for the unsigned minimum
+    auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+    uint32_t v = mn(v0, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v0, 0x111, 0xf, 0xf, false));     // row_shr:1
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v0, 0x112, 0xf, 0xf, false));               // row_shr:2
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v0, 0x113, 0xf, 0xf, false));               // row_shr:3
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xf, 0xe, false));                // row_shr:4
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x118, 0xf, 0xc, false));                // row_shr:8
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xa, 0xf, false));                // row_bcast:15
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xc, 0xf, false));                // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Bound matrix in the main pass' own shape: row s belongs to the entry q = q_begin + s * q_stride (launch slot s of
 // k_nn_scan_refill), element e to its neighbour p = q + 1 + e, e < row_len[s]; lb[row_off[s] + e] = min(255, bound).
 // One wave = QG_QT consecutive rows x 64 neighbours (the lanes): the lane's profile goes through VGPRs QG_CHUNK dwords at a time,
@@ -191,11 +207,7 @@ __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ p
             const bool q_isq = qflag[qq] != 0, q_ist = tflag[qq] != 0;
             // row side: smallest (bound, lane) of the wave, then one atomic
             uint32_t key = (in_row && q_isq && p_ist) ? ((v << 6) | (uint32_t)lane) : 0xffffffffu;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t w = (uint32_t)__shfl_xor((int)key, o, 64);
-                key = w < key ? w : key;
-            }
+            key = wave_min_u32_dpp(key);
             if (key != 0xffffffffu && lane == 0) {
                 const uint64_t ee = p0 + (key & 63u) - qq - 1;
                 atomicMin(rowmin + s, ((unsigned long long)(key >> 6) << 32) | (unsigned long long)ee);
