@@ -191,20 +191,37 @@ __global__ __launch_bounds__(256) void k_qgram_lb(const uint32_t *__restrict__ p
     const bool seeds = rowmin != nullptr;
     const bool p_isq = seeds && inside && qflag[pc] != 0, p_ist = seeds && inside && tflag[pc] != 0;
     unsigned long long cbest = ~0ull;
+    // the rows' scalars (length and offset of the row, sum and roles of its entry): lane i fetches row i's, the loop below reads them
+    // back with v_readlane (as 32 x 5 scalar loads they were hoisted to the top and spilled)
+    uint32_t m_len = 0, m_sum = 0, m_flags = 0, m_off_lo = 0, m_off_hi = 0;
+    {
+        const uint32_t sl = s0 + (uint32_t)(lane & (QG_QT - 1));
+        const uint32_t s = sl <= s_last ? sl : s_last;
+        const uint64_t qq = (uint64_t)q_begin + (uint64_t)s * q_stride;
+        m_len = row_len[s];
+        m_sum = psum[qq];
+        const unsigned long long ro = row_off[s];
+        m_off_lo = (uint32_t)ro; m_off_hi = (uint32_t)(ro >> 32);
+        if (seeds) m_flags = (qflag[qq] != 0 ? 1u : 0u) | (tflag[qq] != 0 ? 2u : 0u);
+    }
 #pragma unroll
     for (int qi = 0; qi < QG_QT; ++qi) {
         const uint32_t s = s0 + (uint32_t)qi;
         if (s > s_last) break;                                      // wave-uniform
         const uint64_t qq = (uint64_t)q_begin + (uint64_t)s * q_stride;
         const uint64_t e = p - qq - 1;                              // wraps for p <= qq: fails the range test
-        const bool in_row = inside && p > qq && e < (uint64_t)row_len[s];
-        const uint32_t sq = psum[qq];
+        const uint32_t r_len = (uint32_t)__builtin_amdgcn_readlane((int)m_len, qi);
+        const bool in_row = inside && p > qq && e < (uint64_t)r_len;
+        const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)m_sum, qi);
         const uint32_t ds = sq > sp ? sq - sp : sp - sq;
         uint32_t v = (acc[qi] + ds + 2u * QG_Q - 1u) / (2u * QG_Q);
         v = v < 255u ? v : 255u;
-        if (in_row) lb[row_off[s] + e] = (uint8_t)v;
+        const unsigned long long r_off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m_off_hi, qi) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)m_off_lo, qi);
+        if (in_row) lb[r_off + e] = (uint8_t)v;
         if (seeds) {
-            const bool q_isq = qflag[qq] != 0, q_ist = tflag[qq] != 0;
+            const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)m_flags, qi);
+            const bool q_isq = (fl & 1u) != 0, q_ist = (fl & 2u) != 0;
             // row side: smallest (bound, lane) of the wave, then one atomic
             uint32_t key = (in_row && q_isq && p_ist) ? ((v << 6) | (uint32_t)lane) : 0xffffffffu;
             key = wave_min_u32_dpp(key);
