@@ -70,7 +70,7 @@ int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const
                     int32_t *out_ed, float *kernel_ms);
 
 /*
- * Lower bounds of the pairs' edit distances from 6-gram count profiles (isocon_amd/csrc/qgram.hpp):
+ * Lower bounds of the pairs' edit distances from q-gram count profiles (8-grams hashed into 6144 bins, isocon_amd/csrc/qgram.hpp):
  * out_bound[p] <= ed(a[p], b[p]) always.  The main pass of the nearest-neighbour search skips a pair whose bound exceeds its
  * threshold -- the pair edlib would have answered with -1 (modules/nearest_neighbor_graph.py:156-162).  The reference has no
  * counterpart; exposed so that the bound can be tested by itself.

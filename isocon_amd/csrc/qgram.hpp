@@ -6,13 +6,17 @@
 // and creates at most q, hence with S+(x, y) = sum_g max(0, G_x(g) - G_y(g)):  S+(x, y) <= q * ed(x, y) and S+(y, x) <= q * ed(x, y)
 // (S+ obeys the triangle inequality).  With L1 = S+(x, y) + S+(y, x) and S+(x, y) - S+(y, x) = |G_x| - |G_y|:
 //        ed(x, y) >= ceil( (L1 + | |G_x| - |G_y| |) / (2 q) ).
-// Counts saturate at 255 and may be merged into fewer bins: both only shrink S+ (max(0, min(a, c) - min(b, c)) <= max(0, a - b)),
+// Counts saturate at 255 and may be merged into fewer bins (here: hashed): both only shrink S+ (max(0, min(a, c) - min(b, c)) <= max(0, a - b)),
 // the identity above holds for the stored vectors, so the bound stays a bound.
 //
-// q = 6: 4096 bins, one byte each, 4 KB per sequence.  Measured on C3 (50 k reads of 2.5 kb at 1 % errors, thresholds = the
-// final nearest-neighbour distances, median 32): same-isoform pairs sit at distance ~50 and their bound at ~0.76 of it, reads of
-// other isoforms inside the +-63 length window are hundreds of edits away -- 89 % of the pairs the main pass would align have a
-// bound above their threshold.  (Presence bitsets of the same size: 0.43; q = 8 hashed into 16 K bins: 0.81 at four times the work.)
+// q = 8, the 65 536 gram codes hashed into 6144 byte-wide bins (6 KB per sequence).  Measured on C3 (50 k reads of 2.5 kb at 1 %
+// errors, thresholds = the final nearest-neighbour distances, median 32; scripts/dev/qgram_filter_estimate.py): same-isoform pairs
+// sit at distance ~50, reads of other isoforms inside the +-63 length window are hundreds of edits away.  Share of the pairs the main
+// pass would align whose bound exceeds their threshold / whole step in ms (bound kernel + main pass):
+//     6-grams, 4096 bins (exact)  89.3 %  61.5 ms (11.5 + 47.7)       8-grams, 4096 bins  91.2 %  56.2 ms (11.5 + 42.4)
+//     8-grams, 6144 bins          94.5 %  53.6 ms (17.8 + 33.4)       8-grams, 8192 bins  95.4 %  57.0 ms (24.2 + 30.5)
+// (presence bitsets of 4 KB: nothing rejected; 9- and 10-grams: as 8-grams; the bound kernel's cost is proportional to the bins, the
+// main pass loses lane balance as its pairs get fewer.)
 //
 // L1 of byte vectors is v_sad_u8: four bins per lane and instruction with the accumulator as third operand.
 #pragma once
@@ -20,8 +24,8 @@
 
 namespace isocon {
 
-static constexpr int QG_Q = 6;
-static constexpr int QG_BINS = 1 << (2 * QG_Q);
+static constexpr int QG_Q = 8;
+static constexpr int QG_BINS = 6144;      // the 4^q gram codes hashed into this many bins (merging bins keeps the bound a bound)
 static constexpr int QG_DWORDS = QG_BINS / 4;
 static constexpr int QG_QT = 32;          // entries (rows of the bound matrix) per wave of k_qgram_lb
 static constexpr int QG_CHUNK = 16;       // dwords of a profile per step
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(256) void k_qgram_profile(DevStore S, uint32_t *__r
             hi |= S.planes[at2 + 1] << (64 - o);
         }
         const uint32_t mask = (1u << QG_Q) - 1u;
-        atomicAdd(&hist[((uint32_t)lo & mask) | (((uint32_t)hi & mask) << QG_Q)], 1u);
+        const uint32_t g = ((uint32_t)lo & mask) | (((uint32_t)hi & mask) << QG_Q);
+        atomicAdd(&hist[QG_BINS == (1 << (2 * QG_Q)) ? g : ((g * 0x9E3779B1u) >> 7) % (uint32_t)QG_BINS], 1u);
     }
     __syncthreads();
     uint32_t local = 0;

@@ -27,7 +27,7 @@ def profile(s, q, bins):
 
 rng = np.random.default_rng(1)
 sample = rng.choice(len(seqs), 120, replace=False)
-for q, bins in ((5, 1024), (6, 4096), (8, 16384)):
+for q, bins in ((8, 4096), (8, 6144), (8, 8192), (8, 12288), (9, 8192), (10, 8192)):
     t0 = time.time()
     cache = {}
     def P(i):

@@ -9,7 +9,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-Q = 6
+Q = 8
+BINS = 6144
 
 
 def profile(s):
@@ -19,12 +20,14 @@ def profile(s):
     c = code[np.frombuffer(s.encode(), np.uint8)]
     ng = len(c) - Q + 1
     if ng <= 0:
-        return np.zeros(4096, np.int64)
+        return np.zeros(BINS, np.int64)
     idx = np.zeros(ng, np.int64)
     for i in range(Q):
         idx |= (c[i:i + ng] & 1) << i
         idx |= (c[i:i + ng] >> 1) << (Q + i)
-    return np.minimum(np.bincount(idx, minlength=4096), 255)
+    if BINS != 4 ** Q:
+        idx = (((idx * 0x9E3779B1) & 0xffffffff) >> 7) % BINS
+    return np.minimum(np.bincount(idx, minlength=BINS), 255)
 
 
 def bound(pa, pb):

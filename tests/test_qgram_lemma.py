@@ -10,22 +10,26 @@ from oracle import oracle as O
 Q = 6
 
 
-def profile(s, cap=255):
+def profile(s, cap=255, q=Q, bins=None):
+    """counts of the q-grams; bins: hash the 4^q gram codes into that many bins (the kernel's choice: q = 8, 6144 bins)"""
     code = np.zeros(256, np.int64)
     code[ord("C")] = 1; code[ord("G")] = 2; code[ord("T")] = 3
     c = code[np.frombuffer(s.encode(), np.uint8)]
-    ng = len(c) - Q + 1
+    ng = len(c) - q + 1
+    nb = bins or 4 ** q
     if ng <= 0:
-        return np.zeros(4096, np.int64)
+        return np.zeros(nb, np.int64)
     idx = np.zeros(ng, np.int64)
-    for i in range(Q):
+    for i in range(q):
         idx |= (c[i:i + ng] & 1) << i
-        idx |= (c[i:i + ng] >> 1) << (Q + i)
-    return np.minimum(np.bincount(idx, minlength=4096), cap)
+        idx |= (c[i:i + ng] >> 1) << (q + i)
+    if bins:
+        idx = (((idx * 0x9E3779B1) & 0xffffffff) >> 7) % bins
+    return np.minimum(np.bincount(idx, minlength=nb), cap)
 
 
-def bound(pa, pb):
-    return int((np.abs(pa - pb).sum() + abs(int(pa.sum()) - int(pb.sum())) + 2 * Q - 1) // (2 * Q))
+def bound(pa, pb, q=Q):
+    return int((np.abs(pa - pb).sum() + abs(int(pa.sum()) - int(pb.sum())) + 2 * q - 1) // (2 * q))
 
 
 def _edits(rng, s, e, kinds="sid"):
@@ -69,6 +73,11 @@ def test_bound_never_exceeds_the_edit_distance():
     merged = [p.reshape(1024, 4).sum(axis=1) for p in prof]
     lbm = np.array([bound(merged[i], merged[j]) for i, j in zip(a, b)])
     assert (lbm <= d).all() and (lbm <= lb).all()
+    # the kernel's parameters: 8-grams hashed into 6144 bins
+    prof8 = [profile(s, q=8, bins=6144) for s in seqs]
+    lb8 = np.array([bound(prof8[i], prof8[j], q=8) for i, j in zip(a, b)])
+    assert (lb8 <= d).all(), [(seqs[a[i]][:30], seqs[b[i]][:30], int(lb8[i]), int(d[i])) for i in np.nonzero(lb8 > d)[0][:3]]
+    assert (lb8[a == b] == 0).all()
     # and it is not vacuous (short sequences with dense edits included; 0.76 on 2.5 kb reads at 1 % errors)
     rel = (d > 0) & (d <= 60)
     assert np.median(lb[rel] / d[rel]) > 0.4
