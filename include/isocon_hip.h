@@ -70,12 +70,22 @@ int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const
                     int32_t *out_ed, float *kernel_ms);
 
 /*
- * Lower bounds of the pairs' edit distances from q-gram count profiles (8-grams hashed into 6144 bins, isocon_amd/csrc/qgram.hpp):
- * out_bound[p] <= ed(a[p], b[p]) always.  The main pass of the nearest-neighbour search skips a pair whose bound exceeds its
- * threshold -- the pair edlib would have answered with -1 (modules/nearest_neighbor_graph.py:156-162).  The reference has no
- * counterpart; exposed so that the bound can be tested by itself.
+ * Lower bounds of the pairs' edit distances from q-gram count profiles (isocon_amd/csrc/qgram_mm.hpp: 9-grams hashed into 16384
+ * presence bins plus 2 levels of 2048 excess bins): out_bound[p] <= ed(a[p], b[p]) always.  The main pass of the
+ * nearest-neighbour search skips a pair whose bound exceeds its threshold -- the pair edlib would have answered with -1
+ * (modules/nearest_neighbor_graph.py:156-162).  The reference has no counterpart; exposed so that the bound can be tested by itself.
  */
 int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound);
+
+/*
+ * The bound matrix the main pass of isocon_nn_graph / isocon_nn_partial consults for the shard q_begin, q_begin + q_stride, ... < q_end
+ * (length-sorted store), read back for tests: row r belongs to the entry q = q_begin + r * q_stride, its bytes
+ * out_bounds[out_row_ptr[r] .. out_row_ptr[r + 1]) are min(255, bound) of the pairs (q, p), p = q + 1, q + 2, ... while
+ * len(p) - len(q) <= 63 and p - q <= depth (the pairs the upward scan of modules/nearest_neighbor_graph.py:136-153 can reach within
+ * 63 edits).  out_row_ptr has (number of rows + 1) entries.  ISOCON_E_CAPACITY + *n_bounds_needed when bounds_cap is too small.
+ */
+int isocon_qgram_bound_matrix(isocon_store *s, uint32_t q_begin, uint32_t q_end, uint32_t q_stride, uint64_t depth,
+                              uint64_t *out_row_ptr, uint8_t *out_bounds, uint64_t bounds_cap, uint64_t *n_bounds_needed);
 
 /* statistics block filled by the nearest-neighbour entry points (all counters are for the one call) */
 typedef struct {

@@ -13,7 +13,7 @@
 #include "common.hpp"
 #include "ed_band.hpp"
 #include "ed_full.hpp"
-#include "qgram.hpp"
+#include "qgram_mm.hpp"
 #include "nn.hpp"
 #include "sg.hpp"
 #include "msa.hpp"
@@ -585,7 +585,7 @@ extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_
     return ed_pairs_impl(s, a, b, k, n_pairs, out_ed, kernel_ms, nullptr);
 }
 
-// q-gram lower bounds of explicit pairs (qgram.hpp): what the main pass of the NN search consults, exposed for tests
+// q-gram lower bounds of explicit pairs (qgram_mm.hpp): what the main pass of the NN search consults, exposed for tests
 extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound)
 {
     if (!s || (n_pairs && (!a || !b || !out_bound))) return ISOCON_E_ARG;
@@ -593,16 +593,18 @@ extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, cons
     const uint32_t n = s->dev.n;
     for (uint64_t i = 0; i < n_pairs; ++i)
         if (a[i] >= n || b[i] >= n) { g_last_error = "pair index out of range"; return ISOCON_E_ARG; }
+    const uint32_t n_pad = std::max<uint32_t>(QM_TILE, ((n + QM_TILE - 1) / QM_TILE) * QM_TILE);
     DevBuf d_prof(&s->pool, SLOT_NN_QPROF), d_sum(&s->pool, SLOT_NN_QSUM), d_a(&s->pool, SLOT_ED_TS), d_b(&s->pool, SLOT_ED_IDS), d_out(&s->pool, SLOT_ED_OUT);
     int rc;
-    if ((rc = d_prof.alloc((size_t)n * QG_BINS)) || (rc = d_sum.alloc((size_t)n * 4)) || (rc = d_a.alloc(n_pairs * 4)) || (rc = d_b.alloc(n_pairs * 4)) ||
+    if ((rc = d_prof.alloc((size_t)n_pad * (QM_K / 2))) || (rc = d_sum.alloc((size_t)n * 4)) || (rc = d_a.alloc(n_pairs * 4)) || (rc = d_b.alloc(n_pairs * 4)) ||
         (rc = d_out.alloc(n_pairs * 4)))
         return rc;
+    g_bound_tag.valid = false;          // the profile slot is shared with the bound matrix builds
     ISO_HIP_CHECK(copy_h2d(d_a.p, a, n_pairs * 4));
     ISO_HIP_CHECK(copy_h2d(d_b.p, b, n_pairs * 4));
-    hipLaunchKernelGGL(k_qgram_profile, dim3(n), dim3(256), 0, 0, s->dev, d_prof.as<uint32_t>(), d_sum.as<uint32_t>());
+    hipLaunchKernelGGL(k_qgram_profile4, dim3(n), dim3(256), 0, 0, s->dev, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad);
     ISO_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_qgram_lb_pairs, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, d_prof.as<uint32_t>(), d_sum.as<uint32_t>(), d_a.as<uint32_t>(),
+    hipLaunchKernelGGL(k_qgram_lb_pairs, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad, d_a.as<uint32_t>(),
                        d_b.as<uint32_t>(), n_pairs, d_out.as<int32_t>());
     ISO_HIP_CHECK(hipGetLastError());
     ISO_HIP_CHECK(copy_d2h(out_bound, d_out.p, n_pairs * 4));

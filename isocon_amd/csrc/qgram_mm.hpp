@@ -1,0 +1,417 @@
+// qgram_mm.hpp -- q-gram count bounds of the nearest-neighbour search as a tiled contraction on the matrix cores.
+//
+// Lemma (Ukkonen 1992, one-sided form).  G_x(g) = number of occurrences of the q-gram g in x.  One edit operation destroys at
+// most q q-gram occurrences of the string it is applied to and creates at most q, hence with
+// S+(x, y) = sum_g max(0, G_x(g) - G_y(g)):  S+(x, y) <= q ed(x, y) and S+(y, x) <= q ed(x, y).  Any map of the count vectors
+// that never increases S+ keeps that true.  The maps used here, each applied to both strings alike:
+//   * merging bins (the 4^q gram codes are hashed into QG_B0 bins):     max(0, sum a - sum b) <= sum max(0, a - b);
+//   * splitting a count into PRESENCE [a > 0] and EXCESS (a - 1)^+:     S+ is unchanged (check the cases a > b = 0, a > b >= 1, a <= b);
+//   * merging the excess counts into QG_B1 coarser bins (bin mod QG_B1) and capping them at QG_CAP:  both only shrink S+.
+// With A = the stored vector of x, |A| its sum and M(x, y) = sum min(A, B):  S+(x, y) = |A| - M, so
+//        ed(x, y) >= ceil( (max(|A|, |B|) - M(x, y)) / q ).
+// M is a DOT PRODUCT of thermometer codes: min(a, b) = sum_t [a > t][b > t].  A profile is therefore stored as QM_K = QG_B0 +
+// QG_B1 * QG_CAP binary elements (presence bits, then QG_CAP levels of the excess bins), the bound matrix of the main pass is
+// (profiles) x (profiles)^T restricted to the length window -- a banded A B^T -- and runs on v_mfma_scale_f32_32x32x64_f8f6f4
+// with fp4 operands (1.0 = 0x2, unit scales; sums of at most QM_K ones are exact in f32): 2048 MAC per cycle and SIMD, twice
+// the i8 rate, at 4 bits per element (scripts/ubench/mfma_fp4.hip: operand layout checked with asymmetric data, 40 cycles per
+// MFMA at the nominal clock).  The v_sad_u8 kernel this replaces moved 308 B per pair and took 17.6 ms at C3.
+//
+// Parameters (scripts/dev/qgram_mm_study.py, C3, final thresholds; survivors per query / K): 8-grams in 6144 byte bins, what the
+// v_sad_u8 kernel used: 396; uniform thermometer 6144 x 3: 456 / 18432; 16384 x 2: 271 / 32768; see DESIGN.md for the mixed designs.
+#pragma once
+#include "common.hpp"
+
+namespace isocon {
+
+static constexpr int QG_Q = 9;            // gram length
+static constexpr int QG_B0 = 16384;       // presence bins (the 4^q gram codes hashed into them)
+static constexpr int QG_B1 = 2048;        // excess bins (presence bin mod QG_B1)
+static constexpr int QG_CAP = 2;          // levels kept of an excess bin
+static constexpr int QM_K = QG_B0 + QG_B1 * QG_CAP;     // binary elements per profile
+static constexpr int QM_KBE = 128;        // elements per K-block: 64 B per row (4 slots of 16 B = 32 fp4 elements)
+static constexpr int QM_ROWB = QM_KBE / 2;
+static constexpr int QM_SLOTS = QM_ROWB / 16;
+static constexpr int QM_NKB = QM_K / QM_KBE;
+static constexpr int QM_TILE = 256;       // rows and columns of the bound matrix per workgroup
+static constexpr int QM_STAGES = 4;       // LDS ring: QM_STAGES x 2 operands x 256 rows x 64 B = 128 KB
+static constexpr int QM_STAGE_BYTES = 2 * QM_TILE * QM_ROWB;
+static constexpr int QM_OUT_STRIDE = QM_TILE + 8;       // bytes per row of the epilogue's byte tile in LDS (66 dwords: 2-way on the dword writes)
+static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 2 * 16 * 2 + 256 * 4;
+static constexpr size_t QM_LDS_BYTES = (size_t)QM_STAGES * QM_STAGE_BYTES + QM_META_BYTES;
+static_assert(QG_B0 % 128 == 0 && QG_B1 % 256 == 0 && QG_B0 % QG_B1 == 0, "K-blocks of 128 elements; excess bin = presence bin mod QG_B1");
+static_assert(QM_K % QM_KBE == 0 && QM_NKB >= QM_STAGES, "whole K-blocks");
+static_assert(QM_TILE * QM_OUT_STRIDE <= QM_STAGES * QM_STAGE_BYTES, "the epilogue's byte tile reuses the ring");
+
+__host__ __device__ __forceinline__ uint32_t qg_bin(uint32_t g)
+{
+    return (QG_B0 == (1 << (2 * QG_Q))) ? g : ((g * 0x9E3779B1u) >> 7) % (uint32_t)QG_B0;
+}
+
+// 8 bits -> 8 fp4 elements (1.0 = 0x2 per set bit)
+__device__ __forceinline__ uint32_t qg_spread8(uint32_t x)
+{
+    uint32_t y = (x | (x << 12)) & 0x000F000Fu;
+    y = (y | (y << 6)) & 0x03030303u;
+    y = (y | (y << 3)) & 0x11111111u;
+    return y << 1;
+}
+
+// prof4[kb][row][QM_ROWB]: the 128 elements kb * 128 .. + 127 of every profile, 4 bits each (n_pad rows per K-block);
+// psum[i] = sum of the stored vector.  One workgroup per sequence: presence bitset + excess counters in LDS.
+__global__ __launch_bounds__(256) void k_qgram_profile4(DevStore S, uint8_t *__restrict__ prof4, uint32_t *__restrict__ psum, uint32_t n_pad)
+{
+    __shared__ uint32_t bits[QM_K / 32];            // presence bits, then QG_CAP level bitsets of the excess bins
+    __shared__ uint32_t exh[QG_B1];
+    __shared__ uint32_t s_sum;
+    const uint32_t i = blockIdx.x;
+    if (i >= S.n) return;
+    for (int e = threadIdx.x; e < QM_K / 32; e += 256) bits[e] = 0;
+    for (int e = threadIdx.x; e < QG_B1; e += 256) exh[e] = 0;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    const int32_t ngrams = S.lens[i] - QG_Q + 1;
+    for (int32_t j = threadIdx.x; j < ngrams; j += 256) {
+        const int32_t c = j >> 6, o = j & 63;
+        const size_t at = ((size_t)c * S.n + i) * 2;
+        uint64_t lo = S.planes[at] >> o, hi = S.planes[at + 1] >> o;
+        if (o > 64 - QG_Q) {
+            const size_t at2 = ((size_t)(c + 1) * S.n + i) * 2;
+            lo |= S.planes[at2] << (64 - o);
+            hi |= S.planes[at2 + 1] << (64 - o);
+        }
+        const uint32_t mask = (1u << QG_Q) - 1u;
+        const uint32_t bin = qg_bin(((uint32_t)lo & mask) | (((uint32_t)hi & mask) << QG_Q));
+        const uint32_t bit = 1u << (bin & 31u);
+        const uint32_t old = atomicOr(&bits[bin >> 5], bit);
+        if (old & bit) atomicAdd(&exh[bin % (uint32_t)QG_B1], 1u);       // every occurrence after the first is excess
+    }
+    __syncthreads();
+    // level bitsets of the excess bins: one ballot per 64 bins and level
+    for (int j0 = (threadIdx.x & ~63); j0 < QG_B1; j0 += 256) {
+        const uint32_t v = exh[j0 + (threadIdx.x & 63)];
+#pragma unroll
+        for (int t = 0; t < QG_CAP; ++t) {
+            const unsigned long long m = __ballot(v > (uint32_t)t);
+            if ((threadIdx.x & 63) == 0) {
+                bits[(QG_B0 + t * QG_B1 + j0) / 32] = (uint32_t)m;
+                bits[(QG_B0 + t * QG_B1 + j0) / 32 + 1] = (uint32_t)(m >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t local = 0;
+    for (int c = threadIdx.x; c < QM_K / 32; c += 256) {
+        const uint32_t w = bits[c];
+        local += (uint32_t)__popc(w);
+        uint4 o;
+        o.x = qg_spread8(w & 0xffu); o.y = qg_spread8((w >> 8) & 0xffu); o.z = qg_spread8((w >> 16) & 0xffu); o.w = qg_spread8(w >> 24);
+        *reinterpret_cast<uint4 *>(prof4 + ((size_t)(c / QM_SLOTS) * n_pad + i) * QM_ROWB + (size_t)(c % QM_SLOTS) * 16) = o;
+    }
+    atomicAdd(&s_sum, local);
+    __syncthreads();
+    if (threadIdx.x == 0) psum[i] = s_sum;
+}
+
+typedef int qm_v8i __attribute__((ext_vector_type(8)));
+typedef float qm_v16f __attribute__((ext_vector_type(16)));
+
+// LDS-DMA of 16 B per lane: LDS destination = lds_dst (wave-uniform byte address) + 16 * lane.  hipcc does not model the
+// statement (cdna_hip_programming.md 5.7): the ring below counts its own vmcnt, and the compiler's ds_reads carry no wait for it.
+__device__ __forceinline__ void qm_glds16(const uint8_t *gsrc, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// One workgroup = one 256 x 256 tile of the bound matrix: columns = the entries p = 256 J .. + 255 (operand A), rows = the launch
+// slots s = 256 I .. + 255 of the main pass, i.e. the entries q = q_begin + s * q_stride (operand B).  8 waves, wave (wp, wq) owns
+// 128 p x 64 q = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator registers).  The profiles stream through a ring of QM_STAGES K-blocks
+// in LDS (LDS-DMA, prefetch distance QM_STAGES - 1, one barrier per K-block); a row of a K-block is 4 slots of 16 B, slot sl of
+// tile row r sits at physical slot sl ^ ((r >> 2) & 3), which makes the ds_read_b128 of a fragment (32 rows x one slot, 16 lanes
+// per LDS cycle) conflict-free; the swizzle is applied to the global source address, the LDS image stays lane-linear.
+// Any k-permutation that is the same for A and B leaves the dot products unchanged, so a lane simply takes 16 consecutive bytes.
+//
+// Epilogue: bound = min(255, ceil((max(|A|, |B|) - M) / q)) as bytes into an LDS tile [q][p], then (1) 16-byte stores into the
+// main pass' row layout lb[row_off[s] + (p - q - 1)] -- the host aligns the rows so that the address of p is congruent to p
+// mod 16 -- and the smallest admissible bound of every row (rowmin), (2) the smallest admissible bound of every column (colmin);
+// keys as in k_qgram_seed_pairs.
+__global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__ prof4, const uint32_t *__restrict__ psum, uint32_t n, uint32_t n_pad,
+                                                      const uint2 *__restrict__ tiles, const unsigned long long *__restrict__ row_off,
+                                                      const uint32_t *__restrict__ row_len, uint8_t *__restrict__ lb, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
+                                                      const uint8_t *__restrict__ qflag, const uint8_t *__restrict__ tflag,
+                                                      unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t qm_lds[];
+    // tile table entry of this workgroup: ids b, b + 8, b + 16, ... share an XCD (round-robin dispatch), and the 32 of them that
+    // are resident together take the 32 tiles of one super-tile (its operands meet in that XCD's L2)
+    const uint32_t b = blockIdx.x;
+    const uint2 tl = tiles[(((b >> 3) >> 5) * 8u + (b & 7u)) * 32u + ((b >> 3) & 31u)];
+    if (tl.x == 0xffffffffu) return;
+    const uint32_t I = tl.x, J = tl.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    uint8_t *meta = qm_lds + (size_t)QM_STAGES * QM_STAGE_BYTES;
+    uint32_t *m_sA = reinterpret_cast<uint32_t *>(meta);                  // |A| of the 256 columns
+    uint32_t *m_sB = m_sA + 256;                                          // |B| of the 256 rows
+    uint32_t *m_q = m_sB + 256;                                           // entry of the row's slot, 0xffffffff = no such slot
+    uint32_t *m_len = m_q + 256;                                          // row length
+    unsigned long long *m_off = reinterpret_cast<unsigned long long *>(m_len + 256);
+    uint32_t *m_flB = reinterpret_cast<uint32_t *>(m_off + 256);          // roles of the row entries: bit 0 query, bit 1 target
+    uint16_t *m_tA = reinterpret_cast<uint16_t *>(m_flB + 256);           // per 16 columns: target flags, query flags
+    uint16_t *m_qA = m_tA + 16;
+    uint32_t *m_cm = reinterpret_cast<uint32_t *>(m_qA + 16);             // column minima of the tile (bound << 8 | row)
+
+    if (tid < 256) {
+        const uint64_t p = (uint64_t)J * QM_TILE + tid;
+        m_sA[tid] = p < n ? psum[p] : 0u;
+        m_cm[tid] = 0xffffffffu;
+        const uint32_t s = I * QM_TILE + tid;
+        const uint64_t qq = (uint64_t)q_begin + (uint64_t)s * q_stride;
+        const bool have = s < nq && qq < n;
+        m_q[tid] = have ? (uint32_t)qq : 0xffffffffu;
+        m_sB[tid] = have ? psum[qq] : 0u;
+        m_len[tid] = have ? row_len[s] : 0u;
+        m_off[tid] = have ? row_off[s] : 0ull;
+        m_flB[tid] = (have && rowmin != nullptr) ? ((qflag[qq] != 0 ? 1u : 0u) | (tflag[qq] != 0 ? 2u : 0u)) : 0u;
+    } else if (tid < 256 + 16) {
+        const int c = tid - 256;
+        uint32_t tm = 0, qm = 0;
+        if (rowmin != nullptr) {
+            for (int k = 0; k < 16; ++k) {
+                const uint64_t p = (uint64_t)J * QM_TILE + c * 16 + k;
+                if (p < n) { tm |= (tflag[p] != 0 ? 1u : 0u) << k; qm |= (qflag[p] != 0 ? 1u : 0u) << k; }
+            }
+        }
+        m_tA[c] = (uint16_t)tm; m_qA[c] = (uint16_t)qm;
+    }
+
+    // ---- global -> LDS: 2 operands x 256 rows x 4 slots = 2048 chunks of 16 B per K-block, 4 per thread
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)qm_lds;
+    const uint8_t *gsrc[4];
+    uint32_t ldst[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (it & 1) * 512 + tid;                       // chunk of the operand: row c >> 2, physical slot c & 3
+        const int row = c >> 2, ps = c & 3, ls = ps ^ ((row >> 2) & 3);
+        uint64_t ent;
+        if (it < 2) ent = (uint64_t)J * QM_TILE + row;            // operand A: columns p (n_pad covers every tile)
+        else {
+            ent = (uint64_t)q_begin + ((uint64_t)I * QM_TILE + row) * q_stride;
+            if (ent >= n_pad) ent = n_pad - 1;
+        }
+        gsrc[it] = prof4 + ent * QM_ROWB + ls * 16;
+        ldst[it] = lds0 + (uint32_t)((it >> 1) * (QM_TILE * QM_ROWB) + ((it & 1) * 512 + wave * 64) * 16);
+    }
+    const size_t kb_stride = (size_t)n_pad * QM_ROWB;
+    auto issue = [&](int kb) {
+        const uint32_t st = (uint32_t)(kb % QM_STAGES) * QM_STAGE_BYTES;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) qm_glds16(gsrc[it] + (size_t)kb * kb_stride, (uint32_t)__builtin_amdgcn_readfirstlane((int)(ldst[it] + st)));
+    };
+#pragma unroll
+    for (int kb = 0; kb < QM_STAGES - 1; ++kb) issue(kb);
+
+    qm_v16f acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = qm_v16f{};
+
+    // fragment addresses inside a stage (bytes): row * 64 + physical slot * 16; the K-step's slot pair is (2 ks + h)
+    const int swz = (r >> 2) & 3;
+    const int offA = (wp * 128 + r) * QM_ROWB, offB = QM_TILE * QM_ROWB + (wq * 64 + r) * QM_ROWB;
+    for (int kb = 0; kb < QM_NKB; ++kb) {
+        // K-block kb has landed (own loads: counted wait; everybody's: the barrier); the barrier also says that everybody is
+        // done with K-block kb - 1, whose stage the next issue overwrites
+        if (kb + 2 < QM_NKB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kb + 1 < QM_NKB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kb + QM_STAGES - 1 < QM_NKB) issue(kb + QM_STAGES - 1);
+        const uint8_t *stg = qm_lds + (size_t)(kb % QM_STAGES) * QM_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ps = ((2 * ks + h) ^ swz) * 16;
+            qm_v8i fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(stg + offA + i * 32 * QM_ROWB + ps);
+                fa[i] = qm_v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(stg + offB + j * 32 * QM_ROWB + ps);
+                fb[j] = qm_v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[j], acc[i][j], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    }
+    __syncthreads();          // every wave is done with the ring: it becomes the byte tile out[q][p]
+
+    // ---- E1: accumulators -> bound bytes.  C layout: column (B side, q) = lane & 31, row (A side, p) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(qm_lds);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ql = wq * 64 + j * 32 + r;
+        const uint32_t sb = m_sB[ql];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int pl = wp * 128 + i * 32 + 8 * g + 4 * h;
+                uint32_t w = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t sa = m_sA[pl + k];
+                    const int32_t mm = (int32_t)acc[i][j][4 * g + k];
+                    int32_t v = (int32_t)(sa > sb ? sa : sb) - mm;
+                    v = v < 0 ? 0 : v;
+                    uint32_t bd = ((uint32_t)v + (uint32_t)QG_Q - 1u) / (uint32_t)QG_Q;
+                    bd = bd < 255u ? bd : 255u;
+                    w |= bd << (8 * k);
+                }
+                out32[ql * (QM_OUT_STRIDE / 4) + (pl >> 2)] = w;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- E2: rows.  16 threads per row (16 columns each), 32 rows per round
+    {
+        const int chunk = tid & 15;
+        const uint64_t p0 = (uint64_t)J * QM_TILE + (uint64_t)chunk * 16;
+        const uint32_t tmask = m_tA[chunk];
+        for (int rr = 0; rr < 8; ++rr) {
+            const int ql = rr * 32 + (tid >> 4);
+            const uint32_t qe = m_q[ql];
+            const uint32_t rl = m_len[ql];
+            // valid columns of this chunk: q < p <= q + rl, p < n
+            int lo = 0, hi = 0;
+            if (qe != 0xffffffffu) {
+                const int64_t first = (int64_t)qe + 1 - (int64_t)p0, last = (int64_t)qe + 1 + (int64_t)rl - (int64_t)p0;        // [first, last)
+                lo = first < 0 ? 0 : (first > 16 ? 16 : (int)first);
+                hi = last < 0 ? 0 : (last > 16 ? 16 : (int)last);
+                const int64_t nn = (int64_t)n - (int64_t)p0;
+                if (nn < hi) hi = nn < 0 ? 0 : (int)nn;
+            }
+            uint32_t key = 0xffffffffu;
+            if (hi > lo) {
+                const uint2 v0 = *reinterpret_cast<const uint2 *>(qm_lds + ql * QM_OUT_STRIDE + chunk * 16);
+                const uint2 v1 = *reinterpret_cast<const uint2 *>(qm_lds + ql * QM_OUT_STRIDE + chunk * 16 + 8);
+                uint4 v; v.x = v0.x; v.y = v0.y; v.z = v1.x; v.w = v1.y;
+                // address of column p: row_off + (p - q - 1), congruent to p mod 16 by the host's row alignment
+                *reinterpret_cast<uint4 *>(lb + (m_off[ql] + (unsigned long long)((int64_t)p0 - (int64_t)qe - 1))) = v;
+                if (m_flB[ql] & 1u) {
+                    const uint32_t vm = (((1u << hi) - 1u) & ~((1u << lo) - 1u)) & tmask;
+                    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t cand = (((wv[k >> 2] >> (8 * (k & 3))) & 0xffu) << 8) | (uint32_t)(chunk * 16 + k);
+                        if ((vm >> k) & 1u) key = cand < key ? cand : key;
+                    }
+                }
+            }
+            if (rowmin != nullptr) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const uint32_t w = (uint32_t)__shfl_xor((int)key, o, 64);
+                    key = w < key ? w : key;
+                }
+                if (chunk == 0 && key != 0xffffffffu) {
+                    const uint64_t e = (uint64_t)J * QM_TILE + (key & 0xffu) - (uint64_t)qe - 1;
+                    atomicMin(rowmin + ((size_t)I * QM_TILE + ql), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)e);
+                }
+            }
+        }
+    }
+    // ---- E3: columns.  Thread = 4 columns (one dword) x the 32 rows of its wave
+    if (colmin != nullptr) {
+        const int pc = lane * 4;
+        const uint32_t qmask = (m_qA[pc >> 4] >> (pc & 15)) & 0xfu;
+        if (__ballot(qmask != 0)) {
+            uint32_t best[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            const uint64_t p0 = (uint64_t)J * QM_TILE + pc;
+            for (int rr = 0; rr < 32; ++rr) {
+                const int ql = wave * 32 + rr;
+                const uint32_t qe = m_q[ql];
+                if (qe == 0xffffffffu || !(m_flB[ql] & 2u)) continue;           // wave-uniform
+                const uint32_t w = out32[ql * (QM_OUT_STRIDE / 4) + lane];
+                const uint32_t rl = m_len[ql];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint64_t p = p0 + k;
+                    const bool ok = ((qmask >> k) & 1u) && p > qe && p - qe - 1 < rl && p < n;
+                    const uint32_t cand = (((w >> (8 * k)) & 0xffu) << 8) | (uint32_t)ql;
+                    if (ok) best[k] = cand < best[k] ? cand : best[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (best[k] != 0xffffffffu) atomicMin(&m_cm[pc + k], best[k]);
+        }
+        __syncthreads();
+        if (tid < 256 && m_cm[tid] != 0xffffffffu) {
+            const uint32_t key = m_cm[tid];
+            atomicMin(colmin + ((size_t)J * QM_TILE + tid), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
+        }
+    }
+}
+
+// Seed pairs from the smallest bounds: entry x with the neighbour of its row minimum (if x owns a row) and with the row entry of
+// its column minimum, unless that row's own minimum is this very pair.  pa / pb hold 2 n slots, 0xffffffff = none.
+__global__ __launch_bounds__(256) void k_qgram_seed_pairs(const unsigned long long *__restrict__ rowmin, const unsigned long long *__restrict__ colmin,
+                                                           uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
+                                                           uint32_t *__restrict__ pa, uint32_t *__restrict__ pb)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= n) return;
+    uint32_t a0 = 0xffffffffu, b0 = 0xffffffffu, a1 = 0xffffffffu, b1 = 0xffffffffu;
+    if (x >= q_begin && (x - q_begin) % q_stride == 0 && (x - q_begin) / q_stride < nq) {
+        const unsigned long long kr = rowmin[(x - q_begin) / q_stride];
+        if (kr != ~0ull) { a0 = x; b0 = x + 1u + (uint32_t)kr; }
+    }
+    const unsigned long long kc = colmin[x];
+    if (kc != ~0ull) {
+        const uint32_t q = (uint32_t)kc;               // a row entry: q = q_begin + s * q_stride by construction
+        const unsigned long long kq = rowmin[(q - q_begin) / q_stride];
+        if (kq == ~0ull || q + 1u + (uint32_t)kq != x) { a1 = q; b1 = x; }
+    }
+    pa[2 * (size_t)x] = a0; pb[2 * (size_t)x] = b0;
+    pa[2 * (size_t)x + 1] = a1; pb[2 * (size_t)x + 1] = b1;
+}
+
+// The same bound for an explicit pair list (one wave per pair; tests and diagnostics: isocon_qgram_bound_pairs).
+__global__ __launch_bounds__(256) void k_qgram_lb_pairs(const uint8_t *__restrict__ prof4, const uint32_t *__restrict__ psum, uint32_t n_pad,
+                                                         const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n_pairs,
+                                                         int32_t *__restrict__ out)
+{
+    const uint64_t pr = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pr >= n_pairs) return;
+    const uint32_t x = a[pr], y = b[pr];
+    uint32_t m = 0;
+    for (int c = lane; c < QM_K / 8; c += 64) {            // dwords of a profile: K-block c / 16, dword c % 16 of its row
+        const size_t at = ((size_t)(c / (QM_ROWB / 4)) * n_pad) * QM_ROWB + (size_t)(c % (QM_ROWB / 4)) * 4;
+        const uint32_t u = *reinterpret_cast<const uint32_t *>(prof4 + at + (size_t)x * QM_ROWB);
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(prof4 + at + (size_t)y * QM_ROWB);
+        m += (uint32_t)__popc(u & v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m += (uint32_t)__shfl_xor((int)m, o, 64);
+    if (lane == 0) {
+        const uint32_t sx = psum[x], sy = psum[y];
+        out[pr] = (int32_t)(((sx > sy ? sx : sy) - m + (uint32_t)QG_Q - 1u) / (uint32_t)QG_Q);
+    }
+}
+
+}  // namespace isocon

@@ -86,7 +86,7 @@ class SeqStore(object):
         return (out, ms.value) if return_ms else out
 
     def qgram_bound_pairs(self, a, b):
-        """Lower bounds of ed(a[i], b[i]) from 6-gram count profiles (csrc/qgram.hpp) -- the pre-filter of the NN main pass."""
+        """Lower bounds of ed(a[i], b[i]) from q-gram count profiles (csrc/qgram_mm.hpp) -- the pre-filter of the NN main pass."""
         a = np.ascontiguousarray(a, dtype=np.uint32)
         b = np.ascontiguousarray(b, dtype=np.uint32)
         if len(a) != len(b):
@@ -95,6 +95,25 @@ class SeqStore(object):
         _lib.check(self._L.isocon_qgram_bound_pairs(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), len(a), _ptr(out, _lib.i32p)),
                    "isocon_qgram_bound_pairs")
         return out
+
+    def qgram_bound_matrix(self, q_begin=0, q_end=None, q_stride=1, depth=2 ** 32):
+        """The bound matrix the NN main pass consults for the shard q_begin, q_begin + q_stride, ... (isocon_qgram_bound_matrix; tests):
+        (row_ptr[rows + 1], bytes) -- row r = entry q_begin + r * q_stride against the entries behind it within 63 of its length."""
+        q_end = self.n if q_end is None else min(int(q_end), self.n)
+        rows = 0 if q_begin >= q_end else (q_end - q_begin + q_stride - 1) // q_stride
+        row_ptr = np.zeros(rows + 1, dtype=np.uint64)
+        needed = ctypes.c_uint64(0)
+        cap = 1 << 20
+        depth = int(min(depth, 2 ** 63 - 1))
+        while True:
+            out = np.empty(cap, dtype=np.uint8)
+            rc = self._L.isocon_qgram_bound_matrix(self._h, q_begin, q_end, q_stride, depth, _ptr(row_ptr, _lib.u64p), _ptr(out, _lib.u8p), cap,
+                                                   ctypes.byref(needed))
+            if rc == _lib.ISOCON_E_CAPACITY:
+                cap = int(needed.value)
+                continue
+            _lib.check(rc, "isocon_qgram_bound_matrix")
+            return row_ptr, out[:int(row_ptr[-1])]
 
     def hw_pairs(self, q, t, k, return_ms=False):
         """Infix (edlib "HW", task="path") alignment of sequence q[p] inside sequence t[p] with threshold k[p]:

@@ -1,5 +1,5 @@
-"""The q-gram pre-filter of the NN main pass (isocon_amd/csrc/qgram.hpp): its bound equals a numpy restatement, never exceeds the
-oracle's edit distance, and the graph with the filter is the graph without it."""
+"""The q-gram pre-filter of the NN main pass (isocon_amd/csrc/qgram_mm.hpp): its bound equals a numpy restatement (pair list and every
+byte of the matrix the main pass reads), never exceeds the oracle's edit distance, and the graph with the filter is the graph without it."""
 import os
 import subprocess
 import sys
@@ -9,29 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-Q = 8
-BINS = 6144
-
-
-def profile(s):
-    """min(255, occurrences) of every 6-gram, indexed like the kernel: low code bits of the bases | high code bits << 6."""
-    code = np.zeros(256, np.int64)
-    code[ord("C")] = 1; code[ord("G")] = 2; code[ord("T")] = 3
-    c = code[np.frombuffer(s.encode(), np.uint8)]
-    ng = len(c) - Q + 1
-    if ng <= 0:
-        return np.zeros(BINS, np.int64)
-    idx = np.zeros(ng, np.int64)
-    for i in range(Q):
-        idx |= (c[i:i + ng] & 1) << i
-        idx |= (c[i:i + ng] >> 1) << (Q + i)
-    if BINS != 4 ** Q:
-        idx = (((idx * 0x9E3779B1) & 0xffffffff) >> 7) % BINS
-    return np.minimum(np.bincount(idx, minlength=BINS), 255)
-
-
-def bound(pa, pb):
-    return int((np.abs(pa - pb).sum() + abs(int(pa.sum()) - int(pb.sum())) + 2 * Q - 1) // (2 * Q))
+from qgram_ref import bound, profile
 
 
 def _mixed_set():
@@ -66,6 +44,56 @@ def test_bound_equals_the_restatement_and_never_exceeds_the_distance():
     same = a == b
     assert (got[same] == 0).all()
     assert (got > 0).sum() > 1000          # the bound is not vacuous
+
+
+def _check_matrix(st, seqs, B, q_begin, q_end, q_stride, depth):
+    """every byte of the matrix the main pass reads (isocon_qgram_bound_matrix) against the restatement"""
+    lens = np.array([len(s) for s in seqs])
+    n = len(seqs)
+    row_ptr, got = st.qgram_bound_matrix(q_begin, q_end, q_stride, depth)
+    qs = list(range(q_begin, min(q_end, n), q_stride))
+    assert len(row_ptr) == len(qs) + 1
+    total = 0
+    for r, q in enumerate(qs):
+        hi = int(np.searchsorted(lens, lens[q] + 63, "right"))
+        hi = min(hi, q + 1 + depth)
+        js = np.arange(q + 1, max(hi, q + 1))
+        assert int(row_ptr[r + 1] - row_ptr[r]) == len(js), (q, len(js))
+        if len(js):
+            want = np.minimum(B[q, js], 255)
+            have = got[int(row_ptr[r]):int(row_ptr[r + 1])]
+            bad = np.nonzero(have != want)[0]
+            assert len(bad) == 0, (q_begin, q_stride, depth, q, int(js[bad[0]]), int(have[bad[0]]), int(want[bad[0]]), len(bad))
+        total += len(js)
+    return total
+
+
+def test_every_byte_of_the_bound_matrix():
+    """The product kernel k_qgram_mm (tiles of 256 x 256 pairs on the matrix cores, rows laid out for the main pass) against the numpy
+    restatement: 1-set, strided shards, a last row block that is not full, finite depths, n not a multiple of the tile."""
+    import random
+    import qgram_ref as R
+    from isocon_amd import synth
+    from isocon_amd.store import SeqStore
+    rng = random.Random(3)
+    accs, seqs, _ = synth.make_reads(2900, 1000, 5, seed=41)
+    seqs = list(dict.fromkeys(seqs))
+    seqs += ["", "A", "ACGTACGTA", "ACGTACGTAC", "A" * 990, "AC" * 500, "ACG" * 340] + ["".join(rng.choice("ACGT") for _ in range(rng.randrange(900, 1100))) for _ in range(150)]
+    seqs = sorted(seqs, key=len)
+    assert len(seqs) % 256 not in (0, 255)
+    B = R.bound_matrix(seqs)
+    st = SeqStore(seqs)
+    try:
+        n = len(seqs)
+        total = _check_matrix(st, seqs, B, 0, n, 1, 2 ** 32)
+        assert total > 1000000
+        for q_begin, q_stride in ((0, 3), (1, 3), (2, 3), (5, 7)):
+            _check_matrix(st, seqs, B, q_begin, n, q_stride, 2 ** 32)
+        _check_matrix(st, seqs, B, 0, n, 1, 300)
+        _check_matrix(st, seqs, B, 1, n - 7, 2, 37)
+        _check_matrix(st, seqs, B, n - 40, n, 1, 2 ** 32)
+    finally:
+        st.close()
 
 
 def test_graph_with_the_filter_is_the_graph_without_it_and_the_filter_is_used():

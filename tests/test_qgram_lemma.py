@@ -1,4 +1,4 @@
-"""The q-gram count bound the NN main pass relies on (isocon_amd/csrc/qgram.hpp), checked on the CPU against the oracle's exact
+"""The q-gram count bound the NN main pass relies on (isocon_amd/csrc/qgram_mm.hpp), checked on the CPU against the oracle's exact
 distances: ceil((L1 + |sum difference|) / 2q) never exceeds the edit distance -- for random pairs, related pairs with every
 kind of edit, homopolymers, repeats, saturating counts and sequences shorter than q."""
 import random
@@ -73,11 +73,20 @@ def test_bound_never_exceeds_the_edit_distance():
     merged = [p.reshape(1024, 4).sum(axis=1) for p in prof]
     lbm = np.array([bound(merged[i], merged[j]) for i, j in zip(a, b)])
     assert (lbm <= d).all() and (lbm <= lb).all()
-    # the kernel's parameters: 8-grams hashed into 6144 bins
+    # hashed bins: 8-grams into 6144 bins
     prof8 = [profile(s, q=8, bins=6144) for s in seqs]
     lb8 = np.array([bound(prof8[i], prof8[j], q=8) for i, j in zip(a, b)])
     assert (lb8 <= d).all(), [(seqs[a[i]][:30], seqs[b[i]][:30], int(lb8[i]), int(d[i])) for i in np.nonzero(lb8 > d)[0][:3]]
     assert (lb8[a == b] == 0).all()
+    # the kernel's stored vector (qgram_mm.hpp): presence bits of hashed 9-grams + capped excess counts in coarser bins -- with the
+    # kernel's parameters and with tiny bin counts that force every merge / cap case
+    import qgram_ref as R
+    for kw in ({}, {"q": 4, "b0": 64, "b1": 16, "cap": 2}, {"q": 3, "b0": 64, "b1": 64, "cap": 1}, {"q": 5, "b0": 256, "b1": 32, "cap": 3}):
+        pk = [R.profile(s, **kw) for s in seqs]
+        qq = kw.get("q", R.Q)
+        lbk = np.array([R.bound(pk[i], pk[j], qq) for i, j in zip(a, b)])
+        assert (lbk <= d).all(), (kw, [(seqs[a[i]][:30], seqs[b[i]][:30], int(lbk[i]), int(d[i])) for i in np.nonzero(lbk > d)[0][:3]])
+        assert (lbk[a == b] == 0).all()
     # and it is not vacuous (short sequences with dense edits included; 0.76 on 2.5 kb reads at 1 % errors)
     rel = (d > 0) & (d <= 60)
     assert np.median(lb[rel] / d[rel]) > 0.4
