@@ -102,7 +102,7 @@ typedef struct {
     uint32_t scan_launches;       /* launches summed into scan_kernel_ms */
     uint64_t pairs_prefiltered;   /* pairs of the main pass whose q-gram bound exceeded their threshold (never aligned) */
     float bound_kernel_ms;        /* HIP-event time of the q-gram profile + bound kernels (part of kernel_ms) */
-    uint32_t reserved_;
+    float list_kernel_ms;         /* ... of the kernels that compact the survivors of the bounds into lists (part of kernel_ms) */
 } isocon_nn_stats;
 
 /*

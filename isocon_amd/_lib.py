@@ -31,7 +31,7 @@ class NNStats(ctypes.Structure):
                 ("hits", ctypes.c_uint64), ("fallback_queries", ctypes.c_uint64), ("full_pairs", ctypes.c_uint64),
                 ("kernel_ms", ctypes.c_float), ("scan_kernel_ms", ctypes.c_float), ("seed_kernel_ms", ctypes.c_float),
                 ("scan_launches", ctypes.c_uint32), ("pairs_prefiltered", ctypes.c_uint64), ("bound_kernel_ms", ctypes.c_float),
-                ("reserved_", ctypes.c_uint32)]
+                ("list_kernel_ms", ctypes.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -38,7 +38,13 @@ struct NNParams {
     const uint8_t *lb;
     const unsigned long long *lb_row;
     const uint32_t *slot_order;    // launch slot handled by workgroup i (nullptr: i itself): entries with the widest windows first
+    // k_nn_scan_refill, "listed" launch (nn_list.hpp; nullptr = not listed): workgroup i aligns the entry chunks[i].slot (its table in
+    // LDS) with the partners list[chunks[i].begin .. + count) -- survivors of the q-gram bound, collected before the launch
+    const struct NNChunk *chunks;
+    const uint32_t *list;          // partner | 0x40000000 (the chunk's entry queries it) | 0x80000000 (it queries the chunk's entry)
 };
+
+struct NNChunk { uint32_t slot, count; unsigned long long begin; };
 
 __device__ __forceinline__ void nn_append(const NNParams &P, bool want, int32_t e, int32_t o, int32_t d)
 {
@@ -280,9 +286,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
     const bool sparse = P.q_list != nullptr;
-    const uint32_t slot = (!sparse && P.slot_order != nullptr) ? P.slot_order[blockIdx.x] : blockIdx.x;
-    const uint64_t q64 = sparse ? (uint64_t)P.q_list[blockIdx.x] : (uint64_t)q_begin + (uint64_t)slot * q_stride;
-    if (q64 >= (uint64_t)q_end) return;
+    const bool listed = P.chunks != nullptr;
+    uint32_t l_count = 0;
+    unsigned long long l_begin = 0;
+    if (listed) { l_count = P.chunks[blockIdx.x].count; l_begin = P.chunks[blockIdx.x].begin; }
+    const uint32_t slot = listed ? P.chunks[blockIdx.x].slot : (!sparse && P.slot_order != nullptr) ? P.slot_order[blockIdx.x] : blockIdx.x;
+    const uint64_t q64 = listed ? (uint64_t)slot : sparse ? (uint64_t)P.q_list[blockIdx.x] : (uint64_t)q_begin + (uint64_t)slot * q_stride;
+    if (q64 >= (listed ? (uint64_t)S.n : (uint64_t)q_end)) return;
     const uint32_t q = (uint32_t)q64;
     const int32_t m = S.lens[q];
     int64_t pbase = (int64_t)q + 1 + (int64_t)tile_begin * 64;
@@ -293,10 +303,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
             if (uniform_i32(S.lens[mid]) < m - P.kcap) lo = mid + 1; else hi = mid;
         }
         pbase = lo;
-    } else if (pbase >= (int64_t)S.n || pbase - (int64_t)q > (int64_t)P.depth || S.lens[pbase] - m > P.kcap) return;   // uniform
+    } else if (!listed && (pbase >= (int64_t)S.n || pbase - (int64_t)q > (int64_t)P.depth || S.lens[pbase] - m > P.kcap)) return;   // uniform
     const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
     if (!q_isq && !q_ist) return;
-    const bool bounded = P.lb != nullptr && !sparse;
+    const bool bounded = P.lb != nullptr && !sparse && !listed;
     const unsigned long long lb_base = bounded ? P.lb_row[slot] : 0ull;
     const int32_t E = (m + 192 * W + 31) & ~31;          // plane length in dwords
     {
@@ -363,12 +373,27 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
             uint32_t c0 = 0;
             if (lane == 0) c0 = atomicAdd(&s_next, 64u);
             c0 = (uint32_t)uniform_i32((int32_t)c0);
-            const int64_t p = pbase + (int64_t)c0 + lane;
+            int64_t p = pbase + (int64_t)c0 + lane;
+            uint32_t pid;
+            int32_t np;
+            bool within, us, ul;
+            if (listed) {
+                // the survivors of the bound, already filtered by roles, window and bound (k_nn_survivors): one coalesced load
+                const bool inr = c0 + (uint32_t)lane < l_count;
+                const uint32_t e = inr ? P.list[l_begin + c0 + (uint32_t)lane] : q;
+                pid = e & 0x3fffffffu;
+                p = (int64_t)pid;
+                np = S.lens[pid];
+                within = inr;
+                us = inr && (e & 0x40000000u) != 0;
+                ul = inr && (e & 0x80000000u) != 0;
+                if (c0 + 64u >= l_count) exhausted = true;
+            } else {
             const int64_t off = p > (int64_t)q ? p - (int64_t)q : (int64_t)q - p;
             const bool inr = p < (int64_t)S.n && (off <= (int64_t)P.depth || (sparse && p < (int64_t)q));
-            const uint32_t pid = inr ? (uint32_t)p : q;
-            const int32_t np = S.lens[pid];
-            bool within = inr && np - m <= P.kcap;
+            pid = inr ? (uint32_t)p : q;
+            np = S.lens[pid];
+            within = inr && np - m <= P.kcap;
             if (__ballot(within) != ~(uint64_t)0) exhausted = true;
             if (sparse) {
                 // entries below q that are too far in the order (depth) are skipped, not the end of the window; the pair
@@ -379,8 +404,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                                   lowi >= P.own_begin && (lowi - P.own_begin) % P.own_stride == 0;
                 within = within && mine;
             }
-            const bool us = within && q_isq && P.tflag[pid];
-            const bool ul = within && q_ist && P.qflag[pid];
+            us = within && q_isq && P.tflag[pid];
+            ul = within && q_ist && P.qflag[pid];
+            }
             int32_t bs = NN_INF;
             if (q_isq) bs = uniform_i32(load_relaxed_agent(P.best + q));
             int32_t ks = -1, kl = -1;
