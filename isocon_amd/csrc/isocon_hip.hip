@@ -54,7 +54,7 @@ struct ScratchPool {
 
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
-    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_SLOTORDER, SLOT_NN_LBCHUNKS, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B, SLOT_NN_LPAIRS, SLOT_NN_LDEG, SLOT_NN_LOWN, SLOT_NN_LCUR, SLOT_NN_LDEST, SLOT_NN_LTOT, SLOT_NN_LCHUNKS, SLOT_NN_LIST, SLOT_NN_LPA, SLOT_NN_LPB,
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_SLOTORDER, SLOT_NN_LBCHUNKS, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B, SLOT_NN_LBT, SLOT_NN_LBT_OFF, SLOT_NN_LBT_SLO, SLOT_NN_LBT_LEN, SLOT_NN_SCORE, SLOT_NN_LDEST, SLOT_NN_LTOT, SLOT_NN_LCHUNKS, SLOT_NN_LIST, SLOT_NN_LPA, SLOT_NN_LPB,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES,
@@ -78,6 +78,24 @@ struct BoundTag {
     unsigned long long lb_total = 0;
 };
 static BoundTag g_bound_tag;
+
+// A second stream for launches that may run BESIDE the one in flight on the null stream (the pair-per-lane kernel of the main pass
+// next to the table kernel: one is limited by LDS-bound occupancy, the other by nothing but VALU issue).  Created on first use; the
+// null stream waits for it through an event before anything reads the results.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok()
+    {
+        if (s) return true;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; (void)hipGetLastError(); return false; }
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(s); s = nullptr; (void)hipGetLastError(); return false;
+        }
+        return true;
+    }
+};
+static SideStream g_side;
 static uint64_t g_store_serial = 0;
 
 struct isocon_store {

@@ -7,16 +7,16 @@
 // few errors are near everybody).  A workgroup per entry that walks its whole window inside the alignment kernel (~110 batches of
 // dependent loads per entry) spends its life finding 22 pairs and then runs them on 256 lanes; a 48 KB table in LDS pays only
 // when hundreds of lanes use it.  Distances are symmetric, so a pair may use either end's table: handing every pair to the end of
-// larger degree puts 88 % of the pairs into lists of >= 512 (73 % by lower index).  Steps:
-//   1. k_nn_survivors   one wave per row of the bound matrix: the in-kernel admission's tests (roles, window, threshold, bound) on
-//                       the same best[]; survivors go to a flat pair buffer (staged in LDS, one cursor atomic per ~200 pairs), degrees
-//                       are counted;
-//   2. k_nn_own_count   per pair: owner = the end of larger degree (ties: the lower index); list sizes;
-//   3. k_nn_plan        one workgroup: owners with >= NN_LIST_MIN pairs get a LIST, cut into chunks of <= NN_LIST_CHUNK pairs (one
-//                       k_nn_scan_refill workgroup per chunk: owner's table in LDS, lanes refilled from the chunk), largest chunks
-//                       first; the other pairs go to flat pair arrays for the one-pair-per-lane kernel (ed_lanes.hpp: no table);
-//   4. k_nn_own_fill    per pair: into its list / pair array slot;
-//   5. the two alignment launches (nn_host.inc).
+// larger degree puts 88 % of the pairs into lists of >= 512 (73 % by lower index).
+// Grouping pairs by an end that is not the row they were found in is a sparse transposition (two scattered atomics per pair: measured
+// 4.8 ms for 1.3 10^7 pairs); instead k_qgram_mm also writes the TRANSPOSED matrix and a hub score per entry (pairs with a small
+// bound, counted in its epilogue), so that ONE pass finds every entry's pairs on both sides and both ends of a pair agree on
+// its owner without communicating:
+//   1. k_nn_survivors   one wave per entry: its row and its transposed row through the in-kernel admission's tests (roles, window,
+//                       threshold from the same best[], bound); the pairs it owns are staged in LDS and leave as chunks of a list
+//                       (one k_nn_scan_refill workgroup per chunk: the entry's table in LDS, lanes refilled from the chunk) or, for
+//                       entries with few pairs, as flat pairs for the one-pair-per-lane kernel (ed_lanes.hpp: no table);
+//   2. the two alignment launches (nn_host.inc).
 // The pair set is exactly the one the in-kernel admission evaluates, so the graph is unchanged; replaces the window walk of
 // /root/reference/modules/nearest_neighbor_graph.py:136-178.
 #pragma once
@@ -24,183 +24,143 @@
 
 namespace isocon {
 
-static constexpr uint32_t NN_LIST_MIN = 512;       // owners with fewer pairs: their pairs go to the pair-per-lane kernel
-static constexpr uint32_t NN_LIST_CHUNK = 4096;    // pairs per table workgroup (512 lanes: eight rounds of refill)
-static constexpr int NN_STAGE = 256;               // pairs a wave stages in LDS before it takes room in the pair buffer
+static constexpr uint32_t NN_LIST_MIN = 256;       // owners with fewer pairs (and what is left of a list below this): one pair per lane
+static constexpr uint32_t NN_LIST_CHUNK = 1536;    // a wave hands over a chunk as soon as it has staged this many pairs of its entry
+static constexpr int NN_STAGE = NN_LIST_CHUNK + 64;
 
-struct NNPlanTotals { unsigned long long n_pairs, n_list, n_small, n_chunks, n_filtered, overflow; };
+// counters of the list builder, each on a cache line of its own (they are hot: tens of thousands of atomics per launch)
+struct NNPlanTotals {
+    unsigned long long n_pairs, pad0[15], n_list, pad1[15], n_small, pad2[15], n_chunks, pad3[15], n_filtered, pad4[15], overflow, pad5[15];
+};
 
-// pairs[i] = (lower entry q, upper entry p | 0x40000000 (q queries p) | 0x80000000 (p queries q))
-__global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, const uint32_t *__restrict__ row_len, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
-                                                       uint2 *__restrict__ pairs, unsigned long long pairs_cap, uint32_t *__restrict__ deg, NNPlanTotals *__restrict__ totals)
+// the matrix rows of both orientations (qgram_mm.hpp) and the hub scores that decide which end owns a pair
+struct NNBoundRows {
+    const uint8_t *lb;  const unsigned long long *row_off; const uint32_t *row_len;                      // row of slot s: columns p = q(s) + 1 ...
+    const uint8_t *lbT; const unsigned long long *offT;    const uint32_t *sloT; const uint32_t *lenT;   // row of entry p: slots sloT[p] ...
+    const uint32_t *score;
+};
+
+// what the scan needs to know about a partner, in one 16-byte load: length, current threshold min(best, length), hub score, roles
+__global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, const uint32_t *__restrict__ score, uint4 *__restrict__ meta)
 {
-    __shared__ uint2 stage[4][NN_STAGE];
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= S.n) return;
+    const int32_t m = S.lens[x], b = load_relaxed_agent(P.best + x);
+    uint4 v;
+    v.x = (uint32_t)m; v.y = (uint32_t)(b < m ? b : m); v.z = score[x]; v.w = (P.tflag[x] != 0 ? 1u : 0u) | (P.qflag[x] != 0 ? 2u : 0u);
+    meta[x] = v;
+}
+
+// One wave per entry x.  Its pairs are the columns of its own row (partners above x; only if x is one of the launch slots) and the
+// slots of its transposed row (partners below x): the same survival test from both sides (roles, length window, threshold from the
+// same best[], bound), and the same ownership rule -- the end with the larger hub score, ties to the lower index -- so every
+// surviving pair is kept by exactly one of its two ends.  Kept pairs are staged in LDS; NN_LIST_CHUNK staged pairs become a chunk
+// of `list` (one k_nn_scan_refill workgroup with x's table), what is left at the end becomes a last chunk if it has NN_LIST_MIN
+// pairs, else flat pairs for the one-pair-per-lane kernel.
+__global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint4 *__restrict__ meta, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
+                                                       uint32_t *__restrict__ list, unsigned long long list_cap, NNChunk *__restrict__ chunks, unsigned long long chunks_cap,
+                                                       uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min)
+{
+    __shared__ uint32_t stage[4][NN_STAGE];
+    __shared__ uint32_t s_small[4], s_filtered[4], s_kept[4];
+    __shared__ unsigned long long s_base;
     const int wave = threadIdx.x >> 6;
-    const uint32_t s = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t x = blockIdx.x * 4u + (uint32_t)wave;
     const int lane = threadIdx.x & 63;
-    if (s >= nq) return;
-    const uint32_t q = q_begin + s * q_stride;
-    const bool q_isq = P.qflag[q] != 0, q_ist = P.tflag[q] != 0;
-    const uint32_t rl = row_len[s];
-    if (rl == 0 || (!q_isq && !q_ist)) return;
-    const int32_t m = S.lens[q];
-    const unsigned long long lb_base = P.lb_row[s];
-    const int32_t bs = q_isq ? load_relaxed_agent(P.best + q) : NN_INF;
-    const int32_t ks0 = bs < m ? bs : m;
+    const uint4 mx = x < S.n ? meta[x] : make_uint4(0, 0, 0, 0);
+    const bool x_isq = (mx.w & 2u) != 0, x_ist = (mx.w & 1u) != 0;
+    // x's own row, if it is a launch slot, and its transposed row
+    uint32_t up_len = 0, dn_len = 0, dn_slo = 0;
+    unsigned long long up_off = 0, dn_off = 0;
+    if (x < S.n && (x_isq || x_ist)) {
+        if (x >= q_begin && (x - q_begin) % q_stride == 0 && (x - q_begin) / q_stride < nq) {
+            const uint32_t s = (x - q_begin) / q_stride;
+            up_len = B.row_len[s];
+            up_off = B.row_off[s];
+        }
+        dn_len = B.lenT[x]; dn_slo = B.sloT[x]; dn_off = B.offT[x];
+    }
+    const int32_t m = (int32_t)mx.x;
+    const int32_t kx0 = (int32_t)mx.y;
+    const uint32_t sx = mx.z;
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
-    uint2 *st = stage[wave];
-    uint32_t fill = 0, total = 0, filtered = 0;
-    auto flush = [&]() {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&totals->n_pairs, (unsigned long long)fill);
+    uint32_t *st = stage[wave];
+    uint32_t fill = 0, filtered = 0, kept = 0;
+    auto emit_chunk = [&]() {
+        unsigned long long base = 0, ci = 0;
+        if (lane == 0) { base = atomicAdd(&totals->n_list, (unsigned long long)fill); ci = atomicAdd(&totals->n_chunks, 1ull); }
         base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-        if (base + fill <= pairs_cap) {
-            for (uint32_t i = (uint32_t)lane; i < fill; i += 64) pairs[base + i] = st[i];
+        ci = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ci >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ci);
+        if (base + fill <= list_cap && ci < chunks_cap) {
+            for (uint32_t i = (uint32_t)lane; i < fill; i += 64) list[base + i] = st[i];
+            if (lane == 0) { NNChunk ch; ch.slot = x; ch.count = fill; ch.begin = base; chunks[ci] = ch; }
         } else if (lane == 0) atomicOr(&totals->overflow, 1ull);
         fill = 0;
     };
-    constexpr int U = 4;                         // batches of 64 columns per iteration: their loads are independent
-    for (uint32_t c0 = 0; c0 < rl; c0 += 64 * U) {
-        uint32_t pid[U];
-        int32_t np[U], bl[U];
-        uint32_t fl[U], lbv[U];
+    constexpr int U = 8;                         // batches of 64 partners per iteration: their loads are independent
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t len = side == 0 ? up_len : dn_len;
+        const uint8_t *row = side == 0 ? B.lb + up_off : B.lbT + dn_off;
+        for (uint32_t c0 = 0; c0 < len; c0 += 64 * U) {
+            uint32_t y[U], lbv[U];
+            uint4 my[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = c0 + 64u * u + (uint32_t)lane;
-            const uint32_t ec = e < rl ? e : rl - 1;
-            pid[u] = q + 1u + ec;
-            np[u] = S.lens[pid[u]];
-            bl[u] = load_relaxed_agent(P.best + pid[u]);
-            fl[u] = (P.tflag[pid[u]] != 0 ? 1u : 0u) | (P.qflag[pid[u]] != 0 ? 2u : 0u);
-            lbv[u] = P.lb[lb_base + ec];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = c0 + 64u * u + (uint32_t)lane;
-            const bool inr = e < rl;
-            const bool us = inr && q_isq && (fl[u] & 1u);
-            const bool ul = inr && q_ist && (fl[u] & 2u);
-            int32_t ks = -1, kl = -1;
-            if (us) ks = ks0;
-            if (ul) kl = bl[u] < np[u] ? bl[u] : np[u];
-            int32_t k = ks > kl ? ks : kl;
-            if (k > P.kcap) k = P.kcap;
-            const int32_t dl = m - np[u], ad = dl < 0 ? -dl : dl;
-            const bool cand = inr && k >= 0 && ad <= k;
-            const bool accept = cand && (int32_t)lbv[u] <= k;
-            const uint64_t am = __ballot(accept);
-            filtered += (uint32_t)__popcll(__ballot(cand && !accept));
-            if (am == 0) continue;                                   // wave-uniform
-            if (accept) {
-                st[fill + (uint32_t)__popcll(am & lt_mask)] = make_uint2(q, pid[u] | (us ? 0x40000000u : 0u) | (ul ? 0x80000000u : 0u));
-                atomicAdd(deg + pid[u], 1u);
+            for (int u = 0; u < U; ++u) {
+                const uint32_t e = c0 + 64u * u + (uint32_t)lane;
+                const uint32_t ec = e < len ? e : len - 1;
+                y[u] = side == 0 ? x + 1u + ec : q_begin + (dn_slo + ec) * q_stride;
+                my[u] = meta[y[u]];
+                lbv[u] = row[ec];
             }
-            fill += (uint32_t)__popcll(am);
-            total += (uint32_t)__popcll(am);
-            if (fill > (uint32_t)NN_STAGE - 64u) flush();
-        }
-    }
-    if (fill) flush();
-    if (lane == 0) {
-        if (total) atomicAdd(deg + q, total);
-        if (filtered) atomicAdd(&totals->n_filtered, (unsigned long long)filtered);
-    }
-}
-
-__device__ __forceinline__ uint32_t nn_pair_owner(uint32_t q, uint32_t p, const uint32_t *__restrict__ deg)
-{
-    return deg[p] > deg[q] ? p : q;
-}
-
-__global__ __launch_bounds__(256) void k_nn_own_count(const uint2 *__restrict__ pairs, unsigned long long n_pairs, const uint32_t *__restrict__ deg, uint32_t *__restrict__ own_cnt)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_pairs) return;
-    const uint2 pr = pairs[i];
-    atomicAdd(own_cnt + nn_pair_owner(pr.x, pr.y & 0x3fffffffu, deg), 1u);
-}
-
-// exclusive scan of one value per thread over a workgroup of 1024 threads; *total receives the sum
-__device__ __forceinline__ unsigned long long nn_block_exscan(unsigned long long v, unsigned long long *wave_sums, unsigned long long *total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long x = v;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long y = ((unsigned long long)(uint32_t)__shfl_up((int)(x >> 32), o, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)x, o, 64);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) wave_sums[wave] = x;
-    __syncthreads();
-    unsigned long long before = 0, all = 0;
-    for (int w = 0; w < 16; ++w) { const unsigned long long t = wave_sums[w]; if (w < wave) before += t; all += t; }
-    __syncthreads();
-    *total = all;
-    return before + x - v;
-}
-
-// One workgroup of 1024 threads: thread t plans the entries [t R, (t + 1) R), R = ceil(n / 1024).  dest[x]: index of the first pair
-// of owner x in `list` (bit 63 clear) or in the pair arrays (bit 63 set).  Chunks in three buckets, largest first.
-__global__ __launch_bounds__(1024) void k_nn_plan(const uint32_t *__restrict__ own_cnt, uint32_t n, unsigned long long *__restrict__ dest,
-                                                   NNChunk *__restrict__ chunks, unsigned long long chunks_cap, NNPlanTotals *__restrict__ totals)
-{
-    __shared__ unsigned long long wave_sums[16];
-    const uint32_t t = threadIdx.x;
-    const uint32_t R = (n + 1023u) / 1024u;
-    const uint32_t r0 = t * R < n ? t * R : n, r1 = (t + 1) * R < n ? (t + 1) * R : n;
-    auto bucket = [](uint32_t c) { return c >= 2048u ? 0 : (c >= 1024u ? 1 : 2); };
-    unsigned long long nl = 0, ns = 0, nc[3] = {0, 0, 0};
-    for (uint32_t x = r0; x < r1; ++x) {
-        const uint32_t c = own_cnt[x];
-        if (c >= NN_LIST_MIN) {
-            nl += c;
-            for (uint32_t b = 0; b < c; b += NN_LIST_CHUNK) nc[bucket(c - b < NN_LIST_CHUNK ? c - b : NN_LIST_CHUNK)] += 1;
-        } else ns += c;
-    }
-    unsigned long long tl, ts, tc[3];
-    unsigned long long ol = nn_block_exscan(nl, wave_sums, &tl);
-    unsigned long long os = nn_block_exscan(ns, wave_sums, &ts);
-    unsigned long long oc[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) oc[b] = nn_block_exscan(nc[b], wave_sums, &tc[b]);
-    oc[1] += tc[0];
-    oc[2] += tc[0] + tc[1];
-    if (t == 0) { totals->n_list = tl; totals->n_small = ts; totals->n_chunks = tc[0] + tc[1] + tc[2]; }
-    for (uint32_t x = r0; x < r1; ++x) {
-        const uint32_t c = own_cnt[x];
-        if (c >= NN_LIST_MIN) {
-            dest[x] = ol;
-            for (uint32_t b = 0; b < c; b += NN_LIST_CHUNK) {
-                NNChunk ch;
-                ch.slot = x; ch.count = c - b < NN_LIST_CHUNK ? c - b : NN_LIST_CHUNK; ch.begin = ol + b;
-                const int bk = bucket(ch.count);
-                if (oc[bk] < chunks_cap) chunks[oc[bk]] = ch;
-                oc[bk] += 1;
+            for (int u = 0; u < U; ++u) {
+                if (c0 + 64u * u >= len) break;                        // wave-uniform
+                const uint32_t e = c0 + 64u * u + (uint32_t)lane;
+                const bool inr = e < len;
+                const bool xq = inr && x_isq && (my[u].w & 1u);        // x queries y
+                const bool yq = inr && x_ist && (my[u].w & 2u);        // y queries x
+                int32_t kx = -1, ky = -1;
+                if (xq) kx = kx0;
+                if (yq) ky = (int32_t)my[u].y;
+                int32_t k = kx > ky ? kx : ky;
+                if (k > P.kcap) k = P.kcap;
+                const int32_t dl = m - (int32_t)my[u].x, ad = dl < 0 ? -dl : dl;
+                const uint32_t sy_u = my[u].z;
+                const bool cand = inr && k >= 0 && ad <= k;
+                const bool accept = cand && (int32_t)lbv[u] <= k;
+                // owner: larger hub score, ties to the lower index (side 0: x is the lower end)
+                const bool mine = accept && (side == 0 ? sy_u <= sx : sx > sy_u);
+                if (side == 0) { filtered += (uint32_t)__popcll(__ballot(cand && !accept)); kept += (uint32_t)__popcll(__ballot(accept)); }
+                const uint64_t am = __ballot(mine);
+                if (am == 0) continue;                                   // wave-uniform
+                if (mine) st[fill + (uint32_t)__popcll(am & lt_mask)] = y[u] | (xq ? 0x40000000u : 0u) | (yq ? 0x80000000u : 0u);
+                fill += (uint32_t)__popcll(am);
+                if (fill >= NN_LIST_CHUNK) emit_chunk();
             }
-            ol += c;
-        } else {
-            dest[x] = os | ((unsigned long long)1 << 63);
-            os += c;
         }
     }
-}
-
-// list entry of owner x: partner | 0x40000000 (x queries the partner) | 0x80000000 (the partner queries x)
-__global__ __launch_bounds__(256) void k_nn_own_fill(const uint2 *__restrict__ pairs, unsigned long long n_pairs, const uint32_t *__restrict__ deg,
-                                                      const unsigned long long *__restrict__ dest, uint32_t *__restrict__ cursor, uint32_t *__restrict__ list,
-                                                      uint32_t *__restrict__ pa, uint32_t *__restrict__ pb)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_pairs) return;
-    const uint2 pr = pairs[i];
-    const uint32_t q = pr.x, p = pr.y & 0x3fffffffu;
-    const bool q_queries_p = (pr.y & 0x40000000u) != 0, p_queries_q = (pr.y & 0x80000000u) != 0;
-    const uint32_t owner = nn_pair_owner(q, p, deg);
-    const unsigned long long d = dest[owner];
-    const unsigned long long at = (d & ~((unsigned long long)1 << 63)) + atomicAdd(cursor + owner, 1u);
-    if (d >> 63) { pa[at] = q; pb[at] = p; }
-    else if (owner == q) list[at] = p | (q_queries_p ? 0x40000000u : 0u) | (p_queries_q ? 0x80000000u : 0u);
-    else list[at] = q | (p_queries_q ? 0x40000000u : 0u) | (q_queries_p ? 0x80000000u : 0u);
+    if (fill >= list_min) emit_chunk();
+    // what is left goes to the pair arrays: one allocation per workgroup
+    if (lane == 0) { s_small[wave] = fill; s_filtered[wave] = filtered; s_kept[wave] = kept; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_small[0] + s_small[1] + s_small[2] + s_small[3];
+        const uint32_t fsum = s_filtered[0] + s_filtered[1] + s_filtered[2] + s_filtered[3], ksum = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+        unsigned long long base = 0;
+        if (tot) {
+            base = atomicAdd(&totals->n_small, (unsigned long long)tot);
+            if (base + tot > small_cap) { atomicOr(&totals->overflow, 1ull); base = ~0ull; }
+        }
+        s_base = base;
+        if (fsum) atomicAdd(&totals->n_filtered, (unsigned long long)fsum);
+        if (ksum) atomicAdd(&totals->n_pairs, (unsigned long long)ksum);
+    }
+    __syncthreads();
+    if (fill && s_base != ~0ull) {
+        unsigned long long base = s_base;
+        for (int w = 0; w < wave; ++w) base += s_small[w];
+        for (uint32_t i = (uint32_t)lane; i < fill; i += 64) { pa[base + i] = x; pb[base + i] = st[i] & 0x3fffffffu; }
+    }
 }
 
 }  // namespace isocon

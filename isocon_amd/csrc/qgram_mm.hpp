@@ -36,7 +36,8 @@ static constexpr int QM_TILE = 256;       // rows and columns of the bound matri
 static constexpr int QM_STAGES = 4;       // LDS ring: QM_STAGES x 2 operands x 256 rows x 64 B = 128 KB
 static constexpr int QM_STAGE_BYTES = 2 * QM_TILE * QM_ROWB;
 static constexpr int QM_OUT_STRIDE = QM_TILE + 8;       // bytes per row of the epilogue's byte tile in LDS (66 dwords: 2-way on the dword writes)
-static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 2 * 16 * 2 + 256 * 4;
+static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 2 * 16 * 2 + 256 * 4 + 256 * (4 + 4 + 8 + 4);
+static constexpr uint32_t QM_HUB_BOUND = 36;   // a pair with a bound up to this counts towards its ends' hub scores (nn_list.hpp: which end's table a pair uses)
 static constexpr size_t QM_LDS_BYTES = (size_t)QM_STAGES * QM_STAGE_BYTES + QM_META_BYTES;
 static_assert(QG_B0 % 128 == 0 && QG_B1 % 256 == 0 && QG_B0 % QG_B1 == 0, "K-blocks of 128 elements; excess bin = presence bin mod QG_B1");
 static_assert(QM_K % QM_KBE == 0 && QM_NKB >= QM_STAGES, "whole K-blocks");
@@ -140,7 +141,9 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
                                                       const uint2 *__restrict__ tiles, const unsigned long long *__restrict__ row_off,
                                                       const uint32_t *__restrict__ row_len, uint8_t *__restrict__ lb, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
                                                       const uint8_t *__restrict__ qflag, const uint8_t *__restrict__ tflag,
-                                                      unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin)
+                                                      unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin,
+                                                      const unsigned long long *__restrict__ offT, const uint32_t *__restrict__ sloT, const uint32_t *__restrict__ lenT,
+                                                      uint8_t *__restrict__ lbT, uint32_t *__restrict__ score)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t qm_lds[];
     // tile table entry of this workgroup: ids b, b + 8, b + 16, ... share an XCD (round-robin dispatch), and the 32 of them that
@@ -165,11 +168,20 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     uint16_t *m_tA = reinterpret_cast<uint16_t *>(m_flB + 256);           // per 16 columns: target flags, query flags
     uint16_t *m_qA = m_tA + 16;
     uint32_t *m_cm = reinterpret_cast<uint32_t *>(m_qA + 16);             // column minima of the tile (bound << 8 | row)
+    uint32_t *m_slo = m_cm + 256;                                         // transposed rows: first slot, number of slots, offset of the first slot
+    uint32_t *m_lenT = m_slo + 256;
+    unsigned long long *m_offT = reinterpret_cast<unsigned long long *>(m_lenT + 256);
+    uint32_t *m_cnt = reinterpret_cast<uint32_t *>(m_offT + 256);         // hub score of the tile's columns
 
     if (tid < 256) {
         const uint64_t p = (uint64_t)J * QM_TILE + tid;
         m_sA[tid] = p < n ? psum[p] : 0u;
         m_cm[tid] = 0xffffffffu;
+        m_cnt[tid] = 0u;
+        const bool tp = lbT != nullptr && p < n;
+        m_slo[tid] = tp ? sloT[p] : 0u;
+        m_lenT[tid] = tp ? lenT[p] : 0u;
+        m_offT[tid] = tp ? offT[p] : 0ull;
         const uint32_t s = I * QM_TILE + tid;
         const uint64_t qq = (uint64_t)q_begin + (uint64_t)s * q_stride;
         const bool have = s < nq && qq < n;
@@ -304,65 +316,75 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
                 const int64_t nn = (int64_t)n - (int64_t)p0;
                 if (nn < hi) hi = nn < 0 ? 0 : (int)nn;
             }
-            uint32_t key = 0xffffffffu;
+            uint32_t key = 0xffffffffu, hub = 0;
             if (hi > lo) {
                 const uint2 v0 = *reinterpret_cast<const uint2 *>(qm_lds + ql * QM_OUT_STRIDE + chunk * 16);
                 const uint2 v1 = *reinterpret_cast<const uint2 *>(qm_lds + ql * QM_OUT_STRIDE + chunk * 16 + 8);
                 uint4 v; v.x = v0.x; v.y = v0.y; v.z = v1.x; v.w = v1.y;
                 // address of column p: row_off + (p - q - 1), congruent to p mod 16 by the host's row alignment
                 *reinterpret_cast<uint4 *>(lb + (m_off[ql] + (unsigned long long)((int64_t)p0 - (int64_t)qe - 1))) = v;
-                if (m_flB[ql] & 1u) {
-                    const uint32_t vm = (((1u << hi) - 1u) & ~((1u << lo) - 1u)) & tmask;
-                    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t inside = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                const uint32_t vm = (m_flB[ql] & 1u) ? (inside & tmask) : 0u;
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const uint32_t cand = (((wv[k >> 2] >> (8 * (k & 3))) & 0xffu) << 8) | (uint32_t)(chunk * 16 + k);
-                        if ((vm >> k) & 1u) key = cand < key ? cand : key;
-                    }
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t bd = (wv[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                    const uint32_t cand = (bd << 8) | (uint32_t)(chunk * 16 + k);
+                    if ((vm >> k) & 1u) key = cand < key ? cand : key;
+                    hub += ((inside >> k) & 1u) && bd <= QM_HUB_BOUND ? 1u : 0u;
                 }
             }
-            if (rowmin != nullptr) {
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const uint32_t w = (uint32_t)__shfl_xor((int)key, o, 64);
-                    key = w < key ? w : key;
-                }
-                if (chunk == 0 && key != 0xffffffffu) {
+            for (int o = 1; o < 16; o <<= 1) {
+                const uint32_t w = (uint32_t)__shfl_xor((int)key, o, 64);
+                key = w < key ? w : key;
+                hub += (uint32_t)__shfl_xor((int)hub, o, 64);
+            }
+            if (chunk == 0) {
+                if (rowmin != nullptr && key != 0xffffffffu) {
                     const uint64_t e = (uint64_t)J * QM_TILE + (key & 0xffu) - (uint64_t)qe - 1;
                     atomicMin(rowmin + ((size_t)I * QM_TILE + ql), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)e);
                 }
+                if (score != nullptr && hub) atomicAdd(score + qe, hub);
             }
         }
     }
-    // ---- E3: columns.  Thread = 4 columns (one dword) x the 32 rows of its wave
-    if (colmin != nullptr) {
-        const int pc = lane * 4;
-        const uint32_t qmask = (m_qA[pc >> 4] >> (pc & 15)) & 0xfu;
-        if (__ballot(qmask != 0)) {
-            uint32_t best[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-            const uint64_t p0 = (uint64_t)J * QM_TILE + pc;
-            for (int rr = 0; rr < 32; ++rr) {
-                const int ql = wave * 32 + rr;
-                const uint32_t qe = m_q[ql];
-                if (qe == 0xffffffffu || !(m_flB[ql] & 2u)) continue;           // wave-uniform
-                const uint32_t w = out32[ql * (QM_OUT_STRIDE / 4) + lane];
-                const uint32_t rl = m_len[ql];
+    // ---- E3: columns.  Thread = one column x half of the rows: the transposed matrix (row p of lbT = the slots whose window holds p,
+    //      lbT[offT[p] + (slot - sloT[p])], address congruent to the slot mod 16), the columns' hub scores and smallest admissible bounds
+    if (lbT != nullptr || colmin != nullptr) {
+        const int pl = tid & 255, hh = tid >> 8;
+        const uint32_t slo = m_slo[pl], shi = slo + m_lenT[pl];
+        const unsigned long long ot = m_offT[pl];
+        const bool p_isq = colmin != nullptr && ((m_qA[pl >> 4] >> (pl & 15)) & 1u) != 0;
+        uint32_t best = 0xffffffffu, hub = 0;
+        for (int c = 0; c < 8; ++c) {
+            const int ql0 = hh * 128 + c * 16;
+            const uint32_t s0 = I * QM_TILE + (uint32_t)ql0;
+            if (s0 + 16u <= slo || s0 >= shi) continue;
+            uint32_t wv[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint64_t p = p0 + k;
-                    const bool ok = ((qmask >> k) & 1u) && p > qe && p - qe - 1 < rl && p < n;
-                    const uint32_t cand = (((w >> (8 * k)) & 0xffu) << 8) | (uint32_t)ql;
-                    if (ok) best[k] = cand < best[k] ? cand : best[k];
-                }
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t bd = qm_lds[(ql0 + k) * QM_OUT_STRIDE + pl];
+                wv[k >> 2] |= bd << (8 * (k & 3));
+                const bool ok = s0 + (uint32_t)k >= slo && s0 + (uint32_t)k < shi;
+                hub += ok && bd <= QM_HUB_BOUND ? 1u : 0u;
+                if (p_isq && ok && (m_flB[ql0 + k] & 2u)) { const uint32_t cand = (bd << 8) | (uint32_t)(ql0 + k); best = cand < best ? cand : best; }
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (best[k] != 0xffffffffu) atomicMin(&m_cm[pc + k], best[k]);
+            if (lbT != nullptr) {
+                uint4 v; v.x = wv[0]; v.y = wv[1]; v.z = wv[2]; v.w = wv[3];
+                *reinterpret_cast<uint4 *>(lbT + (ot + (unsigned long long)((int64_t)s0 - (int64_t)slo))) = v;
+            }
         }
+        if (best != 0xffffffffu) atomicMin(&m_cm[pl], best);
+        if (hub) atomicAdd(&m_cnt[pl], hub);
         __syncthreads();
-        if (tid < 256 && m_cm[tid] != 0xffffffffu) {
-            const uint32_t key = m_cm[tid];
-            atomicMin(colmin + ((size_t)J * QM_TILE + tid), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
+        if (tid < 256) {
+            const uint64_t p = (uint64_t)J * QM_TILE + tid;
+            if (colmin != nullptr && m_cm[tid] != 0xffffffffu) {
+                const uint32_t key = m_cm[tid];
+                atomicMin(colmin + p, ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
+            }
+            if (score != nullptr && m_cnt[tid] != 0 && p < n) atomicAdd(score + p, m_cnt[tid]);
         }
     }
 }
