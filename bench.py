@@ -16,14 +16,17 @@ value depends on nr_cores through the chunk-local seed dictionary, NNG:112,125-1
 baseline and the GPU, and is computable from the result alone.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel k_nn_scan_refill (main pass: the pairs that survive the q-gram bound; `bound_pass` = the
-                kernel that computes the bounds, k_qgram_lb, with the same two fractions).  Integer bit-vector DP with the query in LDS and the
-                neighbours in L2 / Infinity Cache: neither HBM nor MFMA binds it, VALU issue does.  `frac` = VALU
-                wave-instructions / s (SQ_INSTS_VALU of the dispatch, profiles/counters.json, scaled to this run by the
-                kernel's own wave-column counter, divided by the live HIP-event time of the launch) against the
-                guide's independent peak 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction.  `hbm` = PMC
-                bytes (2 x FETCH_SIZE + WRITE_SIZE) / time against 8 TB/s.  `algorithmic` = SURVEY 8(d)'s byte model,
-                reported for reference only (it charges bytes the kernel never moves through HBM).
+  roofline      dominant kernel k_nn_scan_refill (main pass: the pairs that survive the q-gram bound, aligned against the match-mask
+                table of one of their ends).  Integer bit-vector DP with the table in LDS and the partners' texts in L2 /
+                Infinity Cache: neither HBM nor MFMA binds it, VALU issue does.  `frac` = VALU wave-instructions / s against
+                the guide's independent peak 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction, where the
+                instruction count is ALWAYS (instructions per 64-lane column, a property of the code: SQ_INSTS_VALU /
+                wave-columns of the profiled dispatch in profiles/counters.json) x (this run's own wave-columns, counted by
+                the kernel) and the time is the launch's live HIP-event time.  counters.json carries a digest of the kernel
+                sources it was collected from; with other sources it is ignored (`frac` null).  `traffic` = PMC bytes
+                (2 x FETCH_SIZE + WRITE_SIZE) of the dispatch.  `bound_pass` = the kernel that computes the bounds (k_qgram_mm,
+                fp4 MFMA): multiply-adds / s against the dense fp4 peak.  `algorithmic` = SURVEY 8(d)'s byte model, for
+                reference only (it charges bytes the kernels never move through HBM).
   cpu_baseline  the reference's loop on this host's cores: real edlib if the wheel imports ("edlib"), else the C
                 restatement under a Pool ("port").  Reported, not the target.
   wrappers      wall time of the PUBLIC functions end to end (string handling, H2D, kernels, D2H, dict rebuild).
@@ -44,6 +47,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                       # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMD-32 x 2.4 GHz, one wave64 VALU instruction per 2 cycles (same guide)
+MFMA_FP4_PEAK_MACS = 5.0e15                 # ~10 PFLOP/s dense FP4 (same guide, chip-level parameters) = 5e15 multiply-adds / s
 COUNTERS = os.path.join(ROOT, "profiles", "counters.json")   # written by scripts/summarize_profile.py from rocprofv3 --pmc passes
 
 
@@ -208,11 +212,27 @@ def self_launch(args):
     sys.exit(p.returncode)
 
 
+def source_digest():
+    """digest of the kernel sources: counters.json is only valid for the code it was collected from"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "isocon_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_counters():
+    """(counters, note): the committed PMC figures, or {} when they were collected from other kernel sources"""
     try:
-        return json.load(open(COUNTERS))
+        c = json.load(open(COUNTERS))
     except Exception:
-        return {}
+        return {}, "profiles/counters.json missing"
+    if c.get("source_digest") != source_digest():
+        return {}, "profiles/counters.json is stale: collected from kernel sources %s, this tree is %s (run scripts/profile_bench.sh + scripts/summarize_profile.py)" % (c.get("source_digest"), source_digest())
+    return c, "profiles/counters.json (rocprofv3 --pmc, round %s, same kernel sources)" % c.get("round", "?")
 
 
 def main():
@@ -299,13 +319,12 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    main_ms, seed_ms, all_ms, bound_ms = [], [], [], []
+    phase_ms = {k: [] for k in ("scan_kernel_ms", "seed_kernel_ms", "bound_kernel_ms", "list_kernel_ms", "lanes_kernel_ms", "kernel_ms")}
     for _ in range(args.steps):
         step()
-        main_ms.append(sum(x.get("scan_kernel_ms", 0.0) for x in last["stats"]))      # HIP events on the kernels' own stream (EventTimer, csrc/common.hpp)
-        seed_ms.append(sum(x.get("seed_kernel_ms", 0.0) for x in last["stats"]))
-        bound_ms.append(sum(x.get("bound_kernel_ms", 0.0) for x in last["stats"]))
-        all_ms.append(sum(x.get("kernel_ms", 0.0) for x in last["stats"]))
+        for k in phase_ms:          # HIP events on the kernels' own stream (EventTimer, csrc/isocon_hip.hip)
+            phase_ms[k].append(sum(x.get(k, 0.0) for x in last["stats"]))
+    all_ms = phase_ms["kernel_ms"]
     sync()
     dt = time.perf_counter() - t0
     per_rank_kernel_ms = [float(np.mean(all_ms))]
@@ -322,48 +341,55 @@ def main():
     value = n_align / (ms_per_step / 1e3)
 
     # ---- roofline of the dominant kernel on this rank --------------------------------------------------------------
-    st0 = {k: sum(x.get(k, 0) for x in last["stats"]) for k in ("pairs_evaluated", "cells_columns", "pairs_prefiltered")}   # this rank, all phases
+    st0 = {k: sum(x.get(k, 0) for x in last["stats"]) for k in ("pairs_evaluated", "cells_columns", "pairs_prefiltered", "pairs_lanes", "bound_tiles")}   # this rank, all phases
     pairs_eval = int(st0["pairs_evaluated"])
-    wave_cols = float(st0["cells_columns"]) / 64.0            # 64-lane DP columns executed (main + seed pass)
+    wave_cols = float(st0["cells_columns"]) / 64.0            # 64-lane DP columns the table kernel executed (its own counter)
     mean_len = float(lens.mean())
-    k_ms = float(np.mean(main_ms)) if main_ms else 0.0
-    s_ms = float(np.mean(seed_ms)) if seed_ms else 0.0
-    b_ms = float(np.mean(bound_ms)) if bound_ms else 0.0
+    pm = {k: (float(np.mean(v)) if v else 0.0) for k, v in phase_ms.items()}
+    k_ms = pm["scan_kernel_ms"]
     is_default = (args.reads, args.length, args.isoforms, args.seed) == (50000, 2500, 10, 30001)
-    ctr = load_counters()
-    # second kernel of the step: q-gram bounds of every pair of the length window (k_qgram_lb), same two fractions
-    cb = ctr.get("nn_bound", {})
-    bound_pass = None
-    if cb.get("SQ_INSTS_VALU") and b_ms > 0 and is_default and world == 1:
-        bound_pass = {"kernel": cb.get("kernel", "k_qgram_lb")[:40], "valu_insts_per_launch": float(cb["SQ_INSTS_VALU"]),
-                      "valu_frac": float(cb["SQ_INSTS_VALU"]) / (b_ms / 1e3) / VALU_PEAK_WAVE_INSTR,
-                      "hbm_frac": (float(cb["hbm_bytes"]) / (b_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if cb.get("hbm_bytes") else None,
-                      "note": "bound_pass_ms also holds the profile kernel (0.3 ms)"}
+    ctr, ctr_note = load_counters()
     cm = ctr.get("nn_main", {})
-    insts = traffic = None
+    ipc = insts = traffic = None
     if cm.get("SQ_INSTS_VALU") and cm.get("wave_columns"):
-        # instructions per 64-lane column are a property of the code (profiled dispatch); the column count is this run's own
-        if is_default and world == 1:
-            insts = float(cm["SQ_INSTS_VALU"])
-        else:
-            insts = float(cm["SQ_INSTS_VALU"]) / float(cm["wave_columns"]) * wave_cols
+        ipc = float(cm["SQ_INSTS_VALU"]) / float(cm["wave_columns"])       # instructions per 64-lane column: a property of the code
+        insts = ipc * wave_cols                                            # x this run's own columns, whatever the workload
     if is_default and world == 1 and cm.get("hbm_bytes"):
         traffic = float(cm["hbm_bytes"])         # the committed PMC figure belongs to the default workload only
     achieved = insts / (k_ms / 1e3) if insts and k_ms > 0 else None
+    # the kernel that computes the bounds: a banded A B^T of thermometer-coded profiles on the matrix cores
+    bound_pass = None
+    if pm["bound_kernel_ms"] > 0 and st0["bound_tiles"]:
+        from isocon_amd import _lib as _l
+        kk = int(_l.load().isocon_qgram_elements())
+        macs = float(st0["bound_tiles"]) * 65536.0 * kk
+        cb = ctr.get("nn_bound", {})
+        bound_pass = {"kernel": "k_qgram_profile4 + k_qgram_mm (q-gram bounds of every pair of the length window: fp4 MFMA, K = %d)" % kk, "bound": "mfma",
+                      "kernel_ms": pm["bound_kernel_ms"], "tiles_256x256": int(st0["bound_tiles"]), "macs_per_launch": macs,
+                      "achieved": macs / (pm["bound_kernel_ms"] / 1e3), "peak": MFMA_FP4_PEAK_MACS, "unit": "multiply-adds/s (dense fp4 MFMA)",
+                      "frac": macs / (pm["bound_kernel_ms"] / 1e3) / MFMA_FP4_PEAK_MACS,
+                      "hbm_frac": (float(cb["hbm_bytes"]) / (pm["bound_kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS) if (cb.get("hbm_bytes") and is_default and world == 1) else None,
+                      "traffic": float(cb["hbm_bytes"]) if (cb.get("hbm_bytes") and is_default and world == 1) else None}
     alg_bytes = pairs_eval * (2.0 * mean_len + 8.0)
-    roofline = {"bound": "valu", "kernel": cm.get("kernel", "k_nn_scan_refill<8,1>") + " (main pass of one step)",
+    align_ms = k_ms + pm["lanes_kernel_ms"]
+    roofline = {"bound": "valu", "kernel": "isocon::k_nn_scan_refill<8, 1> (table kernel of the main pass, one step)",
                 "achieved": achieved, "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instr/s",
                 "frac": achieved / VALU_PEAK_WAVE_INSTR if achieved else None, "traffic": traffic,
-                "kernel_ms": k_ms, "seed_pass_ms": s_ms, "bound_pass_ms": b_ms, "bound_pass": bound_pass, "valu_insts_per_launch": insts,
-                "pairs_aligned": pairs_eval, "pairs_rejected_by_qgram_bound": int(st0["pairs_prefiltered"]),
-                "valu_insts_source": "profiles/counters.json (rocprofv3 --pmc SQ_INSTS_VALU, %s)%s" % (ctr.get("round", "?"), "" if (is_default and world == 1) else " scaled by this run's wave-columns"),
-                "wave_columns_per_launch": wave_cols, "wave_columns_per_s": wave_cols / ((k_ms + s_ms) / 1e3) if (k_ms + s_ms) > 0 else None,
+                "kernel_ms": k_ms, "valu_insts_per_wave_column": ipc, "wave_columns_this_run": wave_cols, "valu_insts_this_run": insts,
+                "valu_insts_profiled_dispatch": cm.get("SQ_INSTS_VALU"), "wave_columns_profiled_dispatch": cm.get("wave_columns"),
+                "counters": ctr_note,
+                "step_kernels_ms": {"bounds (profiles + k_qgram_mm)": pm["bound_kernel_ms"], "seeds (k_ed_lanes)": pm["seed_kernel_ms"],
+                                    "survivor lists (k_nn_survivors)": pm["list_kernel_ms"], "tables (k_nn_scan_refill)": k_ms,
+                                    "pair per lane (k_ed_lanes)": pm["lanes_kernel_ms"], "all kernels": pm["kernel_ms"]},
+                "bound_pass": bound_pass,
+                "pairs_aligned": pairs_eval, "pairs_aligned_one_per_lane": int(st0["pairs_lanes"]), "pairs_rejected_by_qgram_bound": int(st0["pairs_prefiltered"]),
+                "wave_columns_per_s": wave_cols / (k_ms / 1e3) if k_ms > 0 else None,
                 "hbm": {"achieved": traffic / (k_ms / 1e3) / 1e9 if traffic and k_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": traffic / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS if traffic and k_ms > 0 else None,
                         "source": "PMC 2 x FETCH_SIZE + WRITE_SIZE of the dispatch (profiles/counters.json)"},
                 "algorithmic": {"bytes_per_pair": 2.0 * mean_len + 8.0, "pairs_per_launch": pairs_eval,
-                                "GBps": alg_bytes / ((k_ms + s_ms) / 1e3) / 1e9 if (k_ms + s_ms) > 0 else None,
-                                "note": "SURVEY 8(d) byte model x pairs / kernel time; NOT a physical rate: the query sits in LDS, neighbours come from "
+                                "GBps": alg_bytes / (align_ms / 1e3) / 1e9 if align_ms > 0 else None,
+                                "note": "SURVEY 8(d) byte model x pairs aligned / alignment kernel time; NOT a physical rate: the table sits in LDS, texts come from "
                                         "L2 / Infinity Cache as 0.5 B/base nibbles and pairs are abandoned once they exceed their threshold"}}
 
     result = {

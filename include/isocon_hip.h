@@ -75,6 +75,8 @@ int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const
  * nearest-neighbour search skips a pair whose bound exceeds its threshold -- the pair edlib would have answered with -1
  * (modules/nearest_neighbor_graph.py:156-162).  The reference has no counterpart; exposed so that the bound can be tested by itself.
  */
+/* binary elements of a stored q-gram profile (presence bins + levels of the excess bins): the K of the bound kernel's contraction */
+int isocon_qgram_elements(void);
 int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound);
 
 /*
@@ -102,7 +104,11 @@ typedef struct {
     uint32_t scan_launches;       /* launches summed into scan_kernel_ms */
     uint64_t pairs_prefiltered;   /* pairs of the main pass whose q-gram bound exceeded their threshold (never aligned) */
     float bound_kernel_ms;        /* HIP-event time of the q-gram profile + bound kernels (part of kernel_ms) */
-    float list_kernel_ms;         /* ... of the kernels that compact the survivors of the bounds into lists (part of kernel_ms) */
+    float list_kernel_ms;         /* ... of the kernel that collects the survivors of the bounds into lists (part of kernel_ms) */
+    float lanes_kernel_ms;        /* ... of the one-pair-per-lane launch of the main pass (entries with few pairs; NOT in scan_kernel_ms) */
+    uint32_t reserved_;
+    uint64_t pairs_lanes;         /* pairs of the main pass aligned one pair per lane (the rest went through tables) */
+    uint64_t bound_tiles;         /* 256 x 256 tiles of the bound matrix computed (each: 65 536 pairs x isocon_qgram_elements() multiply-adds) */
 } isocon_nn_stats;
 
 /*

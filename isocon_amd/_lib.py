@@ -31,7 +31,8 @@ class NNStats(ctypes.Structure):
                 ("hits", ctypes.c_uint64), ("fallback_queries", ctypes.c_uint64), ("full_pairs", ctypes.c_uint64),
                 ("kernel_ms", ctypes.c_float), ("scan_kernel_ms", ctypes.c_float), ("seed_kernel_ms", ctypes.c_float),
                 ("scan_launches", ctypes.c_uint32), ("pairs_prefiltered", ctypes.c_uint64), ("bound_kernel_ms", ctypes.c_float),
-                ("list_kernel_ms", ctypes.c_float)]
+                ("list_kernel_ms", ctypes.c_float), ("lanes_kernel_ms", ctypes.c_float), ("reserved_", ctypes.c_uint32),
+                ("pairs_lanes", ctypes.c_uint64), ("bound_tiles", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -50,6 +51,7 @@ SYMBOLS = {
     "isocon_store_device_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
     "isocon_store_digest": (ctypes.c_int, [ctypes.c_void_p, u64p]),
     "isocon_ed_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, i32p, ctypes.c_uint64, i32p, f32p]),
+    "isocon_qgram_elements": (ctypes.c_int, []),
     "isocon_qgram_bound_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, i32p]),
     "isocon_qgram_bound_matrix": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, u64p, u8p,
                                                  ctypes.c_uint64, u64p]),

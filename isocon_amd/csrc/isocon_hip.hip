@@ -79,23 +79,6 @@ struct BoundTag {
 };
 static BoundTag g_bound_tag;
 
-// A second stream for launches that may run BESIDE the one in flight on the null stream (the pair-per-lane kernel of the main pass
-// next to the table kernel: one is limited by LDS-bound occupancy, the other by nothing but VALU issue).  Created on first use; the
-// null stream waits for it through an event before anything reads the results.
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool ok()
-    {
-        if (s) return true;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; (void)hipGetLastError(); return false; }
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipStreamDestroy(s); s = nullptr; (void)hipGetLastError(); return false;
-        }
-        return true;
-    }
-};
-static SideStream g_side;
 static uint64_t g_store_serial = 0;
 
 struct isocon_store {
@@ -604,6 +587,8 @@ extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_
     if (!n_pairs) return ISOCON_OK;
     return ed_pairs_impl(s, a, b, k, n_pairs, out_ed, kernel_ms, nullptr);
 }
+
+extern "C" int isocon_qgram_elements(void) { return QM_K; }
 
 // q-gram lower bounds of explicit pairs (qgram_mm.hpp): what the main pass of the NN search consults, exposed for tests
 extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound)

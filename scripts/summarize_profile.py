@@ -63,13 +63,20 @@ def classify(rows):
         if calls:
             calls[-1].append(r)
         prev = kind
+    # one NN-graph step: k_qgram_profile4, k_qgram_mm, k_qgram_seed_pairs, k_ed_lanes<true> (seeds), k_nn_entry_meta, k_nn_survivors,
+    # k_nn_scan_refill (tables), k_ed_lanes<true> (entries with few pairs)
+    lanes = [r for r in rows if "k_ed_lanes<true>" in r[1]]
     for r in rows:
         if "k_nn_scan_refill" in r[1] and "nn_main" not in cls:
             cls["nn_main"] = [r]
-        if ("k_ed_lanes<true>" in r[1] or "k_nn_scan_up<1>" in r[1]) and "nn_seed" not in cls:
-            cls["nn_seed"] = [r]
-        if "k_qgram_lb" in r[1] and "k_qgram_lb_pairs" not in r[1] and "nn_bound" not in cls:
+        if "k_qgram_mm" in r[1] and "nn_bound" not in cls:
             cls["nn_bound"] = [r]
+        if "k_nn_survivors" in r[1] and "nn_lists" not in cls:
+            cls["nn_lists"] = [r]
+    if lanes:
+        cls["nn_seed"] = lanes[:1]
+    if len(lanes) > 1:
+        cls["nn_lanes"] = lanes[1:2]
     if sg_full:
         cls["sg_full"] = sg_full
     if sg_banded:
@@ -82,7 +89,9 @@ def classify(rows):
 
 
 sq, fetch, write = dispatches("sq"), dispatches("fetch"), dispatches("write")
-counters = {"round": tag, "command": "rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "
+sys.path.insert(0, ROOT)
+import bench as _bench                      # source_digest(): the kernel sources these counters belong to
+counters = {"round": tag, "source_digest": _bench.source_digest(), "command": "rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "
                                      "(three passes: SQ_*, FETCH_SIZE, WRITE_SIZE)", "workload": "C3 (50k x 2.5kb, seed 30001)"}
 lines = [counters["command"], "dispatches of one NN-graph step at C3 (50k x 2.5kb) and of bench.py's untimed extras"]
 for kind, rows in (("sq", sq), ("fetch", fetch), ("write", write)):
@@ -102,7 +111,7 @@ bj = os.path.join(out, "bench_sq_%s.json" % tag)
 if os.path.exists(bj) and "nn_main" in counters:
     try:
         line = [ln for ln in open(bj) if ln.startswith("{")][-1]
-        counters["nn_main"]["wave_columns"] = json.loads(line)["roofline"]["wave_columns_per_launch"]
+        counters["nn_main"]["wave_columns"] = json.loads(line)["roofline"]["wave_columns_this_run"]
     except Exception as ex:
         print("no wave_columns:", ex)
 lines.append("HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE doubled: gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md)")
