@@ -1,0 +1,82 @@
+"""GPU: BASELINE.json configs[4] at its FULL size on one GPU -- 200 000 reads with the ONT error profile (6 %), lengths 1-5 kb, 50
+isoforms in 5 gene families (seed 50001): step 1's exact nearest-neighbour graph through the public
+compute_nearest_neighbor_graph (modules/nearest_neighbor_graph.py:237-296).  Every row satisfies the size-independent properties,
+sampled rows -- the 5 kb end included -- equal the reference loop (oracle restatement of NNG:110-198, neighbour order included),
+sampled edges are true distances; and find_candidate_transcripts (modules/isocon_get_candidates.py:85-312) on the first 20 000 of
+those reads keeps its invariants (the un-gapped alignments are the inputs, the partition covers the reads)."""
+import numpy as np
+import pytest
+
+from conftest import Params
+from test_gpu_configs import _check_properties, _check_rows_against_the_reference_loop, _graph_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c5_reads():
+    from isocon_amd import synth
+    return synth.make_reads(200000, 0, 50, 50001, profile=synth.ONT_PROFILE, families=5, length_range=(1000, 5000))
+
+
+@pytest.fixture(scope="module")
+def c5(c5_reads):
+    from isocon_amd import nearest_neighbor_graph as NNG
+    accs, seqs, iso = c5_reads
+    S = dict(zip(accs, seqs))
+    graph, isolated = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    return S, graph, isolated, dict(NNG.LAST_STATS)
+
+
+def test_c5_full_size_graph(c5):
+    S, graph, isolated, stats = c5
+    seqs, accs, best, rows, cols = _graph_arrays(S, graph)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    assert len(seqs) > 199000 and not isolated
+    assert lens.min() < 1100 and lens.max() > 4000 and np.median(best[best >= 0]) > 63 and stats["fallback_queries"] > 0
+    assert (best >= 0).mean() > 0.999                                # practically every read has a neighbour
+    _check_properties(seqs, best, rows, cols)
+    rng = np.random.default_rng(21)
+    sample = rng.choice(len(seqs), 6, replace=False).tolist() + np.argsort(lens)[-2:].tolist()       # ... and the 5 kb end
+    _check_rows_against_the_reference_loop(seqs, accs, graph, sample)
+    # sampled edges through the independent pair-list entry point, unbounded
+    from isocon_amd.store import SeqStore
+    st = SeqStore(seqs)
+    try:
+        pick = rng.choice(len(rows), 4000, replace=False)
+        assert (st.ed_pairs(rows[pick], cols[pick], None) == best[rows[pick]]).all()
+    finally:
+        st.close()
+
+
+def test_c5_candidates_on_a_subset_keep_their_invariants(c5_reads, tmp_path):
+    from isocon_amd import isocon_get_candidates as IGC
+
+    class P(Params):
+        def __init__(self, out):
+            Params.__init__(self, 1)
+            self.outfolder = str(out)
+            self.ignore_ends_len = 15
+            self.min_candidate_support = 2
+            self.is_fastq = False
+            self.ccs = None
+            self.logfile = None
+            self.min_exon_diff = 20
+
+    accs, seqs, iso = c5_reads
+    n = 20000
+    fa = tmp_path / "reads.fa"
+    with open(fa, "w") as f:
+        for a, s in zip(accs[:n], seqs[:n]):
+            f.write(">%s\n%s\n" % (a, s))
+    (tmp_path / "out").mkdir()
+    cand_file, read_partition, to_realign = IGC.find_candidate_transcripts(str(fa), P(tmp_path / "out"))
+    assigned = 0
+    reads = dict(zip(accs[:n], seqs[:n]))
+    for c_acc, members in read_partition.items():
+        for r_acc, (c_aln, r_aln, (m, x, ind)) in members.items():
+            assert len(c_aln) == len(r_aln) and m + x + ind == len(c_aln)
+            assert r_aln.replace("-", "") == reads[r_acc]                        # correction_module.py:273-275: the un-gapped alignment is the input
+            assigned += 1
+    assert assigned + len(to_realign) == n                                       # isocon_get_candidates.py:293
+    assert len(read_partition) >= 10
