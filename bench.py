@@ -361,7 +361,7 @@ def main():
     bound_pass = None
     if pm["bound_kernel_ms"] > 0 and st0["bound_tiles"]:
         from isocon_amd import _lib as _l
-        kk = int(_l.load().isocon_qgram_elements())
+        kk = int(_l.load().isocon_qgram_params(None))
         macs = float(st0["bound_tiles"]) * 65536.0 * kk
         cb = ctr.get("nn_bound", {})
         bound_pass = {"kernel": "k_qgram_profile4 + k_qgram_mm (q-gram bounds of every pair of the length window: fp4 MFMA, K = %d)" % kk, "bound": "mfma",

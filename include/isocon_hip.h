@@ -70,13 +70,14 @@ int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const
                     int32_t *out_ed, float *kernel_ms);
 
 /*
- * Lower bounds of the pairs' edit distances from q-gram count profiles (isocon_amd/csrc/qgram_mm.hpp: 9-grams hashed into 16384
- * presence bins plus 2 levels of 2048 excess bins): out_bound[p] <= ed(a[p], b[p]) always.  The main pass of the
+ * Lower bounds of the pairs' edit distances from q-gram count profiles (isocon_amd/csrc/qgram_mm.hpp: 9-grams hashed into 24576
+ * presence bins plus 2 levels of 2048 excess bins; isocon_qgram_params): out_bound[p] <= ed(a[p], b[p]) always.  The main pass of the
  * nearest-neighbour search skips a pair whose bound exceeds its threshold -- the pair edlib would have answered with -1
  * (modules/nearest_neighbor_graph.py:156-162).  The reference has no counterpart; exposed so that the bound can be tested by itself.
  */
-/* binary elements of a stored q-gram profile (presence bins + levels of the excess bins): the K of the bound kernel's contraction */
-int isocon_qgram_elements(void);
+/* parameters of the stored q-gram profiles: out[0] = gram length q, out[1] = presence bins, out[2] = excess bins, out[3] = levels kept
+ * of an excess bin; returns the binary elements of a profile (out[1] + out[2] * out[3]): the K of the bound kernel's contraction */
+int isocon_qgram_params(int32_t *out);
 int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound);
 
 /*
@@ -108,7 +109,7 @@ typedef struct {
     float lanes_kernel_ms;        /* ... of the one-pair-per-lane launch of the main pass (entries with few pairs; NOT in scan_kernel_ms) */
     uint32_t reserved_;
     uint64_t pairs_lanes;         /* pairs of the main pass aligned one pair per lane (the rest went through tables) */
-    uint64_t bound_tiles;         /* 256 x 256 tiles of the bound matrix computed (each: 65 536 pairs x isocon_qgram_elements() multiply-adds) */
+    uint64_t bound_tiles;         /* 256 x 256 tiles of the bound matrix computed (each: 65 536 pairs x isocon_qgram_params() multiply-adds) */
 } isocon_nn_stats;
 
 /*
@@ -138,6 +139,8 @@ int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t 
  *   phase 1: 64-row band over every remaining admissible pair whose LOWER index is owned (1-set and 2-set alike;
  *            only the long-read fallback of the 2-set search assigns a pair to the rank that owns its read);
  *            best_inout = element-wise MIN over all ranks' phase-0 results (tight thresholds on every rank).
+ *   phase 3: phases 0 and 1 in one call, no exchange between them (single-rank callers; with several ranks the seeds of a rank's
+ *            own rows leave its thresholds loose: summed work x 2 to x 4 on C3, which is why isocon_amd/dist.py reduces after phase 0).
  *   phase 2: 128/256/512-row bands over the pairs whose lower index is owned and that involve an entry still
  *            unresolved in best_inout (= MIN over all ranks' phase-1 results), then the un-banded kernel for the owned
  *            queries whose neighbour is further than 511 edits.

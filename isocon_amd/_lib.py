@@ -51,7 +51,7 @@ SYMBOLS = {
     "isocon_store_device_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
     "isocon_store_digest": (ctypes.c_int, [ctypes.c_void_p, u64p]),
     "isocon_ed_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, i32p, ctypes.c_uint64, i32p, f32p]),
-    "isocon_qgram_elements": (ctypes.c_int, []),
+    "isocon_qgram_params": (ctypes.c_int, [i32p]),
     "isocon_qgram_bound_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, i32p]),
     "isocon_qgram_bound_matrix": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, u64p, u8p,
                                                  ctypes.c_uint64, u64p]),

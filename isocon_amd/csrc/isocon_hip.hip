@@ -588,7 +588,11 @@ extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_
     return ed_pairs_impl(s, a, b, k, n_pairs, out_ed, kernel_ms, nullptr);
 }
 
-extern "C" int isocon_qgram_elements(void) { return QM_K; }
+extern "C" int isocon_qgram_params(int32_t *out)
+{
+    if (out) { out[0] = QG_Q; out[1] = QG_B0; out[2] = QG_B1; out[3] = QG_CAP; }
+    return QM_K;
+}
 
 // q-gram lower bounds of explicit pairs (qgram_mm.hpp): what the main pass of the NN search consults, exposed for tests
 extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound)

@@ -24,7 +24,7 @@
 namespace isocon {
 
 static constexpr int QG_Q = 9;            // gram length
-static constexpr int QG_B0 = 16384;       // presence bins (the 4^q gram codes hashed into them)
+static constexpr int QG_B0 = 24576;       // presence bins (the 4^q gram codes hashed into them)
 static constexpr int QG_B1 = 2048;        // excess bins (presence bin mod QG_B1)
 static constexpr int QG_CAP = 2;          // levels kept of an excess bin
 static constexpr int QM_K = QG_B0 + QG_B1 * QG_CAP;     // binary elements per profile
@@ -37,6 +37,7 @@ static constexpr int QM_STAGES = 4;       // LDS ring: QM_STAGES x 2 operands x 
 static constexpr int QM_STAGE_BYTES = 2 * QM_TILE * QM_ROWB;
 static constexpr int QM_OUT_STRIDE = QM_TILE + 8;       // bytes per row of the epilogue's byte tile in LDS (66 dwords: 2-way on the dword writes)
 static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 2 * 16 * 2 + 256 * 4 + 256 * (4 + 4 + 8 + 4);
+static constexpr int QM_SEEDS = 4;             // seed candidates kept per row and per column of the matrix: the smallest bound of every fourth tile
 static constexpr uint32_t QM_HUB_BOUND = 36;   // a pair with a bound up to this counts towards its ends' hub scores (nn_list.hpp: which end's table a pair uses)
 static constexpr size_t QM_LDS_BYTES = (size_t)QM_STAGES * QM_STAGE_BYTES + QM_META_BYTES;
 static_assert(QG_B0 % 128 == 0 && QG_B1 % 256 == 0 && QG_B0 % QG_B1 == 0, "K-blocks of 128 elements; excess bin = presence bin mod QG_B1");
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
             if (chunk == 0) {
                 if (rowmin != nullptr && key != 0xffffffffu) {
                     const uint64_t e = (uint64_t)J * QM_TILE + (key & 0xffu) - (uint64_t)qe - 1;
-                    atomicMin(rowmin + ((size_t)I * QM_TILE + ql), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)e);
+                    atomicMin(rowmin + ((size_t)I * QM_TILE + ql) * QM_SEEDS + (J % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)e);
                 }
                 if (score != nullptr && hub) atomicAdd(score + qe, hub);
             }
@@ -382,34 +383,37 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
             const uint64_t p = (uint64_t)J * QM_TILE + tid;
             if (colmin != nullptr && m_cm[tid] != 0xffffffffu) {
                 const uint32_t key = m_cm[tid];
-                atomicMin(colmin + p, ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
+                atomicMin(colmin + p * QM_SEEDS + (I % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
             }
             if (score != nullptr && m_cnt[tid] != 0 && p < n) atomicAdd(score + p, m_cnt[tid]);
         }
     }
 }
 
-// Seed pairs from the smallest bounds: entry x with the neighbour of its row minimum (if x owns a row) and with the row entry of
-// its column minimum, unless that row's own minimum is this very pair.  pa / pb hold 2 n slots, 0xffffffff = none.
+// Seed pairs from the smallest bounds: entry x with the neighbours of its row minima (if x owns a row) and with the row entries of
+// its column minima (QM_SEEDS of each: one per class of tiles).  pa / pb hold 2 QM_SEEDS n slots, 0xffffffff = none; a pair that
+// appears twice is simply aligned twice.
 __global__ __launch_bounds__(256) void k_qgram_seed_pairs(const unsigned long long *__restrict__ rowmin, const unsigned long long *__restrict__ colmin,
                                                            uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
                                                            uint32_t *__restrict__ pa, uint32_t *__restrict__ pb)
 {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     if (x >= n) return;
-    uint32_t a0 = 0xffffffffu, b0 = 0xffffffffu, a1 = 0xffffffffu, b1 = 0xffffffffu;
-    if (x >= q_begin && (x - q_begin) % q_stride == 0 && (x - q_begin) / q_stride < nq) {
-        const unsigned long long kr = rowmin[(x - q_begin) / q_stride];
-        if (kr != ~0ull) { a0 = x; b0 = x + 1u + (uint32_t)kr; }
+    const bool has_row = x >= q_begin && (x - q_begin) % q_stride == 0 && (x - q_begin) / q_stride < nq;
+    const uint32_t s = has_row ? (x - q_begin) / q_stride : 0u;
+#pragma unroll
+    for (int c = 0; c < QM_SEEDS; ++c) {
+        uint32_t a0 = 0xffffffffu, b0 = 0xffffffffu, a1 = 0xffffffffu, b1 = 0xffffffffu;
+        if (has_row) {
+            const unsigned long long kr = rowmin[(size_t)s * QM_SEEDS + c];
+            if (kr != ~0ull) { a0 = x; b0 = x + 1u + (uint32_t)kr; }
+        }
+        const unsigned long long kc = colmin[(size_t)x * QM_SEEDS + c];
+        if (kc != ~0ull) { a1 = (uint32_t)kc; b1 = x; }          // a row entry: q = q_begin + s * q_stride by construction
+        const size_t at = ((size_t)x * QM_SEEDS + c) * 2;
+        pa[at] = a0; pb[at] = b0;
+        pa[at + 1] = a1; pb[at + 1] = b1;
     }
-    const unsigned long long kc = colmin[x];
-    if (kc != ~0ull) {
-        const uint32_t q = (uint32_t)kc;               // a row entry: q = q_begin + s * q_stride by construction
-        const unsigned long long kq = rowmin[(q - q_begin) / q_stride];
-        if (kq == ~0ull || q + 1u + (uint32_t)kq != x) { a1 = q; b1 = x; }
-    }
-    pa[2 * (size_t)x] = a0; pb[2 * (size_t)x] = b0;
-    pa[2 * (size_t)x + 1] = a1; pb[2 * (size_t)x + 1] = b1;
 }
 
 // The same bound for an explicit pair list (one wave per pair; tests and diagnostics: isocon_qgram_bound_pairs).

@@ -4,13 +4,12 @@ The packed sequence set is replicated on every GPU (31 MB for 50 k x 2.5 kb).  T
 unordered pair once, on the rank that owns the pair's LOWER index; rank r of N owns the entries r, r+N, r+2N, ... of the
 length-sorted order (a cyclic split: every rank gets the same mix of dense and sparse length regions, so the very uneven
 windows balance by themselves; `shard_ranges` is the contiguous alternative, balanced by estimated window sizes).
-Phase 0 = seed pass (64 nearest longer neighbours of the owned entries); phase 1 = 64-row band over all other admissible
-pairs; phase 2 = 128/256/512-row bands (only entries still unresolved after the min-reduction act as queries) and the
-un-banded kernel for the owned queries whose neighbour is further than 511 edits.  Exchange steps (the only data-path
-collectives):
-    all_reduce(MIN) of best[n]   after each phase (tight thresholds everywhere; phase 2 and its
-                                 reduction are skipped when no query is left unresolved); the same tensor carries every
-                                 rank's status word and edge count                               (4 B x (n + 1 + N))
+Phase 0 = q-gram bounds of the rank's rows and the seeds they give; phase 1 = survivor lists and alignments of those rows;
+phase 2 = 128/256/512-row bands and the un-banded kernel, only if the reduced bounds leave a query unresolved.  Exchange steps
+(the only data-path collectives):
+    all_reduce(MIN) of best[n]   after phase 0 (global seeds: without it the ranks' thresholds stay loose and the summed work
+                                 doubles) and after phase 1 (and 2); the same tensor carries every rank's status word and
+                                 edge count                                                      (4 B x (n + 1 + N))
     all_gather of the candidate edges that attain best[] on their rank, in fixed-size blocks of the largest count
     known from the last reduction (no size exchange)                                           (12 B x edges)
 The reference has no distributed path (its Pool chunking: /root/reference/modules/nearest_neighbor_graph.py:33-35).
@@ -124,17 +123,22 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
     qb, qe, qs = rank, n, world          # cyclic ownership
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
+    nb = len(best)
+    lens_np = np.asarray(store.lens)[:n]
+    is_query = np.ones(n, dtype=bool)
+    if is_converged is not None:
+        is_query &= np.asarray(is_converged)[:n] == 0
+    if is_target is not None:
+        is_query &= np.asarray(is_target)[:n] == 0
+    # Phase 0 = q-gram bounds of the rank's rows + the seeds they give; phase 1 = survivor lists + alignments of those rows (finds the
+    # bound matrix of phase 0 still in place); phase 2 = wide bands, only when the reduced bounds leave a query unresolved.  The
+    # reduction between phases 0 and 1 is what keeps the work constant: a rank's seeds only tighten the entries its own rows reach,
+    # and without the exchange every rank aligns against looser thresholds -- measured on C3 with the two phases fused into one call
+    # (isocon_nn_partial phase 3): summed DP work x 1.98 / 2.68 / 3.94 at 2 / 4 / 8 ranks (profiles/r03d_emulate_sharding_fused.log).
     for phase in (0, 1, 2):
         if phase == 2:
-            # Nothing left for the wide bands (isocon_nn_partial's own test: a query without a neighbour within 63 edits
-            # that is longer than 63)?  best[] is identical on all ranks after the reduction, so all ranks skip together:
-            # one call and one collective less per step.
-            is_query = np.ones(n, dtype=bool)
-            if is_converged is not None:
-                is_query &= np.asarray(is_converged)[:n] == 0
-            if is_target is not None:
-                is_query &= np.asarray(is_target)[:n] == 0
-            if not (is_query & (best[:n] == _lib.NN_INF) & (np.asarray(store.lens)[:n] > 63)).any():
+            # best[] is identical on all ranks after the reduction, so all ranks skip (or run) this phase together
+            if not (is_query & (best[:n] == _lib.NN_INF) & (lens_np > 63)).any():
                 stats_all.append({k: 0 for k in stats_all[-1]} if stats_all else {})
                 continue
         # A rank that fails here (out of memory, a HIP error) must not leave the others blocked in the collective: its
@@ -150,19 +154,21 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         hits_all.append(hits)
         stats_all.append(stats)
         # one reduction carries: best[n] | this rank's status | -(edges this rank holds so far) in its own slot (0 in the
-        # others' slots): after MIN every rank knows every rank's edge count, so the gather below needs no size exchange
-        nb = len(best)
-        t = torch.zeros(nb + 1 + world, dtype=torch.int32)
+        # others' slots): after MIN every rank knows every rank's edge count, so the gather below needs no size exchange.
+        # The tensor is assembled in pinned memory and reduced on the device RCCL runs on.
+        t = torch.empty(nb + 1 + world, dtype=torch.int32, pin_memory=device.type == "cuda")
         t[:nb] = torch.from_numpy(best)
+        t[nb:] = 0
         t[nb] = -1 if err is not None else 0
         t[nb + 1 + rank] = -sum(len(h) for h in hits_all)
-        t = t.to(device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)           # exchange step 1 (and 2)
-        t = t.cpu()
+        td = t.to(device, non_blocking=True) if device.type == "cuda" else t
+        dist.all_reduce(td, op=dist.ReduceOp.MIN)           # THE exchange of thresholds
+        if device.type == "cuda":
+            t.copy_(td, non_blocking=False)
         if int(t[nb]) != 0:
             raise RuntimeError("sharded_nn_graph: phase %d failed on %s" % (phase, "this rank: %r" % (err,) if err is not None else "another rank"))
         best[:] = t[:nb].numpy()
-        counts = (-t[nb + 1:]).numpy()
+        counts = (-t[nb + 1:]).numpy().copy()
         tl = lap("reduce_min", tl)
     hits = np.concatenate(hits_all, axis=0) if hits_all else np.zeros((0, 3), np.int32)
     if len(hits):   # only edges that attain the global minimum of their endpoint travel

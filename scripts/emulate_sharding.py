@@ -16,7 +16,9 @@ for world in (2, 4, 8):
     best = np.full(n, _lib.NN_INF, dtype=np.int32)
     tot_cols = 0; tot_pairs = 0; crit = 0.0; walls = []
     hits_all = []
-    for phase in (0, 1, 2):
+    for phase in ((3, 2) if os.environ.get("FUSED") else (0, 1, 2)):       # dist.sharded_nn_graph runs 0, 1, 2; FUSED=1: seeds + pass in one call, no exchange between them
+        if phase == 2 and not ((best == _lib.NN_INF) & (np.asarray(st.lens) > 63)).any():
+            continue
         bests = []; kms = []
         for r in range(world):
             b = best.copy()

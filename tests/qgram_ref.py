@@ -3,10 +3,21 @@ the presence bits of its q-grams hashed into B0 bins followed by the excess coun
 and capped at CAP; bound = ceil((max(|A|, |B|) - sum min(A, B)) / q)."""
 import numpy as np
 
-Q = 9
-B0 = 16384
-B1 = 2048
-CAP = 2
+
+
+def _params():
+    """the library's own constants (it loads without a GPU); the values of this round as a fallback"""
+    try:
+        import ctypes
+        from isocon_amd import _lib
+        out = (ctypes.c_int32 * 4)()
+        _lib.load().isocon_qgram_params(out)
+        return tuple(int(v) for v in out)
+    except Exception:
+        return 9, 24576, 2048, 2
+
+
+Q, B0, B1, CAP = _params()
 
 _CODE = np.zeros(256, np.int64)
 _CODE[ord("C")] = 1

@@ -32,7 +32,7 @@ class FakeStore(object):
         conv = np.zeros(n, bool) if is_converged is None else np.asarray(is_converged, bool)
         if phase == 0:      # seed pass: nothing in this stand-in
             pass
-        elif phase == 1:    # pairs owned through their lower index, band limit 63
+        elif phase in (1, 3):    # pairs owned through their lower index, band limit 63
             for q in range(q_begin, q_end, q_stride):
                 for t in range(q + 1, n):
                     if self.lens[t] - self.lens[q] > 63:

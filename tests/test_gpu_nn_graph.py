@@ -101,18 +101,20 @@ def test_sharded_partial_matches_single_call():
     cut = n // 3
     for shards in (((0, cut, 1), (cut, n, 1)),              # contiguous ranges
                    ((0, n, 3), (1, n, 3), (2, n, 3))):      # cyclic ownership (what dist.sharded_nn_graph uses)
-        hits = []
-        red = np.full(n, _lib.NN_INF, dtype=np.int32)
-        for phase in (0, 1, 2):     # seed, 64-row band, wide bands; min-reduction after each
-            bests = []
-            for (b, e, stride) in shards:
-                best = red.copy()
-                h, _ = st.nn_partial(b, e, phase, best, q_stride=stride)
-                bests.append(best); hits.append(h)
-            red = np.minimum.reduce(bests)
-        best2, rp2, cols2 = nn_finalize(n, red, np.concatenate(hits))
-        assert best1.tolist() == best2.tolist()
-        assert rp1.tolist() == rp2.tolist() and cols1.tolist() == cols2.tolist()
+        for phases in ((0, 1, 2),      # seed, 64-row band, wide bands; min-reduction after each
+                       (3, 2)):        # seeds + 64-row band in one call (what dist.sharded_nn_graph runs), wide bands
+            hits = []
+            red = np.full(n, _lib.NN_INF, dtype=np.int32)
+            for phase in phases:
+                bests = []
+                for (b, e, stride) in shards:
+                    best = red.copy()
+                    h, _ = st.nn_partial(b, e, phase, best, q_stride=stride)
+                    bests.append(best); hits.append(h)
+                red = np.minimum.reduce(bests)
+            best2, rp2, cols2 = nn_finalize(n, red, np.concatenate(hits))
+            assert best1.tolist() == best2.tolist()
+            assert rp1.tolist() == rp2.tolist() and cols1.tolist() == cols2.tolist()
 
 
 def test_long_reads_take_the_other_main_pass_kernels():
