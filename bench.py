@@ -532,12 +532,17 @@ def wrappers(accs, seqs_all):
     G_star, partition, M, converged = partitions.partition_strings(S, P())
     n_pairs = sum(len(v) for v in partition.values())
     t0 = time.perf_counter(); ed = EAM.edlib_align_sequences(partition); t_ed = time.perf_counter() - t0
+    # twice: the first call of a process also allocates the pinned output buffers (2 x 146 MB, ~0.1 s, kept for the following
+    # calls -- the pipeline aligns once per correction step); both are reported
+    t0 = time.perf_counter(); sw = SWM.sw_align_sequences(ed); t_sw_first = time.perf_counter() - t0
+    del sw
     t0 = time.perf_counter(); sw = SWM.sw_align_sequences(ed); t_sw = time.perf_counter() - t0
     n_sw = sum(len(v) for v in sw.values())
     return {"compute_nearest_neighbor_graph_wall_ms": t_nn * 1e3, "compute_nearest_neighbor_graph_kernel_ms": kern, "nn_edges": n_edges,
             "partition_centres": len(partition), "partition_pairs": n_pairs,
             "edlib_align_sequences_wall_ms": t_ed * 1e3, "edlib_align_sequences_pairs_per_s": n_pairs / t_ed if t_ed > 0 else None,
-            "sw_align_sequences_wall_ms": t_sw * 1e3, "sw_align_sequences_pairs_per_s": n_sw / t_sw if t_sw > 0 else None,
+            "sw_align_sequences_wall_ms": t_sw * 1e3, "sw_align_sequences_first_call_wall_ms": t_sw_first * 1e3,
+            "sw_align_sequences_pairs_per_s": n_sw / t_sw if t_sw > 0 else None,
             "note": "public functions end to end (dict of 2.5 kb strings in, dict out); the timed region above starts with the store resident"}
 
 

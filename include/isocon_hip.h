@@ -51,6 +51,14 @@ void isocon_release_scratch(void);
  * (modules/nearest_neighbor_graph.py:246 / :208).
  */
 int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t n, isocon_store **out);
+/* The same store from n separate buffers (seq_ptrs[i], seq_lens[i] bytes each): what a host language with its own string objects
+ * has -- the library gathers them into its pinned staging buffer while the previous piece is on its way to the device, so the
+ * caller does not have to build one contiguous copy first (125 MB at 50 000 x 2.5 kb). */
+int isocon_store_create_ptrs(const uint8_t *const *seq_ptrs, const uint64_t *seq_lens, uint32_t n, isocon_store **out);
+/* Pinned host memory for the caller's large input / output buffers (gapped alignments: 2 x 130 MB at 50 000 pairs): copies between
+ * the device and these buffers skip the library's staging.  NULL if the allocation fails.  Ordinary memory works everywhere too. */
+void *isocon_host_alloc(uint64_t bytes);
+void isocon_host_free(void *p);
 void isocon_store_destroy(isocon_store *s);
 uint32_t isocon_store_size(const isocon_store *s);
 /* 64-bit digest of the whole packed set, order-sensitive (computed on the device from the planes and the lengths): the

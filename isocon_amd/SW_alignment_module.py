@@ -14,7 +14,7 @@ from .store import store_for_pairs
 
 TIE_POLICY = 0
 _OPS = "=XID"
-# id(result tuple) -> (the tuple, its CIGAR ops as uint32 array) for the alignments of the most recent batch call; lets
+# id(result tuple) -> (the tuple, the batch's CIGAR ops as uint32 array, begin, end) for the alignments of the most recent batch call; lets
 # isocon_amd.functions.filter_exon_differences work on run-length ops instead of re-scanning the gapped strings.
 _OPS_CACHE = {}
 
@@ -95,16 +95,34 @@ def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed
     finally:
         if owned:
             st.close()
-    aln_a = str(aln_a, "ascii")
-    aln_b = str(aln_b, "ascii")
-    ptr = ptr.tolist()
     counts = res[:, 3:6].tolist()
-    out = [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], tuple(counts[p])) for p in range(len(pairs))]
+    from . import _lib
+    H = _lib.pyhelp()
+    if H is not None:
+        # the 2 x 50 000 gapped strings are cut straight out of the (pinned) byte buffers
+        ptr64 = np.ascontiguousarray(ptr, dtype=np.int64)
+        ba, bb = np.frombuffer(aln_a, dtype=np.uint8), np.frombuffer(aln_b, dtype=np.uint8)
+        sa = H.split_ascii(ba.ctypes.data if len(ba) else 0, ptr64.ctypes.data, len(pairs))
+        sb = H.split_ascii(bb.ctypes.data if len(bb) else 0, ptr64.ctypes.data, len(pairs))
+        out = list(zip(sa, sb, map(tuple, counts)))
+    else:
+        aln_a = str(aln_a, "ascii")
+        aln_b = str(aln_b, "ascii")
+        ptr = ptr.tolist()
+        out = [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], tuple(counts[p])) for p in range(len(pairs))]
     _OPS_CACHE.clear()
     op = ops_ptr.tolist()
     for p, t in enumerate(out):
-        _OPS_CACHE[id(t)] = (t, ops[op[p]:op[p + 1]])
+        _OPS_CACHE[id(t)] = (t, ops, op[p], op[p + 1])          # (the ops are sliced by whoever asks: ops_of)
     return out
+
+
+def ops_of(result_tuple):
+    """CIGAR ops (uint32 array) of an alignment tuple returned by the most recent batch call, or None"""
+    c = _OPS_CACHE.get(id(result_tuple))
+    if c is None or c[0] is not result_tuple:
+        return None
+    return c[1][c[2]:c[3]]
 
 
 def parasail_alignment(s1, s2, i, j, x_acc="", y_acc="", match_score=2, mismatch_penalty=-3, opening_penalty=2, gap_ext=0):

@@ -46,6 +46,9 @@ SYMBOLS = {
     "isocon_device_count": (ctypes.c_int, []),
     "isocon_release_scratch": (None, []),
     "isocon_store_create": (ctypes.c_int, [u8p, u64p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
+    "isocon_store_create_ptrs": (ctypes.c_int, [u64p, u64p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
+    "isocon_host_alloc": (ctypes.c_void_p, [ctypes.c_uint64]),
+    "isocon_host_free": (None, [ctypes.c_void_p]),
     "isocon_store_destroy": (None, [ctypes.c_void_p]),
     "isocon_store_size": (ctypes.c_uint32, [ctypes.c_void_p]),
     "isocon_store_device_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
@@ -95,7 +98,38 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=SRC_DIR)
+    build_pyhelp(verbose)
     return SO_PATH
+
+
+PYHELP_SO = os.path.join(_HERE, "_pyhelp.so")
+
+
+def build_pyhelp(verbose: bool = False):
+    """The CPython helper of the wrappers (cpy/_pyhelp.c: string lists <-> flat buffers); optional -- pure-Python loops otherwise."""
+    import sysconfig
+    src = os.path.join(_HERE, "cpy", "_pyhelp.c")
+    if not os.path.exists(src):
+        return None
+    if os.path.exists(PYHELP_SO) and os.path.getmtime(PYHELP_SO) >= os.path.getmtime(src):
+        return PYHELP_SO
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-I" + sysconfig.get_paths()["include"], "-o", PYHELP_SO, src]
+    if verbose:
+        print(" ".join(cmd))
+    try:
+        subprocess.check_call(cmd)
+    except Exception:
+        return None
+    return PYHELP_SO
+
+
+def pyhelp():
+    """the helper module, or None"""
+    try:
+        from . import _pyhelp
+        return _pyhelp
+    except Exception:
+        return None
 
 
 def load():

@@ -117,9 +117,18 @@ static PinnedStage g_stage;
 static constexpr size_t kStageBytes = (size_t)32 << 20;
 static constexpr size_t kStageMin = (size_t)32 << 10;      // smaller copies: the runtime's own staging path is fine
 
+// Host buffers handed out by isocon_host_alloc are pinned: copies to / from them need no staging.
+static std::vector<std::pair<const char *, size_t>> g_pinned;
+static bool is_pinned(const void *p, size_t bytes)
+{
+    for (const auto &r : g_pinned)
+        if ((const char *)p >= r.first && (const char *)p + bytes <= r.first + r.second) return true;
+    return false;
+}
+
 static hipError_t copy_d2h(void *dst, const void *dsrc, size_t bytes)
 {
-    if (bytes < kStageMin) return hipMemcpy(dst, dsrc, bytes, hipMemcpyDeviceToHost);
+    if (bytes < kStageMin || is_pinned(dst, bytes)) return hipMemcpy(dst, dsrc, bytes, hipMemcpyDeviceToHost);
     char *st = static_cast<char *>(g_stage.get(kStageBytes));
     if (!st) return hipMemcpy(dst, dsrc, bytes, hipMemcpyDeviceToHost);
     for (size_t off = 0; off < bytes; off += kStageBytes) {
@@ -133,7 +142,7 @@ static hipError_t copy_d2h(void *dst, const void *dsrc, size_t bytes)
 
 static hipError_t copy_h2d(void *ddst, const void *src, size_t bytes)
 {
-    if (bytes < kStageMin) return hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice);
+    if (bytes < kStageMin || is_pinned(src, bytes)) return hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice);
     char *st = static_cast<char *>(g_stage.get(kStageBytes));
     if (!st) return hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice);
     for (size_t off = 0; off < bytes; off += kStageBytes) {
@@ -249,9 +258,11 @@ int isocon_init(int device_ordinal)
     return ISOCON_OK;
 }
 
-int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t n, isocon_store **out)
+// ascii != nullptr: one contiguous buffer addressed by offsets; else the sequences lie at seq_ptrs[i] (offsets still hold the prefix
+// sums of their lengths) and are gathered into the two halves of the pinned staging buffer, one half on its way to the device
+// while the other is being filled.
+static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptrs, const uint64_t *offsets, uint32_t n, isocon_store **out)
 {
-    if (!out || (!ascii && n) || !offsets) return ISOCON_E_ARG;
     *out = nullptr;
     int32_t maxlen = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -279,7 +290,36 @@ int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t 
         const unsigned long long none = ~0ull;
         int rc = ISOCON_OK;
         if ((rc = d_ascii.alloc(total ? total : 16)) || (rc = d_off.alloc((size_t)(nn + 1) * 8)) || (rc = d_bad.alloc(8))) { isocon_store_destroy(st); return rc; }
-        bool ok = (total == 0 || copy_h2d(d_ascii.p, ascii + base, total) == hipSuccess) &&
+        bool up = true;
+        if (total && ascii) up = copy_h2d(d_ascii.p, ascii + base, total) == hipSuccess;
+        else if (total) {
+            char *stg = static_cast<char *>(g_stage.get(kStageBytes));
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            up = stg != nullptr && hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            const size_t half = kStageBytes / 2;
+            uint32_t i = 0;
+            uint64_t in_seq = 0, done = 0;           // next byte to gather: byte in_seq of sequence i; bytes already sent
+            bool busy[2] = {false, false};
+            for (int h = 0; up && done < total; h ^= 1) {
+                if (busy[h]) up = hipEventSynchronize(ev[h]) == hipSuccess;
+                size_t fill = 0;
+                while (fill < half && i < n) {
+                    const uint64_t len = offsets[i + 1] - offsets[i];
+                    const size_t take = (size_t)std::min<uint64_t>(len - in_seq, half - fill);
+                    if (take) memcpy(stg + h * half + fill, seq_ptrs[i] + in_seq, take);
+                    fill += take; in_seq += take;
+                    if (in_seq == len) { ++i; in_seq = 0; }
+                }
+                up = up && hipMemcpyAsync(static_cast<char *>(d_ascii.p) + done, stg + h * half, fill, hipMemcpyHostToDevice, 0) == hipSuccess &&
+                     hipEventRecord(ev[h], 0) == hipSuccess;
+                busy[h] = true;
+                done += fill;
+            }
+            up = up && hipStreamSynchronize(0) == hipSuccess;
+            if (ev[0]) (void)hipEventDestroy(ev[0]);
+            if (ev[1]) (void)hipEventDestroy(ev[1]);
+        }
+        bool ok = up &&
                   (n == 0 || copy_h2d(d_off.p, offsets, (size_t)(n + 1) * 8) == hipSuccess) &&
                   hipMemcpy(d_bad.p, &none, 8, hipMemcpyHostToDevice) == hipSuccess && copy_h2d(st->d_lens, lens.data(), lbytes) == hipSuccess;
         unsigned long long bad = none;
@@ -314,6 +354,39 @@ int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t 
     st->lens.resize(n);
     *out = st;
     return ISOCON_OK;
+}
+
+int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t n, isocon_store **out)
+{
+    if (!out || (!ascii && n) || !offsets) return ISOCON_E_ARG;
+    return store_create_impl(ascii, nullptr, offsets, n, out);
+}
+
+int isocon_store_create_ptrs(const uint8_t *const *seq_ptrs, const uint64_t *seq_lens, uint32_t n, isocon_store **out)
+{
+    if (!out || (n && (!seq_ptrs || !seq_lens))) return ISOCON_E_ARG;
+    std::vector<uint64_t> offsets((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (seq_lens[i] && !seq_ptrs[i]) return ISOCON_E_ARG;
+        offsets[i + 1] = offsets[i] + seq_lens[i];
+    }
+    return store_create_impl(nullptr, seq_ptrs, offsets.data(), n, out);
+}
+
+void *isocon_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_pinned.emplace_back((const char *)p, (size_t)(bytes ? bytes : 16));
+    return p;
+}
+
+void isocon_host_free(void *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < g_pinned.size(); ++i)
+        if (g_pinned[i].first == (const char *)p) { g_pinned.erase(g_pinned.begin() + (long)i); break; }
+    (void)hipHostFree(p);
 }
 
 void isocon_store_destroy(isocon_store *s)

@@ -52,7 +52,7 @@ def filter_exon_differences(pairwise_alignments, min_exon_diff, ignore_ends_len)
     with_ops = [i for i, (s1, s2) in enumerate(keys) if id(pairwise_alignments[s1][s2]) in cache]
     if with_ops:
         L = _lib.load()
-        ops_list = [cache[id(pairwise_alignments[keys[i][0]][keys[i][1]])][1] for i in with_ops]
+        ops_list = [SW_alignment_module.ops_of(pairwise_alignments[keys[i][0]][keys[i][1]]) for i in with_ops]
         ptr = np.zeros(len(ops_list) + 1, dtype=np.uint64)
         np.cumsum([len(o) for o in ops_list], out=ptr[1:])
         ops = np.ascontiguousarray(np.concatenate(ops_list) if ops_list else np.zeros(0, np.uint32), dtype=np.uint32)

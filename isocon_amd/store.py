@@ -24,22 +24,34 @@ class SeqStore(object):
     def __init__(self, seqs):
         L = _lib.lib()
         self.n = len(seqs)
-        lens = np.fromiter(map(len, seqs), dtype=np.uint64, count=self.n)
-        self.lens = lens.astype(np.int64)
-        off = np.zeros(self.n + 1, dtype=np.uint64)
-        np.cumsum(lens, out=off[1:])
-        # One join, no second copy: CPython keeps an all-ASCII str as one byte per character, and PyUnicode_AsUTF8AndSize hands
-        # out that very buffer (any non-ASCII symbol makes the sizes differ -- and is outside the alphabet anyway).
-        joined = "".join(seqs)
-        size = ctypes.c_ssize_t(0)
-        addr = _utf8(ctypes.py_object(joined), ctypes.byref(size)) if joined else None
-        if joined and (not addr or size.value != int(off[self.n])):
-            raise _lib.IsoconError("isocon_store_create failed: sequence contains a symbol outside ACGT (non-ASCII character)")
-        dummy = (ctypes.c_uint8 * 1)()
         h = ctypes.c_void_p()
-        _lib.check(L.isocon_store_create(ctypes.cast(addr, _lib.u8p) if addr else dummy, _ptr(off, _lib.u64p), self.n, ctypes.byref(h)),
-                   "isocon_store_create")
-        del joined
+        H = _lib.pyhelp()
+        if H is not None and isinstance(seqs, list):
+            # the strings' own buffers go to the library, which gathers them into its pinned staging buffer (no 125 MB join)
+            ptrs = np.empty(max(self.n, 1), dtype=np.uint64)
+            lens = np.empty(max(self.n, 1), dtype=np.uint64)
+            try:
+                H.str_pointers(seqs, ptrs.ctypes.data, lens.ctypes.data)
+            except ValueError as e:
+                raise _lib.IsoconError("isocon_store_create failed: %s" % e)
+            self.lens = lens[:self.n].astype(np.int64)
+            _lib.check(L.isocon_store_create_ptrs(_ptr(ptrs, _lib.u64p), _ptr(lens, _lib.u64p), self.n, ctypes.byref(h)), "isocon_store_create")
+        else:
+            lens = np.fromiter(map(len, seqs), dtype=np.uint64, count=self.n)
+            self.lens = lens.astype(np.int64)
+            off = np.zeros(self.n + 1, dtype=np.uint64)
+            np.cumsum(lens, out=off[1:])
+            # One join, no second copy: CPython keeps an all-ASCII str as one byte per character, and PyUnicode_AsUTF8AndSize hands
+            # out that very buffer (any non-ASCII symbol makes the sizes differ -- and is outside the alphabet anyway).
+            joined = "".join(seqs)
+            size = ctypes.c_ssize_t(0)
+            addr = _utf8(ctypes.py_object(joined), ctypes.byref(size)) if joined else None
+            if joined and (not addr or size.value != int(off[self.n])):
+                raise _lib.IsoconError("isocon_store_create failed: sequence contains a symbol outside ACGT (non-ASCII character)")
+            dummy = (ctypes.c_uint8 * 1)()
+            _lib.check(L.isocon_store_create(ctypes.cast(addr, _lib.u8p) if addr else dummy, _ptr(off, _lib.u64p), self.n, ctypes.byref(h)),
+                       "isocon_store_create")
+            del joined
         self._h = h
         self._L = L
         self._fingerprint = None
@@ -202,8 +214,30 @@ class SeqStore(object):
             return out + (ms.value,) if return_ms else out
 
 
+_HOST_BUFFERS = {}
+
+
+def _host_buffer(name, nbytes, L):
+    """A grow-only uint8 buffer in pinned host memory (isocon_host_alloc) that the NEXT call of the same wrapper overwrites;
+    ordinary memory if pinning fails."""
+    cur = _HOST_BUFFERS.get(name)
+    if cur is not None and cur[1] >= nbytes:
+        return cur[2][:nbytes]
+    if cur is not None and cur[0]:
+        L.isocon_host_free(cur[0])
+    cap = int(nbytes + nbytes // 8 + 4096)
+    addr = L.isocon_host_alloc(cap)
+    if addr:
+        arr = np.frombuffer((ctypes.c_uint8 * cap).from_address(addr), dtype=np.uint8)
+    else:
+        addr, arr = 0, np.empty(cap, dtype=np.uint8)
+    _HOST_BUFFERS[name] = (addr, cap, arr)
+    return arr[:nbytes]
+
+
 def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ops=False, ed_upper=None):
-    """Gapped strings straight from the device: returns (aln_a bytes, aln_b bytes, aln_ptr int64[n+1], res int32[n,6])."""
+    """Gapped strings straight from the device: returns (aln_a bytes, aln_b bytes, aln_ptr int64[n+1], res int32[n,6]).
+    The two byte buffers are views of buffers the next call reuses: decode them before calling again."""
     a = np.ascontiguousarray(a, dtype=np.uint32)
     b = np.ascontiguousarray(b, dtype=np.uint32)
     n = len(a)
@@ -219,8 +253,8 @@ def _sg_strings(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, ret
     need_ops, need_aln = ctypes.c_uint64(0), ctypes.c_uint64(0)
     while True:
         ops = np.empty(ops_cap, dtype=np.uint32)
-        aln_a = np.empty(aln_cap, dtype=np.uint8)
-        aln_b = np.empty(aln_cap, dtype=np.uint8)
+        aln_a = _host_buffer("aln_a", aln_cap, self._L)         # pinned and reused: no page faults, no staged copy (2 x 130 MB at C3)
+        aln_b = _host_buffer("aln_b", aln_cap, self._L)
         rc = self._L.isocon_sg_strings_batch(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), n, match, _ptr(mm, _lib.i8p), open_, ext,
                                              tie_policy, _ptr(ops, _lib.u32p), _ptr(ops_ptr, _lib.u64p), ops_cap, ctypes.byref(need_ops),
                                              _ptr(res, _lib.i32p), _ptr(aln_a, _lib.u8p), _ptr(aln_b, _lib.u8p), _ptr(aln_ptr, _lib.u64p),
