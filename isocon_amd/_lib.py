@@ -91,6 +91,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     """Cross-compile the HIP library for gfx950 (works without a GPU)."""
     if not force and not needs_build():
+        build_pyhelp(verbose)
         return SO_PATH
     os.makedirs(os.path.dirname(SO_PATH), exist_ok=True)
     cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
