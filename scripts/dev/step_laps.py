@@ -1,0 +1,10 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from isocon_amd import synth
+from isocon_amd.store import SeqStore
+accs, seqs, _ = synth.make_reads(50000, 2500, 10, 30001)
+seqs = sorted(dict.fromkeys(seqs), key=len)
+st = SeqStore(seqs)
+for i in range(3): st.nn_graph()
+os.environ["ISOCON_DEBUG"] = "1"
+t=time.perf_counter(); st.nn_graph(); print("wall %.2f ms" % ((time.perf_counter()-t)*1e3))
