@@ -30,7 +30,7 @@ static constexpr int NN_STAGE = NN_LIST_CHUNK + 64;
 
 // counters of the list builder, each on a cache line of its own (they are hot: tens of thousands of atomics per launch)
 struct NNPlanTotals {
-    unsigned long long n_pairs, pad0[15], n_list, pad1[15], n_small, pad2[15], n_chunks, pad3[15], n_filtered, pad4[15], overflow, pad5[15], n_chunks_part, pad6[15];
+    unsigned long long n_pairs, pad0[15], n_list, pad1[15], n_small, pad2[15], n_chunks, pad3[15], n_filtered, pad4[15], overflow, pad5[15];
 };
 
 // the matrix rows of both orientations (qgram_mm.hpp) and the hub scores that decide which end owns a pair
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
     uint32_t *st = stage[wave];
     uint32_t fill = 0, filtered = 0, kept = 0;
-    auto emit_chunk = [&](bool) {
+    auto emit_chunk = [&]() {
         unsigned long long base = 0, ci = 0;
         if (lane == 0) { base = atomicAdd(&totals->n_list, (unsigned long long)fill); ci = atomicAdd(&totals->n_chunks, 1ull); }
         base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
@@ -135,11 +135,11 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
                 if (am == 0) continue;                                   // wave-uniform
                 if (mine) st[fill + (uint32_t)__popcll(am & lt_mask)] = y[u] | (xq ? 0x40000000u : 0u) | (yq ? 0x80000000u : 0u);
                 fill += (uint32_t)__popcll(am);
-                if (fill >= NN_LIST_CHUNK) emit_chunk(true);
+                if (fill >= NN_LIST_CHUNK) emit_chunk();
             }
         }
     }
-    if (fill >= list_min) emit_chunk(false);
+    if (fill >= list_min) emit_chunk();
     // what is left goes to the pair arrays: one allocation per workgroup
     if (lane == 0) { s_small[wave] = fill; s_filtered[wave] = filtered; s_kept[wave] = kept; }
     __syncthreads();
