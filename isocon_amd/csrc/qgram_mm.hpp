@@ -391,8 +391,8 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
 }
 
 // Seed pairs from the smallest bounds: entry x with the neighbours of its row minima (if x owns a row) and with the row entries of
-// its column minima (QM_SEEDS of each: one per class of tiles).  pa / pb hold 2 QM_SEEDS n slots, 0xffffffff = none; a pair that
-// appears twice is simply aligned twice.
+// its column minima (QM_SEEDS of each: one per class of tiles), unless that row proposes the very pair itself.  pa / pb hold
+// 2 QM_SEEDS n slots, 0xffffffff = none.
 __global__ __launch_bounds__(256) void k_qgram_seed_pairs(const unsigned long long *__restrict__ rowmin, const unsigned long long *__restrict__ colmin,
                                                            uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
                                                            uint32_t *__restrict__ pa, uint32_t *__restrict__ pb)
@@ -409,7 +409,12 @@ __global__ __launch_bounds__(256) void k_qgram_seed_pairs(const unsigned long lo
             if (kr != ~0ull) { a0 = x; b0 = x + 1u + (uint32_t)kr; }
         }
         const unsigned long long kc = colmin[(size_t)x * QM_SEEDS + c];
-        if (kc != ~0ull) { a1 = (uint32_t)kc; b1 = x; }          // a row entry: q = q_begin + s * q_stride by construction
+        if (kc != ~0ull) {
+            // a row entry: q = q_begin + s * q_stride by construction; skipped when it is that row's own candidate for x's class of tiles
+            const uint32_t q = (uint32_t)kc;
+            const unsigned long long kq = rowmin[(size_t)((q - q_begin) / q_stride) * QM_SEEDS + (x / QM_TILE) % QM_SEEDS];
+            if (kq == ~0ull || q + 1u + (uint32_t)kq != x) { a1 = q; b1 = x; }
+        }
         const size_t at = ((size_t)x * QM_SEEDS + c) * 2;
         pa[at] = a0; pb[at] = b0;
         pa[at + 1] = a1; pb[at + 1] = b1;

@@ -89,6 +89,23 @@ def _digest(*arrays):
     return int.from_bytes(h.digest(), "little") >> 1
 
 
+def _staging(store, name, n_int32, device):
+    """A reusable int32 host tensor of at least n_int32 elements (pinned when the collectives run on the GPU), kept on the store."""
+    import torch
+    cache = getattr(store, "_dist_staging", None)
+    if cache is None:
+        cache = {}
+        try:
+            store._dist_staging = cache
+        except AttributeError:
+            pass
+    t = cache.get(name)
+    if t is None or t.numel() < n_int32:
+        t = torch.empty(int(n_int32 * 1.25) + 64, dtype=torch.int32, pin_memory=device.type == "cuda")
+        cache[name] = t
+    return t[:n_int32]
+
+
 def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, dist=None, device=None, return_stats=False, laps=None):
     """Exact NN graph of `store` (length-sorted) computed by all ranks of the default process group.
 
@@ -156,7 +173,7 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         # one reduction carries: best[n] | this rank's status | -(edges this rank holds so far) in its own slot (0 in the
         # others' slots): after MIN every rank knows every rank's edge count, so the gather below needs no size exchange.
         # The tensor is assembled in pinned memory and reduced on the device RCCL runs on.
-        t = torch.empty(nb + 1 + world, dtype=torch.int32, pin_memory=device.type == "cuda")
+        t = _staging(store, "reduce", nb + 1 + world, device)          # pinned, reused from call to call
         t[:nb] = torch.from_numpy(best)
         t[nb:] = 0
         t[nb] = -1 if err is not None else 0
@@ -176,14 +193,22 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         hits = hits[keep]
     tl = time.perf_counter()
     # exchange step 3: ONE all_gather of fixed-size blocks (the largest count of the reduction above; unused rows are -1)
-    kmax = int(counts.max()) if len(counts) else 0
-    buf = torch.full((max(kmax, 1), 3), -1, dtype=torch.int32)
+    kmax = max(int(counts.max()) if len(counts) else 0, 1)
+    buf = _staging(store, "edges", kmax * 3, device).view(kmax, 3)
+    buf[len(hits):] = -1
     if len(hits):
         buf[:len(hits)] = torch.from_numpy(np.ascontiguousarray(hits, dtype=np.int32))
-    buf = buf.to(device)
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf)
-    gathered = torch.cat(outs, dim=0).cpu().numpy()
+    if device.type == "cuda":
+        bd = buf.to(device, non_blocking=True)
+        out_d = torch.empty((world * kmax, 3), dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(out_d, bd)
+        out_h = _staging(store, "gathered", world * kmax * 3, device).view(world * kmax, 3)
+        out_h.copy_(out_d, non_blocking=False)
+        gathered = out_h.numpy()
+    else:
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        gathered = torch.cat(outs, dim=0).numpy()
     gathered = gathered[gathered[:, 2] >= 0]
     tl = lap("gather_edges", tl)
     out = nn_finalize(n, best[:n], gathered)

@@ -20,7 +20,7 @@ seqs = sorted(dict.fromkeys(seqs), key=len)
 st = SeqStore(seqs)
 st.nn_graph()
 sharded_nn_graph(st, dist=dist, device=dev)
-for rep in range(3):
+for rep in range(10):
     t = time.time(); b0, r0, c0, s0 = st.nn_graph(); t1 = time.time() - t
     laps = {}
     t = time.time(); b1, r1, c1, stats = sharded_nn_graph(st, dist=dist, device=dev, return_stats=True, laps=laps); t2 = time.time() - t
