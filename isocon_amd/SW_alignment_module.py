@@ -70,12 +70,11 @@ def ops_to_cigar(ops):
 
 def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0, ed_upper=None):
     """[(s1, s2)], per-pair mismatch penalties -> [(s1_aln, s2_aln, (matches, mismatches, indels))].
+    mismatch None: the penalty of every pair from the error-rate bucket of its ed_upper (SWM:102-109).
     ed_upper: the pairs' edit distances where the caller has them (they only narrow the computed part of the matrix;
     the device re-aligns in full whatever it cannot certify, see include/isocon_hip.h)."""
     if not pairs:
         return []
-    if any(len(s1) == 0 or len(s2) == 0 for s1, s2 in pairs):
-        raise ValueError("empty sequence in an alignment pair")
     from . import perf_log
     with perf_log.call("SW_alignment_module.alignments", pairs=len(pairs), open=opening_penalty, ext=gap_ext, hints=ed_upper is not None):
         return _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed_upper)
@@ -84,6 +83,14 @@ def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0, e
 def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed_upper):
     st, a, b, owned = store_for_pairs(pairs)
     try:
+        la, lb = st.lens[a], st.lens[b]
+        if bool((la == 0).any() or (lb == 0).any()):
+            raise ValueError("empty sequence in an alignment pair")
+        if mismatch is None:
+            # SWM:102-109 for the whole list: error_rate = ed / min(len) as IEEE doubles, like the reference's float division
+            rate = np.asarray(ed_upper, dtype=np.float64) / np.minimum(la, lb).astype(np.float64)
+            mismatch = np.where(rate <= 0.01, -1, np.where(rate <= 0.09, -2, -4)).astype(np.int8)
+            ed_upper = np.where((np.asarray(ed_upper) >= 0) & (np.asarray(ed_upper) < 2 ** 30), ed_upper, -1).astype(np.int32)
         if ed_upper is None and len(pairs) >= 64:
             # callers without distances (hypothesis_test_module's candidate pairs, parasail_alignment batches): the device
             # computes them first (isocon_ed_pairs, ~1e7 pairs/s) -- with a bound the alignment runs inside its certified band
@@ -95,7 +102,7 @@ def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed
     finally:
         if owned:
             st.close()
-    counts = res[:, 3:6].tolist()
+    counts = list(zip(res[:, 3].tolist(), res[:, 4].tolist(), res[:, 5].tolist()))          # (matches, mismatches, indels) tuples
     from . import _lib
     H = _lib.pyhelp()
     if H is not None:
@@ -104,12 +111,12 @@ def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed
         ba, bb = np.frombuffer(aln_a, dtype=np.uint8), np.frombuffer(aln_b, dtype=np.uint8)
         sa = H.split_ascii(ba.ctypes.data if len(ba) else 0, ptr64.ctypes.data, len(pairs))
         sb = H.split_ascii(bb.ctypes.data if len(bb) else 0, ptr64.ctypes.data, len(pairs))
-        out = list(zip(sa, sb, map(tuple, counts)))
+        out = list(zip(sa, sb, counts))
     else:
         aln_a = str(aln_a, "ascii")
         aln_b = str(aln_b, "ascii")
         ptr = ptr.tolist()
-        out = [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], tuple(counts[p])) for p in range(len(pairs))]
+        out = [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], counts[p]) for p in range(len(pairs))]
     _OPS_CACHE.clear()
     op = ops_ptr.tolist()
     for p, t in enumerate(out):
@@ -158,26 +165,42 @@ def _ed_hint(ed):
     return ed if 0 <= ed < 2 ** 30 else -1
 
 
+def _int_distances(vals):
+    """the callers' edit distances as an int64 array, or None if one of them is not an integer (then: the per-pair path)"""
+    try:
+        arr = np.asarray(vals)
+        if arr.dtype.kind in "iu" and arr.ndim == 1:
+            return arr.astype(np.int64)
+    except (TypeError, ValueError, OverflowError):
+        pass
+    return None
+
+
+def _batch(keys_pairs_eds):
+    """[(key pair, (s1, s2), ed)] -> alignments in that order; penalties per pair as in SWM:102-109"""
+    pairs = [t[1] for t in keys_pairs_eds]
+    eds = _int_distances([t[2] for t in keys_pairs_eds])
+    if eds is not None:
+        return _align_pairs(pairs, None, ed_upper=eds)
+    pens = [_penalty(t[2], t[1][0], t[1][1]) for t in keys_pairs_eds]
+    return _align_pairs(pairs, pens, ed_upper=[_ed_hint(t[2]) for t in keys_pairs_eds])
+
+
 def sw_align_sequences(matches, nr_cores=1, mismatch_penalty=-1):
     """SWM:89-164.  {s1: {s2: ed}} -> {s1: {s2: (s1_aln, s2_aln, (matches, mismatches, indels))}}."""
-    pairs = [(s1, s2) for s1 in matches for s2 in matches[s1]]
-    pens = [_penalty(matches[s1][s2], s1, s2) for s1, s2 in pairs]
-    eds = [_ed_hint(matches[s1][s2]) for s1, s2 in pairs]
+    items = [((s1, s2), (s1, s2), ed) for s1, inner in matches.items() for s2, ed in inner.items()]
     exact_matches = {}
-    for (s1, s2), stats in zip(pairs, _align_pairs(pairs, pens, ed_upper=eds)):
+    for (key, _, _), stats in zip(items, _batch(items)):
         if stats:
-            exact_matches.setdefault(s1, {})[s2] = stats
+            exact_matches.setdefault(key[0], {})[key[1]] = stats
     return exact_matches
 
 
 def sw_align_sequences_keeping_accession(matches, nr_cores=1):
     """SWM:167-249.  {acc1: {acc2: (s1, s2, ed)}} -> {acc1: {acc2: (s1_aln, s2_aln, (matches, mismatches, indels))}}."""
-    keys = [(a1, a2) for a1 in matches for a2 in matches[a1]]
-    pairs = [(matches[a1][a2][0], matches[a1][a2][1]) for a1, a2 in keys]
-    pens = [_penalty(matches[a1][a2][2], matches[a1][a2][0], matches[a1][a2][1]) for a1, a2 in keys]
-    eds = [_ed_hint(matches[a1][a2][2]) for a1, a2 in keys]
+    items = [((a1, a2), (v[0], v[1]), v[2]) for a1, inner in matches.items() for a2, v in inner.items()]
     exact_matches = {}
-    for (a1, a2), stats in zip(keys, _align_pairs(pairs, pens, ed_upper=eds)):
+    for (key, _, _), stats in zip(items, _batch(items)):
         if stats:
-            exact_matches.setdefault(a1, {})[a2] = stats
+            exact_matches.setdefault(key[0], {})[key[1]] = stats
     return exact_matches

@@ -305,9 +305,12 @@ class _LazyIndex(object):
         self._d = None
 
     def __getitem__(self, s):
+        return self.mapping()[s]
+
+    def mapping(self):
         if self._d is None:
             self._d = {x: i for i, x in enumerate(self._seqs)}
-        return self._d[s]
+        return self._d
 
 
 def remember(store, seqs):
@@ -334,12 +337,13 @@ def store_for_pairs(pairs):
     b = np.empty(n, dtype=np.uint32)
     if index is not None and _RECENT["store"] is not None and getattr(_RECENT["store"], "_h", None):
         try:
-            for p, (x, y) in enumerate(pairs):
-                a[p] = index[x]
-                b[p] = index[y]
+            d = index.mapping()
+            a = np.fromiter((d[x] for x, _ in pairs), dtype=np.uint32, count=n)
+            b = np.fromiter((d[y] for _, y in pairs), dtype=np.uint32, count=n)
             return _RECENT["store"], a, b, False
         except KeyError:
-            pass
+            a = np.empty(n, dtype=np.uint32)
+            b = np.empty(n, dtype=np.uint32)
     index, seqs = {}, []
     for p, (x, y) in enumerate(pairs):
         ia = index.get(x)
