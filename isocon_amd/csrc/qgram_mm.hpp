@@ -11,8 +11,8 @@
 //        ed(x, y) >= ceil( (max(|A|, |B|) - M(x, y)) / q ).
 // M is a DOT PRODUCT of thermometer codes: min(a, b) = sum_t [a > t][b > t].  A profile is therefore stored as QM_K = QG_B0 +
 // QG_B1 * QG_CAP binary elements (presence bits, then QG_CAP levels of the excess bins), the bound matrix of the main pass is
-// (profiles) x (profiles)^T restricted to the length window -- a banded A B^T -- and runs on v_mfma_scale_f32_32x32x64_f8f6f4
-// with fp4 operands (1.0 = 0x2, unit scales; sums of at most QM_K ones are exact in f32): 2048 MAC per cycle and SIMD, twice
+// (profiles) x (profiles)^T restricted to the length window -- a banded A B^T -- and runs on v_mfma_f32_32x32x64_f8f6f4 (the builtin's
+// scale operands are 0: hipcc emits the non-scaled form, same products) with fp4 operands (1.0 = 0x2; sums of at most QM_K ones are exact in f32): 2048 MAC per cycle and SIMD, twice
 // the i8 rate, at 4 bits per element (scripts/ubench/mfma_fp4.hip: operand layout checked with asymmetric data, 40 cycles per
 // MFMA at the nominal clock).  The v_sad_u8 kernel this replaces moved 308 B per pair and took 17.6 ms at C3.
 //
@@ -41,7 +41,7 @@ static constexpr int QM_SEEDS = 4;             // seed candidates kept per row a
 static constexpr uint32_t QM_HUB_BOUND = 36;   // a pair with a bound up to this counts towards its ends' hub scores (nn_list.hpp: which end's table a pair uses)
 static constexpr size_t QM_LDS_BYTES = (size_t)QM_STAGES * QM_STAGE_BYTES + QM_META_BYTES;
 static_assert(QG_B0 % 128 == 0 && QG_B1 % 256 == 0 && QG_B0 % QG_B1 == 0, "K-blocks of 128 elements; excess bin = presence bin mod QG_B1");
-static_assert(QM_K % QM_KBE == 0 && QM_NKB >= QM_STAGES, "whole K-blocks");
+static_assert(QM_K % QM_KBE == 0 && QM_NKB >= QM_STAGES && QM_STAGES == 4, "whole K-blocks; the K loop's tail is written for a ring of four");
 static_assert(QM_TILE * QM_OUT_STRIDE <= QM_STAGES * QM_STAGE_BYTES, "the epilogue's byte tile reuses the ring");
 
 __host__ __device__ __forceinline__ uint32_t qg_bin(uint32_t g)
@@ -238,36 +238,92 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     // fragment addresses inside a stage (bytes): row * 64 + physical slot * 16; the K-step's slot pair is (2 ks + h)
     const int swz = (r >> 2) & 3;
     const int offA = (wp * 128 + r) * QM_ROWB, offB = QM_TILE * QM_ROWB + (wq * 64 + r) * QM_ROWB;
-    for (int kb = 0; kb < QM_NKB; ++kb) {
-        // K-block kb has landed (own loads: counted wait; everybody's: the barrier); the barrier also says that everybody is
-        // done with K-block kb - 1, whose stage the next issue overwrites
-        if (kb + 2 < QM_NKB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (kb + 1 < QM_NKB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kb + QM_STAGES - 1 < QM_NKB) issue(kb + QM_STAGES - 1);
+    // Software pipeline over the K-blocks.  A K-block is two K-steps (64 elements each) of eight MFMAs; the fragments of K-step ks of
+    // K-block kb + 1 are read from LDS right after the MFMAs that consumed the registers they go to (K-step ks of K-block kb), so
+    // every fragment read has eight MFMAs to land behind; the "K-block kb + 1 has landed" barrier therefore sits in the MIDDLE of
+    // K-block kb.  The four LDS-DMA requests of K-block kb + 3 go between the MFMA groups, one per four MFMAs (issued in a bunch
+    // behind the barrier they cost the wave ~100 cycles each in which it issues no MFMA -- and its SIMD partner stands at the same
+    // point).  Ring bookkeeping: the requests of K-block kb + 3 overwrite the stage of K-block kb - 1, whose last fragment read
+    // lies before the barrier of K-block kb - 1.
+    qm_v8i fa[2][4], fb[2][2];
+    auto read_frags = [&](int kb, int ks) {
         const uint8_t *stg = qm_lds + (size_t)(kb % QM_STAGES) * QM_STAGE_BYTES;
+        const int ps = ((2 * ks + h) ^ swz) * 16;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ps = ((2 * ks + h) ^ swz) * 16;
-            qm_v8i fa[4], fb[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(stg + offA + i * 32 * QM_ROWB + ps);
-                fa[i] = qm_v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(stg + offB + j * 32 * QM_ROWB + ps);
-                fb[j] = qm_v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[j], acc[i][j], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(stg + offA + i * 32 * QM_ROWB + ps);
+            fa[ks][i] = qm_v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(stg + offB + j * 32 * QM_ROWB + ps);
+            fb[ks][j] = qm_v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+        }
+    };
+    auto mfma_group = [&](int g) {          // g = 2 ks + half: four MFMAs
+        const int ks = g >> 1;
+#pragma unroll
+        for (int i = 2 * (g & 1); i < 2 * (g & 1) + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[ks][i], fb[ks][j], acc[i][j], 4, 4, 0, 0, 0, 0);
+    };
+    auto dma_piece = [&](int kb3, int g) {
+        __builtin_amdgcn_sched_barrier(0);
+        qm_glds16(gsrc[g] + (size_t)kb3 * kb_stride, (uint32_t)__builtin_amdgcn_readfirstlane((int)(ldst[g] + (uint32_t)(kb3 % QM_STAGES) * QM_STAGE_BYTES)));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue: K-block 0 has landed for everybody, its fragments are requested
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0);
+    read_frags(0, 1);
+    // The two waves of a SIMD (w and w + 4) run this loop in lockstep; a wave that is issuing an LDS-DMA request issues no MFMA, so the
+    // second half of the workgroup places its requests BEFORE the MFMA groups, the first half behind them: one partner requests while
+    // the other feeds the matrix pipe.
+    if (wave < 4) {
+        for (int kb = 0; kb < QM_NKB - (QM_STAGES - 1); ++kb) {
+            mfma_group(0); dma_piece(kb + 3, 0);
+            mfma_group(1); dma_piece(kb + 3, 1);
+            // K-block kb + 1 has landed: outstanding are its four requests, the four of kb + 2 and the two of kb + 3 issued above
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_frags(kb + 1, 0);
+            mfma_group(2); dma_piece(kb + 3, 2);
+            mfma_group(3); dma_piece(kb + 3, 3);
+            read_frags(kb + 1, 1);
+        }
+    } else {
+        for (int kb = 0; kb < QM_NKB - (QM_STAGES - 1); ++kb) {
+            dma_piece(kb + 3, 0); mfma_group(0);
+            dma_piece(kb + 3, 1); mfma_group(1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_frags(kb + 1, 0);
+            dma_piece(kb + 3, 2); mfma_group(2);
+            dma_piece(kb + 3, 3); mfma_group(3);
+            read_frags(kb + 1, 1);
+        }
+    }
+    // tail: K-blocks NKB - 3, NKB - 2, NKB - 1 (nothing left to request)
+#pragma unroll
+    for (int t = 3; t >= 1; --t) {
+        const int kb = QM_NKB - t;
+        mfma_group(0);
+        mfma_group(1);
+        if (t > 1) {
+            if (t == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_frags(kb + 1, 0);
+        }
+        mfma_group(2);
+        mfma_group(3);
+        if (t > 1) read_frags(kb + 1, 1);
     }
     __syncthreads();          // every wave is done with the ring: it becomes the byte tile out[q][p]
 

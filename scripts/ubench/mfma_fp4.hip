@@ -26,6 +26,18 @@ __global__ void k_once(const uint4 *a, const uint4 *b, float *c)
     for (int r = 0; r < 16; ++r) c[r * 64 + lane] = acc[r];
 }
 
+// the same with scale operands 0: hipcc then emits the NON-scaled v_mfma_f32_32x32x64_f8f6f4 (no v_mfma_ld_scale half)
+__global__ void k_once_ns(const uint4 *a, const uint4 *b, float *c)
+{
+    const int lane = threadIdx.x;
+    const uint4 x = a[lane], y = b[lane];
+    v8i A = {(int)x.x, (int)x.y, (int)x.z, (int)x.w, 0, 0, 0, 0};
+    v8i B = {(int)y.x, (int)y.y, (int)y.z, (int)y.w, 0, 0, 0, 0};
+    v16f acc = {};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 4, 4, 0, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) c[r * 64 + lane] = acc[r];
+}
+
 __global__ void k_once_i8(const uint4 *a, const uint4 *b, int *c)
 {
     const int lane = threadIdx.x;
@@ -38,7 +50,7 @@ __global__ void k_once_i8(const uint4 *a, const uint4 *b, int *c)
 }
 
 // rate: NACC independent accumulators, back to back
-template <int NACC, bool FP4>
+template <int NACC, int FP4>
 __global__ __launch_bounds__(256) void k_rate(float *out, int iters)
 {
     v8i A = {(int)threadIdx.x, 0x22222222, 0x20202020, 0x02020202, 0, 0, 0, 0};
@@ -50,7 +62,8 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
-            if (FP4) acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[i], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            if (FP4 == 1) acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[i], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            else if (FP4 == 2) acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[i], 4, 4, 0, 0, 0, 0);
             else iacc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A4, B4, iacc[i], 0, 0, 0);
         }
     }
@@ -59,7 +72,7 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters)
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int NACC, bool FP4>
+template <int NACC, int FP4>
 void rate(const char *name, int blocks_per_cu)
 {
     const int blocks = 256 * blocks_per_cu, iters = 4000;
@@ -113,6 +126,19 @@ int main()
             if ((int)c[r * 64 + l] != ref) { if (bad < 5) printf("fp4 mismatch lane %d reg %d: got %g want %d\n", l, r, c[r * 64 + l], ref); ++bad; }
         }
     printf("fp4 32x32x64 layout check: %s (%d mismatches of 1024)\n", bad ? "FAILED" : "ok", bad);
+    {
+        k_once_ns<<<1, 64>>>(da, db, dc);
+        hipMemcpy(c.data(), dc, 16 * 64 * 4, hipMemcpyDeviceToHost);
+        int badn = 0;
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 16; ++r) {
+                const int col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                int ref = 0;
+                for (int k = 0; k < 64; ++k) ref += Abit[row * 64 + k] & Bbit[col * 64 + k];
+                if ((int)c[r * 64 + l] != ref) { if (badn < 3) printf("non-scaled mismatch lane %d reg %d: got %g want %d\n", l, r, c[r * 64 + l], ref); ++badn; }
+            }
+        printf("fp4 32x32x64 NON-scaled form (scale operands 0): %s (%d mismatches of 1024)\n", badn ? "DIFFERENT" : "ok, same products", badn);
+    }
     // i8 32x32x32: lane l holds k = 16 (l >> 5) .. + 15 of row l & 31
     {
         std::vector<int8_t> ai(64 * 16), bi(64 * 16);
@@ -137,10 +163,13 @@ int main()
         printf("i8 32x32x32 layout check: %s (%d mismatches of 1024)\n", badi ? "FAILED" : "ok", badi);
     }
     // ---- issue rate
-    rate<1, true>("fp4 32x32x64", 1);
-    rate<4, true>("fp4 32x32x64", 1);
-    rate<4, true>("fp4 32x32x64", 2);
-    rate<4, false>("i8 32x32x32", 1);
-    rate<4, false>("i8 32x32x32", 2);
+    rate<1, 1>("fp4 32x32x64", 1);
+    rate<4, 1>("fp4 32x32x64", 1);
+    rate<4, 1>("fp4 32x32x64", 2);
+    rate<4, 2>("fp4 32x32x64 non-scaled", 1);
+    rate<4, 2>("fp4 32x32x64 non-scaled", 2);
+    rate<8, 2>("fp4 32x32x64 non-scaled", 2);
+    rate<4, 0>("i8 32x32x32", 1);
+    rate<4, 0>("i8 32x32x32", 2);
     return bad != 0;
 }
