@@ -40,15 +40,22 @@ struct NNBoundRows {
     const uint32_t *score;
 };
 
-// what the scan needs to know about a partner, in one 16-byte load: length, current threshold min(best, length), hub score, roles
-__global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, const uint32_t *__restrict__ score, uint4 *__restrict__ meta)
+// what the scan needs to know about a partner, in ONE dword (the scan reads one per window pair and side: 7 10^8 at C3, L2 traffic):
+// length (14 bits: the table kernel's limit is below), threshold min(best, length, 64) (7 bits: anything above 63 acts as 63),
+// roles (2 bits: target, query), hub score >> 5 capped at 511 (9 bits: only orders the two ends of a pair, the same on both sides)
+__device__ __forceinline__ uint32_t nn_meta_len(uint32_t w) { return w & 0x3fffu; }
+__device__ __forceinline__ int32_t nn_meta_thr(uint32_t w) { return (int32_t)((w >> 14) & 0x7fu); }
+__device__ __forceinline__ uint32_t nn_meta_score(uint32_t w) { return w >> 23; }
+
+__global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, const uint32_t *__restrict__ score, uint32_t *__restrict__ meta)
 {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     if (x >= S.n) return;
     const int32_t m = S.lens[x], b = load_relaxed_agent(P.best + x);
-    uint4 v;
-    v.x = (uint32_t)m; v.y = (uint32_t)(b < m ? b : m); v.z = score[x]; v.w = (P.tflag[x] != 0 ? 1u : 0u) | (P.qflag[x] != 0 ? 2u : 0u);
-    meta[x] = v;
+    int32_t thr = b < m ? b : m;
+    thr = thr < 64 ? thr : 64;
+    const uint32_t sc = score[x] >> 5;
+    meta[x] = ((uint32_t)m & 0x3fffu) | ((uint32_t)thr << 14) | ((P.tflag[x] != 0 ? 1u : 0u) << 21) | ((P.qflag[x] != 0 ? 1u : 0u) << 22) | ((sc < 511u ? sc : 511u) << 23);
 }
 
 // One wave per entry x.  Its pairs are the columns of its own row (partners above x; only if x is one of the launch slots) and the
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, c
 // surviving pair is kept by exactly one of its two ends.  Kept pairs are staged in LDS; NN_LIST_CHUNK staged pairs become a chunk
 // of `list` (one k_nn_scan_refill workgroup with x's table), what is left at the end becomes a last chunk if it has NN_LIST_MIN
 // pairs, else flat pairs for the one-pair-per-lane kernel.
-__global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint4 *__restrict__ meta, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
+__global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint32_t *__restrict__ meta, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
                                                        uint32_t *__restrict__ list, unsigned long long list_cap, NNChunk *__restrict__ chunks, unsigned long long chunks_cap,
                                                        uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min)
 {
@@ -67,8 +74,8 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
     const int wave = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * 4u + (uint32_t)wave;
     const int lane = threadIdx.x & 63;
-    const uint4 mx = x < S.n ? meta[x] : make_uint4(0, 0, 0, 0);
-    const bool x_isq = (mx.w & 2u) != 0, x_ist = (mx.w & 1u) != 0;
+    const uint32_t mx = x < S.n ? meta[x] : 0u;
+    const bool x_isq = (mx & (1u << 22)) != 0, x_ist = (mx & (1u << 21)) != 0;
     // x's own row, if it is a launch slot, and its transposed row
     uint32_t up_len = 0, dn_len = 0, dn_slo = 0;
     unsigned long long up_off = 0, dn_off = 0;
@@ -80,9 +87,9 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
         }
         dn_len = B.lenT[x]; dn_slo = B.sloT[x]; dn_off = B.offT[x];
     }
-    const int32_t m = (int32_t)mx.x;
-    const int32_t kx0 = (int32_t)mx.y;
-    const uint32_t sx = mx.z;
+    const int32_t m = (int32_t)nn_meta_len(mx);
+    const int32_t kx0 = nn_meta_thr(mx);
+    const uint32_t sx = nn_meta_score(mx);
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
     uint32_t *st = stage[wave];
     uint32_t fill = 0, filtered = 0, kept = 0;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
         const uint8_t *row = side == 0 ? B.lb + up_off : B.lbT + dn_off;
         for (uint32_t c0 = 0; c0 < len; c0 += 64 * U) {
             uint32_t y[U], lbv[U];
-            uint4 my[U];
+            uint32_t my[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t e = c0 + 64u * u + (uint32_t)lane;
@@ -117,15 +124,15 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
                 if (c0 + 64u * u >= len) break;                        // wave-uniform
                 const uint32_t e = c0 + 64u * u + (uint32_t)lane;
                 const bool inr = e < len;
-                const bool xq = inr && x_isq && (my[u].w & 1u);        // x queries y
-                const bool yq = inr && x_ist && (my[u].w & 2u);        // y queries x
+                const bool xq = inr && x_isq && (my[u] & (1u << 21));        // x queries y
+                const bool yq = inr && x_ist && (my[u] & (1u << 22));        // y queries x
                 int32_t kx = -1, ky = -1;
                 if (xq) kx = kx0;
-                if (yq) ky = (int32_t)my[u].y;
+                if (yq) ky = nn_meta_thr(my[u]);
                 int32_t k = kx > ky ? kx : ky;
                 if (k > P.kcap) k = P.kcap;
-                const int32_t dl = m - (int32_t)my[u].x, ad = dl < 0 ? -dl : dl;
-                const uint32_t sy_u = my[u].z;
+                const int32_t dl = m - (int32_t)nn_meta_len(my[u]), ad = dl < 0 ? -dl : dl;
+                const uint32_t sy_u = nn_meta_score(my[u]);
                 const bool cand = inr && k >= 0 && ad <= k;
                 const bool accept = cand && (int32_t)lbv[u] <= k;
                 // owner: larger hub score, ties to the lower index (side 0: x is the lower end)

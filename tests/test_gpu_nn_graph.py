@@ -247,3 +247,37 @@ def test_sample_stage_and_one_workgroup_per_query_launches(monkeypatch):
         rp, c, e, _ = O.nn_1set(seqs, conv, i, 1, packed=packed)
         assert cols[row_ptr[i]:row_ptr[i + 1]].tolist() == c.tolist() and (e == best[i]).all(), i
     st.close()
+
+
+def test_device_finalize_matches_the_host_routine():
+    """The CSR of the graph built on the device (csrc/nn_finalize.hpp) against the host routine on the same hits: a set with many
+    equidistant neighbours per read (star-shaped families of single substitutions), and one with a row too long for the device sort."""
+    import os
+    import random
+    from isocon_amd.store import SeqStore
+    rng = random.Random(77)
+    for family, n_families in ((12, 400), (400, 6)):
+        seqs = set()
+        for f in range(n_families):
+            L = rng.randrange(300, 900)
+            root = "".join(rng.choice("ACGT") for _ in range(L))
+            seqs.add(root)
+            for _ in range(family):
+                i = rng.randrange(L)
+                seqs.add(root[:i] + rng.choice("ACGT".replace(root[i], "")) + root[i + 1:])
+        seqs = sorted(seqs, key=len)
+        assert len(seqs) >= 1024
+        st = SeqStore(seqs)
+        try:
+            dev = st.nn_graph()
+            os.environ["ISOCON_NN_HOST_FINALIZE"] = "1"
+            try:
+                host = st.nn_graph()
+            finally:
+                del os.environ["ISOCON_NN_HOST_FINALIZE"]
+            assert dev[3]["hits"] >= 4096
+            assert all((x == y).all() for x, y in zip(dev[:3], host[:3])), (family, n_families)
+            if family == 400:
+                assert (np.diff(dev[1]) > 256).any()          # (the fallback was taken: a root with hundreds of neighbours at distance 1)
+        finally:
+            st.close()
