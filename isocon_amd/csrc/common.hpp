@@ -53,6 +53,27 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
     return v;
 }
 
+// exclusive prefix sum of one value per thread over a workgroup of 1024 threads (16 waves); *total = the sum.  wave_sums: 16 words of LDS
+__device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long long s, unsigned long long *wave_sums, unsigned long long *total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long inc = s;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    unsigned long long off = inc - s, tot = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < wave) off += wave_sums[w];
+        tot += wave_sums[w];
+    }
+    *total = tot;
+    return off;
+}
+
 __device__ __forceinline__ int32_t uniform_i32(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ int32_t load_relaxed_agent(const int32_t *p)

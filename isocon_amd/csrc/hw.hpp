@@ -39,15 +39,19 @@ struct HwTileIn {
     const uint32_t *pt;          // target of every pair
     const int32_t *pk;           // threshold of every pair
     uint32_t n_tiles;
+    const uint32_t *tile_list;   // the launch's tiles (indices into tile_q / lane_pair), or nullptr: tiles 0 .. n_tiles - 1
+    uint32_t *flags;             // or nullptr: bit HW_FLAG_STATUS is set when a pair ends with an internal status (< -1)
 };
+static constexpr uint32_t HW_FLAG_STATUS = 16u;
 
 // out_he[2 p] = distance (-1: above k, -3: the tile's band does not fit W words), out_he[2 p + 1] = end
 template <int W>
 __global__ __launch_bounds__(256) void k_hw_locate(DevStore S, HwTileIn in, int32_t *__restrict__ out_he)
 {
-    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (tile >= in.n_tiles) return;
+    if (slot >= in.n_tiles) return;
+    const uint32_t tile = in.tile_list ? (uint32_t)uniform_i32((int32_t)in.tile_list[slot]) : slot;
     const uint32_t q = (uint32_t)uniform_i32((int32_t)in.tile_q[tile]);
     const int32_t P = uniform_i32(S.lens[q]);
     const uint32_t pair = in.lane_pair[(size_t)tile * 64 + lane];
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(256) void k_hw_locate(DevStore S, HwTileIn in, int3
         }
     }
     if (has) { out_he[(size_t)pair * 2] = r_h; out_he[(size_t)pair * 2 + 1] = r_end; }
+    if (in.flags && __ballot(has && r_h < -1) != 0 && lane == 0) atomicOr(in.flags, HW_FLAG_STATUS);
 }
 
 // Hits only: he[2 p] = h, he[2 p + 1] = end.  out[5 p ..] = h, start, end, leading insertion run, trailing insertion run
@@ -103,7 +108,8 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
     const uint32_t *pw = reinterpret_cast<const uint32_t *>(planes);
     const uint32_t nseq = S.n;
     const int32_t nchunks = (int32_t)S.nchunks;
-    for (uint32_t tile = blockIdx.x; tile < in.n_tiles; tile += gridDim.x) {
+    for (uint32_t slot = blockIdx.x; slot < in.n_tiles; slot += gridDim.x) {
+        const uint32_t tile = in.tile_list ? (uint32_t)uniform_i32((int32_t)in.tile_list[slot]) : slot;
         const uint32_t q = (uint32_t)uniform_i32((int32_t)in.tile_q[tile]);
         const int32_t P = uniform_i32(S.lens[q]);
         const uint32_t pair = in.lane_pair[(size_t)tile * 64 + lane];
@@ -231,6 +237,7 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
             const bool fine = r0 >= 0;
             o[0] = r0; o[1] = fine ? r_start : -1; o[2] = fine ? end : -1; o[3] = fine ? r_lead : 0; o[4] = fine ? r_trail : 0;
         }
+        if (in.flags && __ballot(has && r0 < -1) != 0 && lane == 0) atomicOr(in.flags, HW_FLAG_STATUS);
     }
 }
 

@@ -34,20 +34,8 @@ __global__ __launch_bounds__(1024) void k_fin_scan(const uint32_t *__restrict__ 
     const uint32_t r0 = t * R < n ? t * R : n, r1 = (t + 1) * R < n ? (t + 1) * R : n;
     unsigned long long s = 0;
     for (uint32_t i = r0; i < r1; ++i) s += cnt[i];
-    // exclusive scan of the 1024 partial sums: inside each wave by shuffles, then over the 16 wave totals
-    const uint32_t lane = t & 63u, wave = t >> 6;
-    unsigned long long inc = s;
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const unsigned long long o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) wave_sums[wave] = inc;
-    __syncthreads();
-    unsigned long long off = inc - s, total = 0;
-    for (uint32_t w = 0; w < 16; ++w) {
-        if (w < wave) off += wave_sums[w];
-        total += wave_sums[w];
-    }
+    unsigned long long total;
+    unsigned long long off = block_exscan_1024(s, wave_sums, &total);
     for (uint32_t i = r0; i < r1; ++i) { start[i] = off; off += cnt[i]; }
     if (t == 0) start[n] = total;
 }

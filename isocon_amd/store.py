@@ -136,7 +136,7 @@ class SeqStore(object):
         kk = np.ascontiguousarray(np.broadcast_to(np.asarray(k, dtype=np.int32), q.shape))
         if len(q) != len(t):
             raise ValueError("pair arrays differ in length")
-        out = np.full((len(q), 5), -1, dtype=np.int32)
+        out = np.empty((len(q), 5), dtype=np.int32)          # (every row is written by the call)
         ms = ctypes.c_float(0)
         _lib.check(self._L.isocon_hw_pairs(self._h, _ptr(q, _lib.u32p), _ptr(t, _lib.u32p), _ptr(kk, _lib.i32p), len(q),
                                            _ptr(out, _lib.i32p), ctypes.byref(ms)), "isocon_hw_pairs")

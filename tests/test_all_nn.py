@@ -169,3 +169,56 @@ def test_gpu_hw_pairs_limits():
     with pytest.raises(RuntimeError):
         st.hw_pairs([0], [1], [200])                # 350 + 400 + 1 diagonals > 512
     assert list(st.hw_pairs([1], [0], [5])[0]) == [-1, -1, -1, 0, 0]        # query longer than target + k
+
+
+@pytest.mark.gpu
+def test_gpu_hw_pairs_tiles_built_on_the_device(monkeypatch):
+    """Calls of >= 2048 pairs build their tiles on the device (csrc/hw_tiles.hpp): shuffled pair order, thresholds of every class in one
+    call, pairs that need no kernel; against the host-built tiles for every pair and against the oracle for a sample; the same error
+    behaviour; and the call that only the host's greedy cut can tile (one query, two targets whose common window exceeds 512 diagonals)."""
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    rng = random.Random(4242)
+    seqs = []
+    for fam in range(6):
+        b = "".join(rng.choice("ACGT") for _ in range(rng.randint(250, 700)))
+        for _ in range(40):
+            seqs.append(_mut(rng, b, rng.choice([0, 1, 3, 8, 20]), 20))
+    seqs.append("")                                                 # an empty sequence: no kernel, no hit
+    n = len(seqs)
+    q = np.array([rng.randrange(n) for _ in range(9000)], dtype=np.uint32)
+    t = np.array([(int(x) // 40 * 40 + rng.randrange(40)) % n if rng.random() < 0.9 else rng.randrange(n) for x in q], dtype=np.uint32)
+    k = np.array([rng.choice([0, 5, 25, 25, 25, 40, 70, 120]) for _ in q], dtype=np.int32)
+    lens = np.array([len(s) for s in seqs])
+    k = np.where(np.maximum(lens[t] - lens[q], 0) + 2 * k + 1 > 512, 25, k).astype(np.int32)      # (every pair supported on its own)
+    st = SeqStore(seqs)
+    try:
+        dev = st.hw_pairs(q, t, k)
+        monkeypatch.setenv("ISOCON_HW_HOST_TILES", "1")
+        host = st.hw_pairs(q, t, k)
+        monkeypatch.delenv("ISOCON_HW_HOST_TILES")
+        assert (dev == host).all()
+        assert (dev[:, 0] >= 0).sum() > 1000 and (dev[:, 0] < 0).sum() > 1000
+        for p in range(0, len(q), 45):
+            assert list(dev[p]) == hw_row(O, seqs[q[p]], seqs[t[p]], int(k[p])) if seqs[q[p]] and seqs[t[p]] else list(dev[p]) == [-1, -1, -1, 0, 0]
+        kbad = k.copy(); kbad[4000] = -1
+        with pytest.raises(RuntimeError):
+            st.hw_pairs(q, t, kbad)
+        qbad = q.copy(); qbad[17] = n
+        with pytest.raises(RuntimeError):
+            st.hw_pairs(qbad, t, k)
+    finally:
+        st.close()
+    # one query; targets that fit on their own (longer target with a small k; same length with a large k) but not in one window
+    base = "".join(rng.choice("ACGT") for _ in range(300))
+    seqs2 = [base, base + "".join(rng.choice("ACGT") for _ in range(380)), base[:140] + "T" + base[141:]]
+    st = SeqStore(seqs2)
+    try:
+        q2 = np.zeros(2048, dtype=np.uint32)
+        t2 = np.array([1, 2] * 1024, dtype=np.uint32)
+        k2 = np.array([20, 200] * 1024, dtype=np.int32)            # 380 + 41 and 0 + 401 diagonals; together 380 + 401
+        r = st.hw_pairs(q2, t2, k2)
+        assert list(r[0]) == hw_row(O, seqs2[0], seqs2[1], 20) and list(r[1]) == hw_row(O, seqs2[0], seqs2[2], 200)
+        assert (r[0::2] == r[0]).all() and (r[1::2] == r[1]).all()
+    finally:
+        st.close()
