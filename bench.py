@@ -407,6 +407,8 @@ def main():
         "rccl_ranks": dist.get_world_size() if dist is not None else 1,
         "dist_backend": dist.get_backend() if dist is not None else None,
         "per_rank_kernel_ms": per_rank_kernel_ms,
+        # what a step costs beyond the slowest rank's kernels: host work of the phases, the reductions and the gather, waiting for the others
+        "protocol_ms": ms_per_step - max(per_rank_kernel_ms),
     }
     if world == 1 and not args.no_extras:
         try:

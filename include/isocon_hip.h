@@ -163,6 +163,25 @@ int isocon_nn_finalize(uint32_t n, const int32_t *best, const int32_t *hits, uin
                        uint64_t *n_cols_needed);
 
 /*
+ * The same protocol with the exchanged data resident in device memory (what isocon_amd/dist.py uses on a GPU: RCCL reduces and
+ * gathers device buffers, nothing crosses PCIe between the exchange steps but a few status words).  All work is issued on the
+ * NULL stream of the current device; pointers named *_dev are device pointers owned by the caller.
+ *   isocon_nn_partial_dev  one phase like isocon_nn_partial; best_inout_dev[n] is read and updated in place; the phase's candidate
+ *                          edges are appended to a list the library keeps in device memory (keep_hits 0: the list starts empty --
+ *                          pass 0 for the first phase of a search); *n_hits_held = edges held after the call.
+ *   isocon_nn_hits_dev     writes the held edges that attain best_dev[] of their endpoint to out_hits_dev (int32 triples), the
+ *                          rest of the cap_rows rows as (-1, -1, -1): a fixed-size block for one all_gather.  cap_rows must be >=
+ *                          the number of edges held (ISOCON_E_CAPACITY otherwise).
+ *   isocon_nn_finalize_dev isocon_nn_finalize from device buffers (rows with a negative endpoint are skipped); n = size of the store.
+ */
+int isocon_nn_partial_dev(isocon_store *s, const uint8_t *is_converged, const uint8_t *is_target, uint64_t depth,
+                          uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t phase, int32_t *best_inout_dev,
+                          int32_t keep_hits, uint64_t *n_hits_held, isocon_nn_stats *stats);
+int isocon_nn_hits_dev(isocon_store *s, const int32_t *best_dev, int32_t *out_hits_dev, uint64_t cap_rows, uint64_t *n_kept);
+int isocon_nn_finalize_dev(isocon_store *s, const int32_t *best_dev, const int32_t *hits_dev, uint64_t n_rows,
+                           int32_t *out_best, uint64_t *out_row_ptr, uint32_t *out_cols, uint64_t cols_cap, uint64_t *n_cols_needed);
+
+/*
  * Batched semi-global affine alignment with traceback == parasail.sg_trace_scan_16/32(s1=a, s2=b, open, ext,
  * matrix_create("ACGT", match, mismatch)) + the CIGAR decode and column counting of parasail_alignment
  * (modules/SW_alignment_module.py:64-86).  mismatch is per pair (the reference picks it from the error-rate

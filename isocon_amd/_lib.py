@@ -65,6 +65,11 @@ SYMBOLS = {
                                          ctypes.POINTER(NNStats)]),
     "isocon_nn_finalize": (ctypes.c_int, [ctypes.c_uint32, i32p, i32p, ctypes.c_uint64, i32p, u64p, u32p,
                                           ctypes.c_uint64, u64p]),
+    "isocon_nn_partial_dev": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, u64p, ctypes.POINTER(NNStats)]),
+    "isocon_nn_hits_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, u64p]),
+    "isocon_nn_finalize_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, i32p, u64p, u32p,
+                                              ctypes.c_uint64, u64p]),
     "isocon_sg_trace_batch": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, ctypes.c_int32, i8p,
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, u32p, u64p, ctypes.c_uint64,
                                              u64p, i32p, f32p, i32p]),

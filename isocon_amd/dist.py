@@ -106,6 +106,85 @@ def _staging(store, name, n_int32, device):
     return t[:n_int32]
 
 
+def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap):
+    """The protocol of sharded_nn_graph with best[] and the candidate edges in device memory from the first phase to the CSR
+    (SeqStore.nn_partial_dev / nn_hits_dev / nn_finalize_dev): RCCL reduces and gathers the device buffers themselves, the host sees
+    1 + world status words per reduction and the final graph.  The library works on the null stream, which is torch's current
+    stream here, so its kernels and the collectives are ordered without host synchronisation."""
+    import time
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev):
+        raise RuntimeError("sharded_nn_graph: call it on the default stream (the library's kernels run there)")
+    n = store.n
+    tl = time.perf_counter()
+    cache = store.__dict__.setdefault("_dist_device", {})
+    t = cache.get("reduce")
+    if t is None or t.numel() != n + 1 + world:
+        t = cache["reduce"] = torch.empty(n + 1 + world, dtype=torch.int32, device=dev)
+        cache["tail_host"] = torch.empty(1 + world, dtype=torch.int32).pin_memory()
+    tail_host = cache["tail_host"]
+    t[:n].fill_(_lib.NN_INF)
+    # phase 2 runs only if a query longer than 63 is still without a neighbour after the reduction (the same on every rank)
+    far = np.asarray(store.lens)[:n] > 63
+    if is_converged is not None:
+        far &= np.asarray(is_converged)[:n] == 0
+    if is_target is not None:
+        far &= np.asarray(is_target)[:n] == 0
+    far_d = torch.from_numpy(far).to(dev)
+    tl = lap("setup", tl)
+    stats_all = []
+    held = 0
+    for phase in (0, 1, 2):
+        if phase == 2 and not bool(((t[:n] == _lib.NN_INF) & far_d).any().item()):
+            stats_all.append({k: 0 for k in stats_all[-1]} if stats_all else {})
+            continue
+        err = None
+        tl = time.perf_counter()
+        try:
+            held, stats = store.nn_partial_dev(rank, n, phase, t.data_ptr(), phase > 0, is_converged=is_converged, is_target=is_target,
+                                               depth=depth, q_stride=world)
+        except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
+            err, stats = e, {}
+        tl = lap("nn_partial_phase%d" % phase, tl)
+        stats_all.append(stats)
+        # best[n] | this rank's status | -(edges this rank holds) in its own slot: one all_reduce(MIN) of the device tensor
+        tail_host.zero_()
+        tail_host[0] = -1 if err is not None else 0
+        tail_host[1 + rank] = -held
+        t[n:].copy_(tail_host, non_blocking=True)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)           # THE exchange of thresholds
+        tail_host.copy_(t[n:])
+        if int(tail_host[0]) != 0:
+            raise RuntimeError("sharded_nn_graph: phase %d failed on %s" % (phase, "this rank: %r" % (err,) if err is not None else "another rank"))
+        counts = (-tail_host[1:]).numpy().copy()
+        tl = lap("reduce_min", tl)
+    tl = time.perf_counter()
+    # ONE all_gather of fixed-size blocks (the largest count of the last reduction; unused rows are -1), device to device
+    kmax = max(int(counts.max()) if len(counts) else 0, 1)
+    blk = cache.get("block")
+    if blk is None or blk.shape[0] < kmax:
+        blk = cache["block"] = torch.empty((int(kmax * 1.25) + 64, 3), dtype=torch.int32, device=dev)
+    blk = blk[:kmax]
+    store.nn_hits_dev(t.data_ptr(), blk.data_ptr(), kmax)
+    if world == 1:
+        gathered = blk
+    else:
+        gathered = cache.get("gathered")
+        if gathered is None or gathered.shape[0] < world * kmax:
+            gathered = cache["gathered"] = torch.empty((int(world * kmax * 1.25) + 64, 3), dtype=torch.int32, device=dev)
+        gathered = gathered[:world * kmax]
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(gathered, blk)
+        else:
+            dist.all_gather(list(gathered.view(world, kmax, 3).unbind(0)), blk)
+    tl = lap("gather_edges", tl)
+    out = store.nn_finalize_dev(t.data_ptr(), gathered.data_ptr(), gathered.shape[0])
+    lap("finalize", tl)
+    return out + (stats_all,)
+
+
 def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, dist=None, device=None, return_stats=False, laps=None):
     """Exact NN graph of `store` (length-sorted) computed by all ranks of the default process group.
 
@@ -137,6 +216,9 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         except AttributeError:
             pass
     tl = lap("fingerprint", tl)
+    if hasattr(store, "nn_partial_dev") and torch.cuda.is_available() and n > 0:
+        out = _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap)
+        return out if return_stats else out[:3]
     qb, qe, qs = rank, n, world          # cyclic ownership
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)

@@ -187,6 +187,41 @@ class SeqStore(object):
             _lib.check(rc, "isocon_nn_partial")
             return hits[:int(n_hits.value)], stats.as_dict()
 
+    # the same protocol with best[] and the candidate edges resident in device memory (isocon_amd/dist.py on a GPU)
+    def nn_partial_dev(self, q_begin, q_end, phase, best_dev_ptr, keep_hits, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1):
+        """One shard / one phase on best[] in device memory (an int: the device address of n int32).  The phase's candidate edges join
+        the list the library holds on the device (keep_hits False: a new list).  Returns (edges held, stats)."""
+        conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
+        targ = None if is_target is None else np.ascontiguousarray(is_target, dtype=np.uint8)
+        held = ctypes.c_uint64(0)
+        stats = _lib.NNStats()
+        _lib.check(self._L.isocon_nn_partial_dev(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), int(min(depth, 2 ** 63 - 1)), q_begin, q_end,
+                                                 q_stride, phase, ctypes.c_void_p(int(best_dev_ptr)), 1 if keep_hits else 0, ctypes.byref(held),
+                                                 ctypes.byref(stats)), "isocon_nn_partial_dev")
+        return int(held.value), stats.as_dict()
+
+    def nn_hits_dev(self, best_dev_ptr, out_dev_ptr, cap_rows):
+        """The held edges that attain best[] of their endpoint -> out (device, cap_rows x 3 int32; unused rows -1)."""
+        _lib.check(self._L.isocon_nn_hits_dev(self._h, ctypes.c_void_p(int(best_dev_ptr)), ctypes.c_void_p(int(out_dev_ptr)), int(cap_rows), None),
+                   "isocon_nn_hits_dev")
+
+    def nn_finalize_dev(self, best_dev_ptr, hits_dev_ptr, n_rows):
+        """(best, row_ptr, cols) from reduced best[] and gathered edges in device memory (isocon_nn_finalize_dev)."""
+        n = self.n
+        out_best = np.empty(max(n, 1), dtype=np.int32)
+        row_ptr = np.zeros(n + 1, dtype=np.uint64)
+        cap = max(4 * n, 1024)
+        needed = ctypes.c_uint64(0)
+        while True:
+            cols = np.empty(cap, dtype=np.uint32)
+            rc = self._L.isocon_nn_finalize_dev(self._h, ctypes.c_void_p(int(best_dev_ptr)), ctypes.c_void_p(int(hits_dev_ptr)), int(n_rows),
+                                                _ptr(out_best, _lib.i32p), _ptr(row_ptr, _lib.u64p), _ptr(cols, _lib.u32p), cap, ctypes.byref(needed))
+            if rc == _lib.ISOCON_E_CAPACITY:
+                cap = int(needed.value) + 16
+                continue
+            _lib.check(rc, "isocon_nn_finalize_dev")
+            return out_best[:n], row_ptr.astype(np.int64), cols[:int(row_ptr[n])]
+
     # ---- semi-global affine alignment with traceback ----------------------------------------------------------
     def sg_trace(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ms=False, ed_upper=None):
         """Returns (ops uint32[], ops_ptr int64[n+1], res int32[n,6]) -- see include/isocon_hip.h."""
