@@ -138,6 +138,36 @@ def pyhelp():
         return None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's, found through its RPATH under
+    the un-versioned file name): if this library came first and bound /opt/rocm's copy, a later `import torch` would bring a second
+    runtime into the process -- torch then sees no GPU, and device pointers could not be handed from one to the other
+    (isocon_amd/dist.py gives RCCL the buffers this library fills).  So torch's copy, when there is one, is loaded first and the
+    dynamic linker binds this library's libamdhip64.so.7 to it by SONAME.  ISOCON_HIP_RUNTIME=system keeps /opt/rocm's."""
+    if os.environ.get("ISOCON_HIP_RUNTIME", "") == "system":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return None
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if not os.path.exists(path):
+            return None
+        return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        return None
+
+
+def hip_runtimes_loaded():
+    """paths of the libamdhip64 copies mapped into this process (more than one: device pointers must not cross libraries)"""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
 def load():
     """Load the shared object and bind every symbol (no GPU needed for this)."""
     global _lib
@@ -145,6 +175,7 @@ def load():
         if not os.path.exists(SO_PATH):
             raise RuntimeError("libisocon_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                                "there is no CPU fallback" % SO_PATH)
+        _preload_torch_hip_runtime()
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -216,7 +216,7 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         except AttributeError:
             pass
     tl = lap("fingerprint", tl)
-    if hasattr(store, "nn_partial_dev") and torch.cuda.is_available() and n > 0:
+    if hasattr(store, "nn_partial_dev") and n > 0 and len(_lib.hip_runtimes_loaded()) == 1 and torch.cuda.is_available():
         out = _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap)
         return out if return_stats else out[:3]
     qb, qe, qs = rank, n, world          # cyclic ownership

@@ -281,3 +281,49 @@ def test_device_finalize_matches_the_host_routine():
                 assert (np.diff(dev[1]) > 256).any()          # (the fallback was taken: a root with hundreds of neighbours at distance 1)
         finally:
             st.close()
+
+
+def test_device_resident_phases_equal_the_single_call():
+    """isocon_nn_partial_dev / _hits_dev / _finalize_dev (what dist.sharded_nn_graph runs on a GPU).  Three ranks emulated on one device:
+    sweep 1 runs every phase on every rank and reduces the bounds with torch.minimum (the all_reduce); the library holds ONE edge list
+    per process, so sweep 2 replays each rank's phases from the same reduced bounds with its list kept, filters it against the final
+    bounds into a fixed-size block, and the blocks are concatenated like the all_gather."""
+    import torch
+    from isocon_amd import _lib, synth
+    from isocon_amd.store import SeqStore
+    accs, seqs, _ = synth.make_reads(2500, 700, 4, seed=91)
+    seqs = sorted(dict.fromkeys(seqs), key=len) + ["ACGT" * 40 + "TTTTGGGGCCCCAAAA" * 30]          # a read far from all others: phase 2
+    seqs = sorted(seqs, key=len)
+    conv = np.zeros(len(seqs), np.uint8); conv[::7] = 1
+    st = SeqStore(seqs)
+    try:
+        n, world = st.n, 3
+        want = st.nn_graph(is_converged=conv)
+        dev = torch.device("cuda", 0)
+        reduced = [torch.full((n,), _lib.NN_INF, dtype=torch.int32, device=dev)]          # bounds before phase 0, 1, 2 and the final ones
+        for phase in (0, 1, 2):
+            outs = []
+            for r in range(world):
+                b = reduced[-1].clone()
+                st.nn_partial_dev(r, n, phase, b.data_ptr(), False, is_converged=conv, q_stride=world)
+                outs.append(b)
+            reduced.append(torch.stack(outs).min(dim=0).values)
+        final = reduced[-1]
+        blocks = []
+        for r in range(world):
+            held = 0
+            for phase in (0, 1, 2):
+                b = reduced[phase].clone()
+                held, stats = st.nn_partial_dev(r, n, phase, b.data_ptr(), phase > 0, is_converged=conv, q_stride=world)
+            assert held > 0
+            with pytest.raises(RuntimeError):
+                st.nn_hits_dev(final.data_ptr(), torch.empty((held - 1, 3), dtype=torch.int32, device=dev).data_ptr(), held - 1)
+            blk = torch.empty((held + 5, 3), dtype=torch.int32, device=dev)
+            st.nn_hits_dev(final.data_ptr(), blk.data_ptr(), held + 5)
+            blocks.append(blk)
+        gathered = torch.cat(blocks)
+        assert int((gathered[:, 0] < 0).sum()) >= 5 * world          # the unused rows of the fixed-size blocks
+        got = st.nn_finalize_dev(final.data_ptr(), gathered.data_ptr(), gathered.shape[0])
+        assert all((x == y).all() for x, y in zip(got, want[:3]))
+    finally:
+        st.close()
