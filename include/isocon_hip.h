@@ -118,6 +118,7 @@ typedef struct {
     uint32_t reserved_;
     uint64_t pairs_lanes;         /* pairs of the main pass aligned one pair per lane (the rest went through tables) */
     uint64_t bound_tiles;         /* 256 x 256 tiles of the bound matrix computed (each: 65 536 pairs x isocon_qgram_params() multiply-adds) */
+    uint64_t pairs_wide_to_lanes; /* of pairs_lanes: pairs with a threshold above 31 while the table kernel ran its 32-row form */
 } isocon_nn_stats;
 
 /*

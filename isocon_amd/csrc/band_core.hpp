@@ -185,6 +185,123 @@ ISO_HD void band_step_eq(BandLane<W> &L, const uint64_t (&EQ)[W])
     L.VN[W - 1] = d0s & hpp;
 }
 
+// The 32-row band: thresholds up to 31 need no more (a path of cost <= k stays inside k + 1 diagonals, lane_emin), and on 32-bit
+// vectors a column is 10 instructions instead of 19.  zreg collects bit 0 of D0 column by column (shifted in at the top: after c
+// columns the c bits sit in the highest c positions of a register that started as 0); the caller adds its popcount to the top-row
+// counter once per block of 32 columns instead of an and + add per column.
+ISO_HD uint32_t or_nor32(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xF1);
+#else
+    return a | ~(b | c);
+#endif
+}
+
+ISO_HD void band_step_eq32(uint32_t &VP, uint32_t &VN, uint32_t &zreg, uint32_t eq)
+{
+    const uint32_t vp = VP, vn = VN;
+    const uint32_t s = (eq & vp) + vp;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t d0 = __builtin_amdgcn_bitop3_b32(s, vp, eq, 0xBE) | vn;          // ((s ^ vp) | eq) | vn
+    zreg = __builtin_amdgcn_alignbit(d0, zreg, 1);
+#else
+    const uint32_t d0 = (s ^ vp) | eq | vn;
+    zreg = (zreg >> 1) | (d0 << 31);
+#endif
+    const uint32_t hp = or_nor32(vn, d0, vp);
+    const uint32_t hn = d0 & vp;
+    const uint32_t d0s = d0 >> 1;
+    VP = or_nor32(hn, d0s, hp);
+    VN = d0s & hp;
+}
+
+// ... for a block in which a lane's text may end: real = all ones for a text column, 0 behind the end.  A column behind the end
+// acts as a "virtual" column (Eq = all ones => D0 = all ones): the band state below the window's last row and the value on the final
+// diagonal stay what they were at the text's last column (the top-row counter is bumped through zreg like the column count), so a
+// block is always 32 columns for every lane and the 32-column checks read the result afterwards.  One more instruction than
+// band_step_eq32 (the caller's bit extract); the two uses of Eq absorb `| ~real` in their 3-input boolean.
+ISO_HD void band_step_eq32_tail(uint32_t &VP, uint32_t &VN, uint32_t &zreg, uint32_t eq, uint32_t real)
+{
+    const uint32_t vp = VP, vn = VN;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t s = __builtin_amdgcn_bitop3_b32(eq, real, vp, 0xA2) + vp;         // ((eq | ~real) & vp) + vp
+    const uint32_t t = __builtin_amdgcn_bitop3_b32(s, vp, eq, 0xBE);                 // (s ^ vp) | eq
+    const uint32_t d0 = __builtin_amdgcn_bitop3_b32(t, vn, real, 0xFD);              // t | vn | ~real
+    zreg = __builtin_amdgcn_alignbit(d0, zreg, 1);
+#else
+    const uint32_t e2 = eq | ~real;
+    const uint32_t s = (e2 & vp) + vp;
+    const uint32_t d0 = (s ^ vp) | e2 | vn;
+    zreg = (zreg >> 1) | (d0 << 31);
+#endif
+    const uint32_t hp = or_nor32(vn, d0, vp);
+    const uint32_t hn = d0 & vp;
+    const uint32_t d0s = d0 >> 1;
+    VP = or_nor32(hn, d0s, hp);
+    VN = d0s & hp;
+}
+
+// The 64-row column step in the same two forms (top-row bits through zreg; `real` = all ones for a text column, 0 behind the end)
+ISO_HD void band_step_eq64z(uint64_t &VP, uint64_t &VN, uint32_t &zreg, uint64_t eq)
+{
+    const uint64_t vp = VP, vn = VN;
+    const uint64_t s = (eq & vp) + vp;
+    const uint64_t d0 = (s ^ vp) | eq | vn;
+#if defined(__HIP_DEVICE_COMPILE__)
+    zreg = __builtin_amdgcn_alignbit((uint32_t)d0, zreg, 1);
+#else
+    zreg = (zreg >> 1) | ((uint32_t)d0 << 31);
+#endif
+    const uint64_t hp = or_nor(vn, d0, vp);
+    const uint64_t hn = d0 & vp;
+    uint64_t d0s = d0 >> 1;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ISOCON_NO_SHIFT_PIN)
+    asm("" : "+v"(d0s));
+#endif
+    VP = or_nor(hn, d0s, hp);
+    VN = d0s & hp;
+}
+
+ISO_HD void band_step_eq64z_tail(uint64_t &VP, uint64_t &VN, uint32_t &zreg, uint64_t eq, uint32_t real)
+{
+    const uint64_t vp = VP, vn = VN;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t xl = __builtin_amdgcn_bitop3_b32((uint32_t)eq, real, (uint32_t)vp, 0xA2);
+    const uint32_t xh = __builtin_amdgcn_bitop3_b32((uint32_t)(eq >> 32), real, (uint32_t)(vp >> 32), 0xA2);
+    const uint64_t s = (((uint64_t)xh << 32) | xl) + vp;
+    const uint32_t tl = __builtin_amdgcn_bitop3_b32((uint32_t)s, (uint32_t)vp, (uint32_t)eq, 0xBE);
+    const uint32_t th = __builtin_amdgcn_bitop3_b32((uint32_t)(s >> 32), (uint32_t)(vp >> 32), (uint32_t)(eq >> 32), 0xBE);
+    const uint32_t dl = __builtin_amdgcn_bitop3_b32(tl, (uint32_t)vn, real, 0xFD);
+    const uint32_t dh = __builtin_amdgcn_bitop3_b32(th, (uint32_t)(vn >> 32), real, 0xFD);
+    const uint64_t d0 = ((uint64_t)dh << 32) | dl;
+    zreg = __builtin_amdgcn_alignbit(dl, zreg, 1);
+#else
+    const uint64_t r64 = ((uint64_t)real << 32) | real;
+    const uint64_t e2 = eq | ~r64;
+    const uint64_t s = (e2 & vp) + vp;
+    const uint64_t d0 = (s ^ vp) | e2 | vn;
+    zreg = (zreg >> 1) | ((uint32_t)d0 << 31);
+#endif
+    const uint64_t hp = or_nor(vn, d0, vp);
+    const uint64_t hn = d0 & vp;
+    uint64_t d0s = d0 >> 1;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ISOCON_NO_SHIFT_PIN)
+    asm("" : "+v"(d0s));
+#endif
+    VP = or_nor(hn, d0s, hp);
+    VN = d0s & hp;
+}
+
+ISO_HD int popc32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(x);
+#else
+    return __builtin_popcount(x);
+#endif
+}
+
 // The same column step that also hands out the horizontal "+1" vector HP of the column (bit r <-> window row r of THIS
 // column, i.e. before the slide) -- what a traceback needs next to the new VP (hw_core.hpp).
 template <int W>

@@ -272,12 +272,15 @@ __device__ __forceinline__ int32_t diag_value_w(const BandLane<W> &L, int32_t nv
     return v;
 }
 
-template <int NWAVES, int W>
+// HALF (with W = 1): the 32-row band on 32-bit vectors for launches whose pairs all have thresholds <= 31 (the listed launch in its
+// narrow mode, nn_list.hpp): one table dword and 12 instead of 22 vector instructions per column.
+template <int NWAVES, int W, bool HALF = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNParams P, const uint32_t *__restrict__ text, uint32_t text_stride,
                                                                       uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t tile_begin)
 {
     static_assert(W >= 1 && W <= 8, "band widths: 64 .. 512 rows");
-    constexpr int ROWS = 64 * W;
+    static_assert(!HALF || W == 1, "the 32-row band is the narrow form of the 64-row kernel");
+    constexpr int ROWS = HALF ? 32 : 64 * W;
     constexpr int UNROLL_COLS = W >= 5 ? 1 : 8;      // 5 words and more: a real loop (VGPRs, instruction cache)
     extern __shared__ uint32_t tw[];
     __shared__ uint32_t s_next;
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     if (!q_isq && !q_ist) return;
     const bool bounded = P.lb != nullptr && !sparse && !listed;
     const unsigned long long lb_base = bounded ? P.lb_row[slot] : 0ull;
-    const int32_t E = (m + 192 * W + 31) & ~31;          // plane length in dwords
+    const int32_t E = (m + 3 * ROWS + 31) & ~31;          // plane length in dwords
     {
         const uint64_t *planes = S.planes;
         const uint32_t nseq = S.n;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
             tw[2 * E + e] = ~lo & hi & v;
             tw[3 * E + e] = lo & hi & v;
         }
-        for (int32_t e = threadIdx.x; e < 128 * W + 32; e += NWAVES * 64) tw[4 * E + e] = 0xffffffffu;
+        for (int32_t e = threadIdx.x; e < 2 * ROWS + 32; e += NWAVES * 64) tw[4 * E + e] = 0xffffffffu;
         if (threadIdx.x == 0) s_next = 0;
     }
     __syncthreads();
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
 #pragma unroll
     for (int i = 0; i < W; ++i) { L.VP[i] = ~(uint64_t)0; L.VN[i] = 0; }
     L.ztop = 0;
+    uint32_t hvp = ~0u, hvn = 0u;          // HALF: the band state
     uint32_t qhead = 0, qcount = 0;
     bool exhausted = false;
     uint32_t n_pairs = 0, n_batches = 0, n_blocks = 0, n_live = 0, n_filtered = 0;
@@ -459,12 +463,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                 k_eff = (int32_t)((e1w >> 14) & 511u);
                 nv = (int32_t)(e1w >> 23);
                 bstar = m - n_t + nv;                        // in [0, ROWS - 1]
+                if (HALF) {
+                    hvp = nv <= 0 ? ~0u : (nv >= 32 ? 0u : (~0u << nv));
+                    hvn = ~hvp;
+                } else {
 #pragma unroll
-                for (int i = 0; i < W; ++i) {
-                    const int32_t lo = nv - 64 * i;
-                    const uint64_t vp = lo <= 0 ? ~(uint64_t)0 : (lo >= 64 ? 0 : (~(uint64_t)0 << lo));
-                    L.VP[i] = vp;
-                    L.VN[i] = ~vp;
+                    for (int i = 0; i < W; ++i) {
+                        const int32_t lo = nv - 64 * i;
+                        const uint64_t vp = lo <= 0 ? ~(uint64_t)0 : (lo >= 64 ? 0 : (~(uint64_t)0 << lo));
+                        L.VP[i] = vp;
+                        L.VN[i] = ~vp;
+                    }
                 }
                 const uint32_t e0 = (uint32_t)(ROWS - 1 - nv);
                 const uint32_t phi = (e0 - (uint32_t)lane) & 31u;
@@ -488,17 +497,49 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
         uint32_t w0 = __builtin_amdgcn_alignbit(cur[1], cur[0], nsh), w1 = __builtin_amdgcn_alignbit(cur[2], cur[1], nsh),
                  w2 = __builtin_amdgcn_alignbit(cur[3], cur[2], nsh), w3 = __builtin_amdgcn_alignbit(cur[4], cur[3], nsh);
         if (run && col + 32 < n_t) load5(tp + 4, cur);
-        if (W == 1 && __ballot(run && col + 32 > n_t) == 0) {
-            // 64-row band: all 32 columns unrolled, immediate table offsets
-            const uint32_t wq[4] = {w0, w1, w2, w3};
+        if (HALF) {
+            uint32_t zreg = 0;
+            if (__ballot(run && col + 32 > n_t) == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 32; ++jj) {
-                const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(wq[jj >> 3], 4 * (jj & 7), 3);
-                lds_u32 *pe = (lds_u32 *)(uintptr_t)(__umul24(code, plane_bytes) + blk);
-                uint64_t EQ[W];
-                EQ[0] = ((uint64_t)pe[jj + 32] << 32) | pe[jj];
-                band_step_eq<W>(L, EQ);
+                for (int jj = 0; jj < 32; ++jj) {
+                    const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(jj < 8 ? w0 : jj < 16 ? w1 : jj < 24 ? w2 : w3, 4 * (jj & 7), 3);
+                    lds_u32 *pe = (lds_u32 *)(uintptr_t)(__umul24(code, plane_bytes) + blk);
+                    band_step_eq32(hvp, hvn, zreg, pe[jj]);
+                }
+            } else {
+                // a lane's text ends inside this block: its columns behind the end run as virtual columns (band_core.hpp)
+                const int32_t rem = n_t - col;
+                const uint32_t act = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+#pragma unroll
+                for (int jj = 0; jj < 32; ++jj) {
+                    const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(jj < 8 ? w0 : jj < 16 ? w1 : jj < 24 ? w2 : w3, 4 * (jj & 7), 3);
+                    lds_u32 *pe = (lds_u32 *)(uintptr_t)(__umul24(code, plane_bytes) + blk);
+                    band_step_eq32_tail(hvp, hvn, zreg, pe[jj], (uint32_t)__builtin_amdgcn_sbfe(act, jj, 1));
+                }
             }
+            L.ztop += (uint32_t)__popc(zreg);
+        } else if (W == 1) {
+            // 64-row band: all 32 columns unrolled, immediate table offsets; a block in which some lane's text ends runs that lane's
+            // columns behind the end as virtual columns (band_core.hpp) -- every block is 32 columns for every lane, no per-column branch
+            uint32_t zreg = 0;
+            if (__ballot(run && col + 32 > n_t) == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 32; ++jj) {
+                    const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(jj < 8 ? w0 : jj < 16 ? w1 : jj < 24 ? w2 : w3, 4 * (jj & 7), 3);
+                    lds_u32 *pe = (lds_u32 *)(uintptr_t)(__umul24(code, plane_bytes) + blk);
+                    band_step_eq64z(L.VP[0], L.VN[0], zreg, ((uint64_t)pe[jj + 32] << 32) | pe[jj]);
+                }
+            } else {
+                const int32_t rem = n_t - col;
+                const uint32_t act = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+#pragma unroll
+                for (int jj = 0; jj < 32; ++jj) {
+                    const uint32_t code = (uint32_t)__builtin_amdgcn_ubfe(jj < 8 ? w0 : jj < 16 ? w1 : jj < 24 ? w2 : w3, 4 * (jj & 7), 3);
+                    lds_u32 *pe = (lds_u32 *)(uintptr_t)(__umul24(code, plane_bytes) + blk);
+                    band_step_eq64z_tail(L.VP[0], L.VN[0], zreg, ((uint64_t)pe[jj + 32] << 32) | pe[jj], (uint32_t)__builtin_amdgcn_sbfe(act, jj, 1));
+                }
+            }
+            L.ztop += (uint32_t)__popc(zreg);
         } else if (__ballot(run && col + 32 > n_t) == 0) {
             uint32_t a_blk = blk;
 #pragma unroll 1
@@ -537,7 +578,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
         n_live += (uint32_t)__popcll(runmask);
         col += 32;
         const bool fin = run && col >= n_t;
-        const int32_t dv = diag_value_w<W>(L, nv, fin ? n_t : col, bstar);
+        int32_t dv;
+        if (HALF) {
+            const uint32_t lm = bstar <= 0 ? 0u : (bstar >= 32 ? ~0u : ((1u << bstar) - 1u));
+            dv = nv + col - (int32_t)L.ztop + __popc(hvp & lm) - __popc(hvn & lm);          // (virtual columns behind the end count on both sides)
+        } else dv = diag_value_w<W>(L, nv, (W == 1 || !fin) ? col : n_t, bstar);
         int32_t r = -1;
         if (fin) { r = dv <= k_eff ? dv : -1; run = false; }
         else if (run && dv > k_eff) run = false;

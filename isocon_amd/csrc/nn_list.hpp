@@ -31,7 +31,18 @@ static constexpr int NN_STAGE = NN_LIST_CHUNK + 64;
 // counters of the list builder, each on a cache line of its own (they are hot: tens of thousands of atomics per launch)
 struct NNPlanTotals {
     unsigned long long n_pairs, pad0[15], n_list, pad1[15], n_small, pad2[15], n_chunks, pad3[15], n_filtered, pad4[15], overflow, pad5[15];
+    unsigned long long n_wide_entries, n_wide_pairs, narrow, pad6[13];          // written before / by the scan, see nn_narrow_mode
 };
+
+// The narrow mode of the listed launch: when few queries still have a threshold above NN_NARROW_K after the seeds (CCS-like data: the
+// nearest neighbour is a few edits away), the table kernel runs its 32-row form (nn.hpp, HALF) and the pairs whose threshold is
+// larger go to the one-pair-per-lane kernel, which takes any threshold up to 63.  Decided on the device from a count k_nn_entry_meta
+// takes (no extra round trip); the host reads the decision with the totals.
+static constexpr int32_t NN_NARROW_K = 31;
+__device__ __forceinline__ bool nn_narrow_mode(unsigned long long wide_entries, uint32_t n, int32_t force)
+{
+    return force > 0 || (force == 0 && wide_entries * 16ull <= (unsigned long long)n);
+}
 
 // the matrix rows of both orientations (qgram_mm.hpp) and the hub scores that decide which end owns a pair
 struct NNBoundRows {
@@ -47,15 +58,21 @@ __device__ __forceinline__ uint32_t nn_meta_len(uint32_t w) { return w & 0x3fffu
 __device__ __forceinline__ int32_t nn_meta_thr(uint32_t w) { return (int32_t)((w >> 14) & 0x7fu); }
 __device__ __forceinline__ uint32_t nn_meta_score(uint32_t w) { return w >> 23; }
 
-__global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, const uint32_t *__restrict__ score, uint32_t *__restrict__ meta)
+__global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, const uint32_t *__restrict__ score, uint32_t *__restrict__ meta, NNPlanTotals *__restrict__ totals)
 {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
-    if (x >= S.n) return;
-    const int32_t m = S.lens[x], b = load_relaxed_agent(P.best + x);
-    int32_t thr = b < m ? b : m;
-    thr = thr < 64 ? thr : 64;
-    const uint32_t sc = score[x] >> 5;
-    meta[x] = ((uint32_t)m & 0x3fffu) | ((uint32_t)thr << 14) | ((P.tflag[x] != 0 ? 1u : 0u) << 21) | ((P.qflag[x] != 0 ? 1u : 0u) << 22) | ((sc < 511u ? sc : 511u) << 23);
+    bool wide = false;
+    if (x < S.n) {
+        const int32_t m = S.lens[x], b = load_relaxed_agent(P.best + x);
+        int32_t thr = b < m ? b : m;
+        thr = thr < 64 ? thr : 64;
+        const uint32_t sc = score[x] >> 5;
+        const bool isq = P.qflag[x] != 0;
+        meta[x] = ((uint32_t)m & 0x3fffu) | ((uint32_t)thr << 14) | ((P.tflag[x] != 0 ? 1u : 0u) << 21) | ((isq ? 1u : 0u) << 22) | ((sc < 511u ? sc : 511u) << 23);
+        wide = isq && thr > NN_NARROW_K;
+    }
+    const uint64_t wm = __ballot(wide);
+    if (wm != 0 && (threadIdx.x & 63u) == 0) atomicAdd(&totals->n_wide_entries, (unsigned long long)__popcll(wm));
 }
 
 // One wave per entry x.  Its pairs are the columns of its own row (partners above x; only if x is one of the launch slots) and the
@@ -66,7 +83,8 @@ __global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, c
 // pairs, else flat pairs for the one-pair-per-lane kernel.
 __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint32_t *__restrict__ meta, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
                                                        uint32_t *__restrict__ list, unsigned long long list_cap, NNChunk *__restrict__ chunks, unsigned long long chunks_cap,
-                                                       uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min)
+                                                       uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min,
+                                                       int32_t force_narrow)
 {
     __shared__ uint32_t stage[4][NN_STAGE];
     __shared__ uint32_t s_small[4], s_filtered[4], s_kept[4];
@@ -93,6 +111,8 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
     uint32_t *st = stage[wave];
     uint32_t fill = 0, filtered = 0, kept = 0;
+    const bool narrow = nn_narrow_mode((unsigned long long)__builtin_amdgcn_readfirstlane((int)(uint32_t)totals->n_wide_entries), S.n, force_narrow);
+    if (blockIdx.x == 0 && threadIdx.x == 0) totals->narrow = narrow ? 1ull : 0ull;
     auto emit_chunk = [&]() {
         unsigned long long base = 0, ci = 0;
         if (lane == 0) { base = atomicAdd(&totals->n_list, (unsigned long long)fill); ci = atomicAdd(&totals->n_chunks, 1ull); }
@@ -138,9 +158,26 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
                 // owner: larger hub score, ties to the lower index (side 0: x is the lower end)
                 const bool mine = accept && (side == 0 ? sy_u <= sx : sx > sy_u);
                 if (side == 0) { filtered += (uint32_t)__popcll(__ballot(cand && !accept)); kept += (uint32_t)__popcll(__ballot(accept)); }
-                const uint64_t am = __ballot(mine);
+                // narrow mode: the (few) pairs with a larger threshold go straight to the pair arrays
+                const bool wide = mine && narrow && k > NN_NARROW_K;
+                const uint64_t wm = __ballot(wide);
+                if (wm != 0) {
+                    const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(wm));
+                    unsigned long long wbase = 0;
+                    if (lane == first) {
+                        wbase = atomicAdd(&totals->n_small, (unsigned long long)__popcll(wm));
+                        atomicAdd(&totals->n_wide_pairs, (unsigned long long)__popcll(wm));
+                        if (wbase + (unsigned long long)__popcll(wm) > small_cap) { atomicOr(&totals->overflow, 1ull); wbase = ~0ull; }
+                    }
+                    wbase = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(wbase >> 32), first) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wbase, first);
+                    if (wide && wbase != ~0ull) {
+                        const unsigned long long at = wbase + (unsigned long long)__popcll(wm & lt_mask);
+                        pa[at] = x; pb[at] = y[u];
+                    }
+                }
+                const uint64_t am = __ballot(mine && !wide);
                 if (am == 0) continue;                                   // wave-uniform
-                if (mine) st[fill + (uint32_t)__popcll(am & lt_mask)] = y[u] | (xq ? 0x40000000u : 0u) | (yq ? 0x80000000u : 0u);
+                if (mine && !wide) st[fill + (uint32_t)__popcll(am & lt_mask)] = y[u] | (xq ? 0x40000000u : 0u) | (yq ? 0x80000000u : 0u);
                 fill += (uint32_t)__popcll(am);
                 if (fill >= NN_LIST_CHUNK) emit_chunk();
             }

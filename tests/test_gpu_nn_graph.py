@@ -327,3 +327,32 @@ def test_device_resident_phases_equal_the_single_call():
         assert all((x == y).all() for x, y in zip(got, want[:3]))
     finally:
         st.close()
+
+
+def test_narrow_mode_on_reads_with_few_errors(monkeypatch):
+    """Reads whose nearest neighbour is a few edits away: the listed launch picks its 32-row form by itself (thresholds <= 31; the few
+    pairs above go one per lane).  Same graph as with the 64-row tables, and the rows of some reads against the reference loop."""
+    from isocon_amd import synth
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    accs, seqs, _ = synth.make_reads(6000, 1100, 4, seed=515, profile=dict(synth.CCS_PROFILE, rate=0.003))
+    seqs = sorted(dict.fromkeys(seqs), key=len)
+    st = SeqStore(seqs)
+    try:
+        got = st.nn_graph()
+        assert got[3]["pairs_lanes"] > 0 and got[3]["pairs_wide_to_lanes"] * 5 < got[3]["pairs_evaluated"]
+        monkeypatch.setenv("ISOCON_NN_NARROW", "0")
+        wide = st.nn_graph()
+        monkeypatch.delenv("ISOCON_NN_NARROW")
+        assert wide[3]["pairs_wide_to_lanes"] == 0
+        assert all((x == y).all() for x, y in zip(got[:3], wide[:3]))
+        assert np.median(got[0][got[0] >= 0]) <= 31
+        best, row_ptr, cols = got[:3]
+        packed = O.pack(seqs)
+        conv = np.zeros(st.n, np.uint8)
+        for i in list(range(0, st.n, 397)) + [st.n - 1]:
+            rp, c, e, _ = O.nn_1set(seqs, conv, i, 1, packed=packed)
+            assert list(cols[row_ptr[i]:row_ptr[i + 1]]) == list(c[rp[0]:rp[1]]), i
+            assert rp[1] == rp[0] or best[i] == e[rp[0]]
+    finally:
+        st.close()

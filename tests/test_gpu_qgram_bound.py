@@ -119,7 +119,8 @@ def test_graph_with_the_filter_is_the_graph_without_it_and_the_filter_is_used():
         # that do not fit (fallback to the kernel's own admission)
         for env in ({"ISOCON_NN_OLD_SEED": "1"}, {"ISOCON_NN_WAVES": "8"}, {"ISOCON_NN_ORDER": "0"}, {"ISOCON_NN_ORDER": "1"},
                     {"ISOCON_NN_NO_LIST": "1"}, {"ISOCON_NN_LIST_MIN": "1"}, {"ISOCON_NN_LIST_MIN": "1000000"}, {"ISOCON_NN_LIST_CAP": "1000"},
-                    {"ISOCON_NN_LIST_WAVES": "4"}, {"ISOCON_NN_HOST_FINALIZE": "1"}):
+                    {"ISOCON_NN_LIST_WAVES": "4"}, {"ISOCON_NN_HOST_FINALIZE": "1"}, {"ISOCON_NN_NARROW": "1"}, {"ISOCON_NN_NARROW": "0"},
+                    {"ISOCON_NN_NARROW": "1", "ISOCON_NN_LIST_WAVES": "4"}):
             os.environ.update(env)
             try:
                 b2, r2, c2, s2 = st.nn_graph(is_converged=conv)
