@@ -18,5 +18,5 @@ for combo in itertools.product(*[v for _, v in axes]) if axes else [()]:
         t0 = time.perf_counter(); best, rp, cols, stats = st.nn_graph(); ts.append((time.perf_counter() - t0) * 1e3)
     key = (best.tobytes(), rp.tobytes(), cols.tobytes())
     if ref is None: ref = key
-    print(" ".join("%s=%s" % (k, v) for (k, _), v in zip(axes, combo)), "| step %.2f ms (min of 3) | bounds %.2f seeds %.2f lists %.2f tables %.2f lanes %.2f | pairs %d (lanes %d, wide %d) filtered %d | same graph %s"
-          % (min(ts[1:]), stats["bound_kernel_ms"], stats["seed_kernel_ms"], stats["list_kernel_ms"], stats["scan_kernel_ms"], stats["lanes_kernel_ms"], stats["pairs_evaluated"], stats["pairs_lanes"], stats["pairs_wide_to_lanes"], stats["pairs_prefiltered"], key == ref), flush=True)
+    print(" ".join("%s=%s" % (k, v) for (k, _), v in zip(axes, combo)), "| step %.2f ms (min of 3) | bounds %.2f seeds %.2f lists %.2f tables %.2f lanes %.2f | pairs %d (lanes %d, wide %d) filtered %d | live %.3f wave-cols %.3e | same graph %s"
+          % (min(ts[1:]), stats["bound_kernel_ms"], stats["seed_kernel_ms"], stats["list_kernel_ms"], stats["scan_kernel_ms"], stats["lanes_kernel_ms"], stats["pairs_evaluated"], stats["pairs_lanes"], stats["pairs_wide_to_lanes"], stats["pairs_prefiltered"], stats["live_columns"] / max(1, stats["cells_columns"]), stats["cells_columns"] / 64.0, key == ref), flush=True)
