@@ -41,6 +41,20 @@ __global__ __launch_bounds__(256) void k_issue(uint32_t *out, int iters, long lo
             REP64(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
         } else if (KIND == 12) {  // v_bcnt_u32_b32
             REP64(asm volatile("v_bcnt_u32_b32 %0, %0, %4\n v_bcnt_u32_b32 %1, %1, %4\n v_bcnt_u32_b32 %2, %2, %4\n v_bcnt_u32_b32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+        } else if (KIND == 13) {  // v_mul_u32_u24 with a byte of its source selected (SDWA)
+            REP64(asm volatile("v_mul_u32_u24_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_mul_u32_u24_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n v_mul_u32_u24_sdwa %2, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n v_mul_u32_u24_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+        } else if (KIND == 14) {  // v_mul_u32_u24 (VOP2)
+            REP64(asm volatile("v_mul_u32_u24_e32 %0, %0, %4\n v_mul_u32_u24_e32 %1, %1, %4\n v_mul_u32_u24_e32 %2, %2, %4\n v_mul_u32_u24_e32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+        } else if (KIND == 15) {  // v_add_u32 with a byte of its source selected (SDWA)
+            REP64(asm volatile("v_add_u32_sdwa %0, %4, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_add_u32_sdwa %1, %4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n v_add_u32_sdwa %2, %4, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n v_add_u32_sdwa %3, %4, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+        } else if (KIND == 16) {  // v_or3_b32
+            REP64(asm volatile("v_or3_b32 %0, %0, %4, %5\n v_or3_b32 %1, %1, %4, %5\n v_or3_b32 %2, %2, %4, %5\n v_or3_b32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+        } else if (KIND == 17) {  // v_lshl_add_u32
+            REP64(asm volatile("v_lshl_add_u32 %0, %0, 2, %4\n v_lshl_add_u32 %1, %1, 2, %4\n v_lshl_add_u32 %2, %2, 2, %4\n v_lshl_add_u32 %3, %3, 2, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+        } else if (KIND == 18) {  // v_and_b32 with a 32-bit literal
+            REP64(asm volatile("v_and_b32 %0, 0x0f0f0f0f, %0\n v_and_b32 %1, 0x0f0f0f0f, %1\n v_and_b32 %2, 0x0f0f0f0f, %2\n v_and_b32 %3, 0x0f0f0f0f, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+        } else if (KIND == 19) {  // v_xor3? (v_xad / v_add3)
+            REP64(asm volatile("v_add3_u32 %0, %0, %4, %5\n v_add3_u32 %1, %1, %4, %5\n v_add3_u32 %2, %2, %4, %5\n v_add3_u32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
         }
     }
     const long long t1 = __builtin_readcyclecounter();
@@ -51,7 +65,7 @@ __global__ __launch_bounds__(256) void k_issue(uint32_t *out, int iters, long lo
 template <int KIND>
 void run(const char *name, int waves_per_simd)
 {
-    const int blocks = 256 * waves_per_simd, iters = 200;
+    const int blocks = 256 * waves_per_simd, iters = 1500;
     uint32_t *d; long long *dc;
     hipMalloc(&d, (size_t)blocks * 256 * 4); hipMalloc(&dc, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -71,7 +85,7 @@ void run(const char *name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 4, 6}) {
         run<0>("v_and_b32 x4 chains", w);
         run<6>("v_and_b32 one dependent chain", w);
         run<1>("v_bitop3_b32 x4 chains", w);
@@ -85,6 +99,13 @@ int main()
         run<10>("v_bfe_u32 x4", w);
         run<11>("v_add_u32 x4", w);
         run<12>("v_bcnt_u32_b32 x4", w);
+        run<13>("v_mul_u32_u24_sdwa (byte) x4", w);
+        run<14>("v_mul_u32_u24_e32 x4", w);
+        run<15>("v_add_u32_sdwa (byte) x4", w);
+        run<16>("v_or3_b32 x4", w);
+        run<17>("v_lshl_add_u32 x4", w);
+        run<18>("v_and_b32 literal x4", w);
+        run<19>("v_add3_u32 x4", w);
     }
     return 0;
 }
