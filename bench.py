@@ -47,6 +47,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                       # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMD-32 x 2.4 GHz, one wave64 VALU instruction per 2 cycles (same guide)
+HALF_RATE_SHARE = 5.0 / 19.0      # of the table kernel's column (static, from its ISA)
+HALF_RATE_COST = 1.72             # issue cost of a half-rate vector instruction relative to a full-rate one (measured)
 MFMA_FP4_PEAK_MACS = 5.0e15                 # ~10 PFLOP/s dense FP4 (same guide, chip-level parameters) = 5e15 multiply-adds / s
 COUNTERS = os.path.join(ROOT, "profiles", "counters.json")   # written by scripts/summarize_profile.py from rocprofv3 --pmc passes
 
@@ -378,6 +380,12 @@ def main():
                 "kernel_ms": k_ms, "valu_insts_per_wave_column": ipc, "wave_columns_this_run": wave_cols, "valu_insts_this_run": insts,
                 "valu_insts_profiled_dispatch": cm.get("SQ_INSTS_VALU"), "wave_columns_profiled_dispatch": cm.get("wave_columns"),
                 "counters": ctr_note,
+                # Not every vector instruction issues in 2 cycles: measured on this part (scripts/ubench/valu_issue.hip, profiles/r03h_ubench_valu_issue.txt)
+                # v_and / v_add_u32 / v_lshrrev_b32 / v_bitop3_b32 issue at the full rate, every other instruction of the band step
+                # (v_bfe, v_mad_u32_u24, v_alignbit, v_lshl_add_u64, v_lshrrev_b64) at 1.72x that cost.  The unrolled column of the table kernel
+                # is 14 full-rate + 5 half-rate instructions (ISA of k_nn_scan_refill<8, 1>): frac above counts instructions, this one issue slots.
+                "issue_slots": {"half_rate_share_of_column": HALF_RATE_SHARE, "half_rate_cost": HALF_RATE_COST,
+                                "frac": (achieved / VALU_PEAK_WAVE_INSTR) * (1.0 + HALF_RATE_SHARE * (HALF_RATE_COST - 1.0)) if achieved else None},
                 "step_kernels_ms": {"bounds (profiles + k_qgram_mm)": pm["bound_kernel_ms"], "seeds (k_ed_lanes)": pm["seed_kernel_ms"],
                                     "survivor lists (k_nn_survivors)": pm["list_kernel_ms"], "tables (k_nn_scan_refill)": k_ms,
                                     "pair per lane (k_ed_lanes)": pm["lanes_kernel_ms"], "all kernels": pm["kernel_ms"]},

@@ -74,6 +74,77 @@ __device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long lo
     return off;
 }
 
+// Exclusive prefix sum of f(in[i]) over n elements in two launches of ceil(n / 2048) workgroups of 256 threads (8 consecutive elements
+// per thread): k_scan_tiles leaves every element's prefix inside its tile in tmp[] and the tile's sum in tile_sum[]; k_scan_finish adds
+// the sums of the tiles before and writes out[i], and out[n] = the total.  SHIFT: f(v) = (v + 2^SHIFT - 1) >> SHIFT (SHIFT 0: v itself).
+static constexpr uint32_t SCAN_TILE = 2048;
+
+template <int SHIFT>
+__global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ tmp, unsigned long long *__restrict__ tile_sum)
+{
+    __shared__ unsigned long long wave_sums[4];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8u;
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t x = base + j < n ? in[base + j] : 0u;
+        v[j] = SHIFT ? (x + (1u << SHIFT) - 1u) >> SHIFT : x;
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = s;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    uint32_t off = inc - s;
+    for (uint32_t w = 0; w < wave; ++w) off += (uint32_t)wave_sums[w];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (base + j < n) tmp[base + j] = off;
+        off += v[j];
+    }
+    if (threadIdx.x == 255) tile_sum[blockIdx.x] = (unsigned long long)off;
+}
+
+template <class OUT>
+__global__ __launch_bounds__(256) void k_scan_finish(const uint32_t *__restrict__ tmp, uint32_t n, const unsigned long long *__restrict__ tile_sum, uint32_t n_tiles,
+                                                      OUT *__restrict__ out, unsigned long long *__restrict__ total_out)
+{
+    __shared__ unsigned long long part[4];
+    unsigned long long s = 0, all = 0;
+    for (uint32_t b = threadIdx.x; b < n_tiles; b += 256u) {
+        const unsigned long long t = tile_sum[b];
+        if (b < blockIdx.x) s += t;
+        all += t;
+    }
+    // workgroup sums of s (tiles before this one) and, for the last workgroup, of all tiles
+    const bool last = blockIdx.x + 1 == gridDim.x;
+    unsigned long long r = last ? all : s, r2 = s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o, 64); r2 += __shfl_xor(r2, o, 64); }
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = r2;
+    __syncthreads();
+    const unsigned long long before = part[0] + part[1] + part[2] + part[3];
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = r;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (base + j < n) out[base + j] = (OUT)(before + tmp[base + j]);
+    if (last && threadIdx.x == 0) {
+        const unsigned long long tot = part[0] + part[1] + part[2] + part[3];
+        out[n] = (OUT)tot;
+        if (total_out) *total_out = tot;
+    }
+}
+
 __device__ __forceinline__ int32_t uniform_i32(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ int32_t load_relaxed_agent(const int32_t *p)

@@ -79,19 +79,8 @@ __global__ __launch_bounds__(256) void k_hwt_keys(DevStore S, const uint32_t *__
     (void)hwt_wave_add(hist, kk, base);
 }
 
-// tile_base[key] = tiles before the key's first (a key with c pairs has ceil(c / 64) tiles); one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_hwt_scan(const uint32_t *__restrict__ hist, uint32_t n_keys, uint32_t *__restrict__ tile_base, HwTileCounters *__restrict__ ctr)
-{
-    __shared__ unsigned long long wave_sums[16];
-    const uint32_t t = threadIdx.x, R = (n_keys + 1023u) / 1024u;
-    const uint32_t r0 = t * R < n_keys ? t * R : n_keys, r1 = (t + 1) * R < n_keys ? (t + 1) * R : n_keys;
-    unsigned long long s = 0;
-    for (uint32_t i = r0; i < r1; ++i) s += (hist[i] + 63u) >> 6;
-    unsigned long long total;
-    unsigned long long off = block_exscan_1024(s, wave_sums, &total);
-    for (uint32_t i = r0; i < r1; ++i) { tile_base[i] = (uint32_t)off; off += (hist[i] + 63u) >> 6; }
-    if (t == 0) ctr->n_tiles = (uint32_t)total;
-}
+// tile_base[key] = tiles before the key's first (a key with c pairs has ceil(c / 64) tiles), tile_base[n_keys] = tiles in all: the host's
+// device_exscan<6> over the histogram.
 
 // lane_pair (pre-set to "empty") and tile_q
 __global__ __launch_bounds__(256) void k_hwt_scatter(const uint32_t *__restrict__ key, unsigned long long n_pairs, const uint32_t *__restrict__ tile_base,
@@ -111,10 +100,10 @@ __global__ __launch_bounds__(256) void k_hwt_scatter(const uint32_t *__restrict_
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_hwt_classes(DevStore S, const uint32_t *__restrict__ tile_q, const uint32_t *__restrict__ lane_pair,
                                                       const uint32_t *__restrict__ t, const int32_t *__restrict__ k, uint32_t max_tiles,
-                                                      uint32_t *__restrict__ cls_tiles, HwTileCounters *__restrict__ ctr)
+                                                      const uint32_t *__restrict__ n_tiles, uint32_t *__restrict__ cls_tiles, HwTileCounters *__restrict__ ctr)
 {
     const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (tile >= ctr->n_tiles) return;
+    if (tile >= *n_tiles) return;
     const uint32_t pair = lane_pair[(size_t)tile * 64 + lane];
     const bool has = pair != HWT_NONE;
     const int32_t P = S.lens[tile_q[tile]];

@@ -60,7 +60,7 @@ enum {
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES, SLOT_HW_PQ, SLOT_HW_KEY, SLOT_HW_HIST, SLOT_HW_CURSOR, SLOT_HW_TBASE, SLOT_HW_CLS,
-    SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD,
+    SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD, SLOT_SCAN_TMP, SLOT_SCAN_SUMS,
     SLOT_COUNT
 };
 static_assert(SLOT_COUNT <= 112, "ScratchPool::slots too small");
@@ -178,6 +178,20 @@ struct DevBuf {
         return ISOCON_OK;
     }
 };
+
+// out[0 .. n] = exclusive prefix sums of f(in[i]) (common.hpp: k_scan_tiles + k_scan_finish), on the null stream
+template <int SHIFT, class OUT>
+static int device_exscan(ScratchPool *pl, const uint32_t *d_in, uint32_t n, OUT *d_out)
+{
+    DevBuf d_tmp(pl, SLOT_SCAN_TMP), d_sums(pl, SLOT_SCAN_SUMS);
+    const uint32_t tiles = std::max<uint32_t>(1, (n + SCAN_TILE - 1) / SCAN_TILE);
+    int rc;
+    if ((rc = d_tmp.alloc((size_t)std::max<uint32_t>(n, 1) * 4)) || (rc = d_sums.alloc((size_t)tiles * 8))) return rc;
+    hipLaunchKernelGGL((k_scan_tiles<SHIFT>), dim3(tiles), dim3(256), 0, 0, d_in, n, d_tmp.as<uint32_t>(), d_sums.as<unsigned long long>());
+    hipLaunchKernelGGL((k_scan_finish<OUT>), dim3(tiles), dim3(256), 0, 0, d_tmp.as<uint32_t>(), n, d_sums.as<unsigned long long>(), tiles, d_out, (unsigned long long *)nullptr);
+    ISO_HIP_CHECK(hipGetLastError());
+    return ISOCON_OK;
+}
 
 struct EventTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;

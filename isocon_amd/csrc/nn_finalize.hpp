@@ -26,20 +26,6 @@ __global__ __launch_bounds__(256) void k_fin_count(const int32_t *__restrict__ h
     if (h < n_hits && nn_fin_valid(hits, h, best, n, e, o)) atomicAdd(cnt + e, 1u);
 }
 
-// start[i] = exclusive prefix sum of cnt (start[n] = total); one workgroup of 1024 threads, contiguous ranges per thread
-__global__ __launch_bounds__(1024) void k_fin_scan(const uint32_t *__restrict__ cnt, uint32_t n, unsigned long long *__restrict__ start)
-{
-    __shared__ unsigned long long wave_sums[16];
-    const uint32_t t = threadIdx.x, R = (n + 1023u) / 1024u;
-    const uint32_t r0 = t * R < n ? t * R : n, r1 = (t + 1) * R < n ? (t + 1) * R : n;
-    unsigned long long s = 0;
-    for (uint32_t i = r0; i < r1; ++i) s += cnt[i];
-    unsigned long long total;
-    unsigned long long off = block_exscan_1024(s, wave_sums, &total);
-    for (uint32_t i = r0; i < r1; ++i) { start[i] = off; off += cnt[i]; }
-    if (t == 0) start[n] = total;
-}
-
 __global__ __launch_bounds__(256) void k_fin_scatter(const int32_t *__restrict__ hits, unsigned long long n_hits, const int32_t *__restrict__ best, uint32_t n,
                                                       const unsigned long long *__restrict__ start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ nb)
 {
