@@ -97,13 +97,14 @@ __global__ __launch_bounds__(256) void k_hw_locate(DevStore S, HwTileIn in, int3
 
 // Hits only: he[2 p] = h, he[2 p + 1] = end.  out[5 p ..] = h, start, end, leading insertion run, trailing insertion run
 // (h < -1: internal status).  grid = any number of 64-thread blocks (tiles are dealt round-robin); trace: per block
-// (trace_cols + 1) x 2 W x 64 words.
+// (trace_cols + 1) x 2 W x 64 words (W > 2) or (trace_cols / HW_SEG + 2) x 2 W x 64 (checkpoints, W <= 2).
 template <int W>
 __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const int32_t *__restrict__ he, uint64_t *__restrict__ trace_all,
                                                    uint32_t trace_cols, int32_t *__restrict__ out)
 {
     const int lane = threadIdx.x;
-    uint64_t *trace = trace_all + (size_t)blockIdx.x * ((size_t)trace_cols + 1) * 2 * W * 64;
+    // the workgroup's store: checkpoints (W <= 2) or every column's vectors (nn_host's hw_finish_store_bytes is the same formula)
+    uint64_t *trace = trace_all + (size_t)blockIdx.x * (W <= 2 ? ((size_t)trace_cols / HW_SEG + 2) : ((size_t)trace_cols + 1)) * 2 * W * 64;
     const uint64_t *planes = S.planes;
     const uint32_t *pw = reinterpret_cast<const uint32_t *>(planes);
     const uint32_t nseq = S.n;
@@ -150,12 +151,69 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
             const int32_t ms = ok ? end - start + 1 : 0;
             const bool packed = hw_packable(W, h, kmax);           // (per lane: its own distance decides)
             const int32_t pshift = kmax - h - 1;
-            // ---- TRACE: query against t[start..end], the columns' VP / HP vectors stored ----
+            // ---- TRACE: query against t[start..end] ----
             ln.ncols = ok && ms <= (int32_t)trace_cols ? ms : 0;
             if (ok && ms > (int32_t)trace_cols) r0 = -7;
             T.ncols_max = uniform_i32(wave_max_i32(ln.ncols));
             T.jx = 1;
-            {
+            if (W <= 2) {
+                // One and two words of band (thresholds up to 63): only CHECKPOINTS of the band state leave the registers (every HW_SEG-th
+                // column, 1 B per column and word instead of 16), and the walk runs segment by segment from the end on columns recomputed
+                // from their checkpoint into LDS (hw_core.hpp).  Measured on the candidate graph of C3 (2.4 M hits): 54 -> see DESIGN.md.
+                extern __shared__ uint64_t seg[];          // [HW_SEG][2][W][64]
+                T.jx = uniform_i32(wave_min_i32(ln.ncols > 0 ? ln.ncols : 0x7fffffff));
+                auto plo = [&](int32_t off) { return stream64(chunk_lo, off); };
+                auto phi = [&](int32_t off) { return stream64(chunk_hi, off); };
+                auto text = [&](int32_t jb, uint32_t &wl, uint32_t &wh) {       // column c <-> target position start + c
+                    wl = hw_text32(pw, nseq, (uint32_t)nchunks, tid, 0, start + jb);
+                    wh = hw_text32(pw, nseq, (uint32_t)nchunks, tid, 1, start + jb);
+                };
+                // (only start == 0 can have a leading insertion run, see below: the other lanes keep nothing)
+                const bool need = ln.ncols > 0 && start == 0;
+                auto keep = [&](int32_t c, int w, uint64_t vp, uint64_t vn) {
+                    if (need) {
+                        trace[(((size_t)c * 2) * W + w) * 64 + lane] = vp;
+                        trace[(((size_t)c * 2 + 1) * W + w) * 64 + lane] = vn;
+                    }
+                };
+                if (T.ncols_max > 0) hw_run<W, HW_TRACE_CK>(T, ln, plo, phi, text, any_live, keep);
+                if (ln.ncols > 0) {
+                    if (ln.r_final != h) r0 = -5;
+                    else {
+                        r_trail = ln.r_trail;
+                        r_start = start;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const bool walking = need && r0 >= 0;
+                int32_t wi = P, wj = ms;
+                bool bad = false;
+                for (int32_t sg = T.ncols_max > 0 ? (T.ncols_max - 1) / HW_SEG : -1; sg >= 0; --sg) {
+                    const int32_t c0 = sg * HW_SEG;
+                    const bool act = walking && !bad && wi > 0 && wj > c0;
+                    if (__ballot(act) == 0) continue;                         // wave-uniform
+                    BandLane<W> L2;
+                    hw_trace_init<W>(T, L2);
+                    if (sg > 0 && need) {
+#pragma unroll
+                        for (int w = 0; w < W; ++w) {
+                            L2.VP[w] = trace[(((size_t)sg * 2) * W + w) * 64 + lane];
+                            L2.VN[w] = trace[(((size_t)sg * 2 + 1) * W + w) * 64 + lane];
+                        }
+                    }
+                    const uint32_t wl = hw_text32(pw, nseq, (uint32_t)nchunks, tid, 0, start + c0);
+                    const uint32_t wh = hw_text32(pw, nseq, (uint32_t)nchunks, tid, 1, start + c0);
+                    hw_trace_segment<W>(T, c0, L2, plo, phi, wl, wh, [&](int jj, int w, uint64_t vp, uint64_t hp) {
+                        seg[((jj * 2) * W + w) * 64 + lane] = vp;
+                        seg[((jj * 2 + 1) * W + w) * 64 + lane] = hp;
+                    });
+                    if (act) bad = !hw_walk_segment<W>(T.a0, c0, wi, wj, [&](int jj, int which, int w) -> uint64_t { return seg[((jj * 2 + which) * W + w) * 64 + lane]; });
+                }
+                if (walking) {
+                    if (bad) r0 = -6;
+                    else r_lead = wj == 0 ? wi : 0;
+                }
+            } else {
                 auto plo = [&](int32_t off) { return stream64(chunk_lo, off); };
                 auto phi = [&](int32_t off) { return stream64(chunk_hi, off); };
                 auto text = [&](int32_t jb, uint32_t &wl, uint32_t &wh) {       // column c <-> target position start + c
@@ -175,7 +233,6 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
                     }
                 };
                 hw_run<W, HW_TRACE>(T, ln, plo, phi, text, any_live, sink);
-            }
             if (ln.ncols > 0) {
                 if (ln.r_final != h) r0 = -5;
                 else {
@@ -230,6 +287,7 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
                 if (bad) r0 = -6;
                 else r_lead = j == 0 ? i : 0;
             }
+            }          // (W > 2)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (compiler) the next tile's stores stay behind these loads
         }
         if (has) {

@@ -21,7 +21,11 @@
 
 namespace isocon {
 
-enum { HW_LOCATE = 0, HW_START = 1, HW_TRACE = 2 };
+enum { HW_LOCATE = 0, HW_START = 1, HW_TRACE = 2, HW_TRACE_CK = 3 };
+// HW_TRACE_CK: the TRACE pass that keeps only CHECKPOINTS -- the band state (VP, VN) after every HW_SEG-th column -- instead of every
+// column's VP / HP: the walk then goes segment by segment from the end, each segment's columns recomputed from its checkpoint
+// (hw_trace_segment) into a small buffer (LDS on the device) and walked there (hw_walk_segment).  1 byte per column and word instead of 16.
+static constexpr int HW_SEG = 8;
 static constexpr int32_t HWB_INF = 1 << 28;
 
 struct HwTile {          // wave-uniform
@@ -103,7 +107,8 @@ ISO_HD uint32_t hw_bit(const uint64_t (&V)[W], int32_t r)
 // One pass over one lane of one tile.  plo / phi(off): 64 bits of the query's bit-planes starting at row offset off (the
 // caller hands a forward or a reversed stream); text(jb, wl, wh): the lane's target bits of columns jb + 1 .. jb + 32;
 // any_live(live): does any lane of the wave still need columns (device: a ballot; emulator: the lane itself);
-// sink(j, word, vp_new, hp): TRACE only.
+// sink(j, word, vp_new, hp): TRACE; sink(j / HW_SEG, word, vp_new, vn_new) after every column j that is a multiple of HW_SEG: TRACE_CK
+// (there T.jx = the smallest ncols of the tile's lanes: the blocks before it take the unrolled path).
 template <int W, int MODE, class PLo, class PHi, class Text, class AnyLive, class Sink>
 ISO_HD void hw_run(const HwTile &T, HwLane &ln, PLo plo, PHi phi, Text text, AnyLive any_live, Sink sink)
 {
@@ -148,6 +153,10 @@ ISO_HD void hw_run(const HwTile &T, HwLane &ln, PLo plo, PHi phi, Text text, Any
                 }
                 band_step_eq<W>(L, EQ);
                 window_slide<W>(NL, NH, VM, FL, FH);
+                if (MODE == HW_TRACE_CK && (jj & (HW_SEG - 1)) == HW_SEG - 1) {
+#pragma unroll
+                    for (int i = 0; i < W; ++i) sink((jb + jj + 1) / HW_SEG, i, L.VP[i], L.VN[i]);
+                }
             }
         } else {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -178,9 +187,13 @@ ISO_HD void hw_run(const HwTile &T, HwLane &ln, PLo plo, PHi phi, Text text, Any
                         if (hw_row_value<W>(L, top, b) == ln.h) pl = j;
                     }
                 } else {
-                    if (j <= ln.ncols) {
+                    if (MODE == HW_TRACE && j <= ln.ncols) {
 #pragma unroll
                         for (int i = 0; i < W; ++i) sink(j, i, L.VP[i], HP[i]);
+                    }
+                    if (MODE == HW_TRACE_CK && j <= ln.ncols && (j & (HW_SEG - 1)) == 0) {
+#pragma unroll
+                        for (int i = 0; i < W; ++i) sink(j / HW_SEG, i, L.VP[i], L.VN[i]);
                     }
                     if (j == ln.ncols && b >= 0 && b < 64 * W) {
                         ln.r_final = hw_row_value<W>(L, top, b);
@@ -206,6 +219,62 @@ ISO_HD void hw_run(const HwTile &T, HwLane &ln, PLo plo, PHi phi, Text text, Any
     ln.r_h = h;
     ln.r_end = end;
     ln.r_pl = pl;
+}
+
+// Columns c0 + 1 .. c0 + HW_SEG of the TRACE pass again, from the band state after column c0 (c0 a multiple of HW_SEG; L = the
+// checkpoint, or the initial state for c0 = 0: hw_trace_init).  wl / wh: the lane's target bits of these columns (bit jj <-> column
+// c0 + 1 + jj).  sink(jj, word, vp_new, hp) like the TRACE pass.
+template <int W>
+ISO_HD void hw_trace_init(const HwTile &T, BandLane<W> &L)
+{
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        L.VP[i] = valid_word(-T.a0, i);
+        L.VN[i] = ~L.VP[i];
+    }
+    L.ztop = 0;
+}
+
+template <int W, class PLo, class PHi, class Sink>
+ISO_HD void hw_trace_segment(const HwTile &T, int32_t c0, BandLane<W> &L, PLo plo, PHi phi, uint32_t wl, uint32_t wh, Sink sink)
+{
+    uint64_t NL[W], NH[W], VM[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        NL[i] = ~plo(T.a0 + c0 + 64 * i);
+        NH[i] = ~phi(T.a0 + c0 + 64 * i);
+        VM[i] = valid_word(-T.a0 - c0, i);
+    }
+    uint64_t FL = ~plo(T.a0 + c0 + 64 * W), FH = ~phi(T.a0 + c0 + 64 * W);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int jj = 0; jj < HW_SEG; ++jj) {
+        const uint32_t sl = 0u - ((wl >> jj) & 1u), sh = 0u - ((wh >> jj) & 1u);
+        const uint64_t sl64 = ((uint64_t)sl << 32) | sl, sh64 = ((uint64_t)sh << 32) | sh;
+        uint64_t EQ[W], HP[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) EQ[i] = (NL[i] ^ sl64) & (NH[i] ^ sh64) & VM[i];
+        band_step_eq_hp<W>(L, EQ, HP);
+        window_slide<W>(NL, NH, VM, FL, FH);
+#pragma unroll
+        for (int i = 0; i < W; ++i) sink(jj, i, L.VP[i], HP[i]);
+    }
+}
+
+// The walk inside the segment of columns c0 + 1 .. c0 + HW_SEG: load(jj, which, word) = what hw_trace_segment's sink got for column
+// c0 + 1 + jj.  Stops when the path leaves the segment (j == c0) or ends (i == 0); false: off the band (cannot happen on an optimal path).
+template <int W, class Load>
+ISO_HD bool hw_walk_segment(int32_t a0, int32_t c0, int32_t &i, int32_t &j, Load load)
+{
+    while (i > 0 && j > c0) {
+        const int32_t hb = i - a0 - j, vb = hb - 1;
+        if (hb < 0 || hb >= 64 * W) return false;
+        if (vb >= 0 && ((load(j - c0 - 1, 0, vb >> 6) >> (vb & 63)) & 1)) { --i; continue; }
+        if ((load(j - c0 - 1, 1, hb >> 6) >> (hb & 63)) & 1) --j;
+        else { --i; --j; }
+    }
+    return true;
 }
 
 // Packed column store (one word of band, pairs at distance h <= 14): the walk only visits cells whose diagonal offset j - i lies

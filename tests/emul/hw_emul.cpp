@@ -90,6 +90,49 @@ static void tile(const char *q, int P, int nl, const char **ts, const int *tl, c
     int smax = 0;
     for (int l = 0; l < nl; ++l) if (start[l] >= 0) smax = std::max(smax, end[l] - start[l] + 1);
     HwTile C; C.P = P; C.a0 = -hk; C.ncols_max = smax; C.jx = 1;
+    if (W <= 2) {
+        // checkpoints every HW_SEG columns, the walk segment by segment on recomputed columns (what k_hw_finish<1|2> does)
+        int smin = 1 << 30;
+        for (int l = 0; l < nl; ++l) if (start[l] >= 0) smin = std::min(smin, end[l] - start[l] + 1);
+        C.jx = smin;
+        for (int l = 0; l < nl; ++l) {
+            if (start[l] < 0) continue;
+            HwLane ln; memset(&ln, 0, sizeof ln);
+            const int ms = end[l] - start[l] + 1;
+            ln.ncols = ms; ln.h = h[l];
+            const long s0 = start[l];
+            auto text = [&](int32_t jb, uint32_t &wl, uint32_t &wh) {
+                wl = wh = 0;
+                for (int x = 0; x < 32; ++x) { wl |= T[l].bit(T[l].lo, s0 + jb + x) << x; wh |= T[l].bit(T[l].hi, s0 + jb + x) << x; }
+            };
+            std::vector<uint64_t> ck((size_t)(smax / HW_SEG + 2) * 2 * W, 0);
+            auto keep = [&](int32_t c, int w, uint64_t vp, uint64_t vn) { ck[((size_t)c * 2) * W + w] = vp; ck[((size_t)c * 2 + 1) * W + w] = vn; };
+            hw_run<W, HW_TRACE_CK>(C, ln, f_lo, f_hi, text, alone, keep);
+            if (ln.r_final != h[l]) { out[5 * l] = -5; continue; }
+            int32_t lead = 0;
+            if (start[l] == 0) {
+                int32_t wi = P, wj = ms;
+                bool ok = true;
+                uint64_t seg[HW_SEG * 2 * W];
+                for (int32_t sg = (smax - 1) / HW_SEG; sg >= 0 && ok; --sg) {
+                    const int32_t c0 = sg * HW_SEG;
+                    if (!(wi > 0 && wj > c0)) continue;
+                    BandLane<W> L2;
+                    if (sg == 0) hw_trace_init<W>(C, L2);
+                    else for (int w = 0; w < W; ++w) { L2.VP[w] = ck[((size_t)sg * 2) * W + w]; L2.VN[w] = ck[((size_t)sg * 2 + 1) * W + w]; }
+                    uint32_t wl = 0, wh = 0;
+                    for (int x = 0; x < 32; ++x) { wl |= T[l].bit(T[l].lo, s0 + c0 + x) << x; wh |= T[l].bit(T[l].hi, s0 + c0 + x) << x; }
+                    hw_trace_segment<W>(C, c0, L2, f_lo, f_hi, wl, wh,
+                                        [&](int jj, int w, uint64_t vp, uint64_t hp) { seg[(jj * 2) * W + w] = vp; seg[(jj * 2 + 1) * W + w] = hp; });
+                    ok = hw_walk_segment<W>(C.a0, c0, wi, wj, [&](int jj, int which, int w) -> uint64_t { return seg[(jj * 2 + which) * W + w]; });
+                }
+                lead = !ok ? -1 : (wj == 0 ? wi : 0);
+            }
+            if (lead < 0) { out[5 * l] = -6; continue; }
+            out[5 * l] = h[l]; out[5 * l + 1] = start[l]; out[5 * l + 2] = end[l]; out[5 * l + 3] = lead; out[5 * l + 4] = ln.r_trail;
+        }
+        return;
+    }
     for (int l = 0; l < nl; ++l) {
         if (start[l] < 0) continue;
         HwLane ln; memset(&ln, 0, sizeof ln);
