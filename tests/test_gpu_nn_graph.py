@@ -356,3 +356,46 @@ def test_narrow_mode_on_reads_with_few_errors(monkeypatch):
             assert rp[1] == rp[0] or best[i] == e[rp[0]]
     finally:
         st.close()
+
+
+def test_device_resident_entry_points_argument_checks_and_long_rows():
+    """isocon_nn_finalize_dev on a graph with a row of hundreds of equidistant neighbours (the device sort declines, the host routine
+    finishes from the downloaded buffers) equals isocon_nn_finalize on the same hits; null / short buffers are refused."""
+    import random
+    import torch
+    from isocon_amd import _lib
+    from isocon_amd.store import SeqStore, nn_finalize
+    rng = random.Random(5)
+    seqs = set()
+    for f in range(5):
+        L = rng.randrange(400, 700)
+        root = "".join(rng.choice("ACGT") for _ in range(L))
+        seqs.add(root)
+        for _ in range(420):
+            i = rng.randrange(L)
+            seqs.add(root[:i] + rng.choice("ACGT".replace(root[i], "")) + root[i + 1:])
+    seqs = sorted(seqs, key=len)
+    st = SeqStore(seqs)
+    try:
+        n = st.n
+        best = np.full(n, _lib.NN_INF, dtype=np.int32)
+        hits = []
+        for phase in (0, 1, 2):
+            h, _ = st.nn_partial(0, n, phase, best)
+            hits.append(h)
+        hits = np.concatenate(hits)
+        want = nn_finalize(n, best, hits)
+        assert (np.diff(want[1]) > 256).any()
+        dev = torch.device("cuda", 0)
+        b_d = torch.from_numpy(best).to(dev)
+        h_d = torch.from_numpy(np.ascontiguousarray(hits)).to(dev)
+        got = st.nn_finalize_dev(b_d.data_ptr(), h_d.data_ptr(), len(hits))
+        assert all((x == y).all() for x, y in zip(got, want))
+        with pytest.raises(RuntimeError):
+            st.nn_partial_dev(0, n, 1, 0, False)                       # no bounds buffer
+        with pytest.raises(RuntimeError):
+            st.nn_partial_dev(0, n, 7, b_d.data_ptr(), False)          # no such phase
+        with pytest.raises(RuntimeError):
+            st.nn_finalize_dev(b_d.data_ptr(), 0, 5)                   # rows announced, no buffer
+    finally:
+        st.close()
