@@ -203,11 +203,18 @@ __global__ __launch_bounds__(64) void k_hw_finish(DevStore S, HwTileIn in, const
                     }
                     const uint32_t wl = hw_text32(pw, nseq, (uint32_t)nchunks, tid, 0, start + c0);
                     const uint32_t wh = hw_text32(pw, nseq, (uint32_t)nchunks, tid, 1, start + c0);
-                    hw_trace_segment<W>(T, c0, L2, plo, phi, wl, wh, [&](int jj, int w, uint64_t vp, uint64_t hp) {
-                        seg[((jj * 2) * W + w) * 64 + lane] = vp;
-                        seg[((jj * 2 + 1) * W + w) * 64 + lane] = hp;
-                    });
-                    if (act) bad = !hw_walk_segment<W>(T.a0, c0, wi, wj, [&](int jj, int which, int w) -> uint64_t { return seg[((jj * 2 + which) * W + w) * 64 + lane]; });
+                    if (W == 1) {
+                        // one word of band: the segment's vectors stay in registers and the walk is an unrolled loop over its columns
+                        uint64_t VPs[HW_SEG][W], HPs[HW_SEG][W];
+                        hw_trace_segment<W>(T, c0, L2, plo, phi, wl, wh, [&](int jj, int w, uint64_t vp, uint64_t hp) { VPs[jj][w] = vp; HPs[jj][w] = hp; });
+                        if (act) bad = !hw_walk_segment_regs<W>(T.a0, c0, wi, wj, VPs, HPs);
+                    } else {
+                        hw_trace_segment<W>(T, c0, L2, plo, phi, wl, wh, [&](int jj, int w, uint64_t vp, uint64_t hp) {
+                            seg[((jj * 2) * W + w) * 64 + lane] = vp;
+                            seg[((jj * 2 + 1) * W + w) * 64 + lane] = hp;
+                        });
+                        if (act) bad = !hw_walk_segment<W>(T.a0, c0, wi, wj, [&](int jj, int which, int w) -> uint64_t { return seg[((jj * 2 + which) * W + w) * 64 + lane]; });
+                    }
                 }
                 if (walking) {
                     if (bad) r0 = -6;

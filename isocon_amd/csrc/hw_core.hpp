@@ -277,6 +277,35 @@ ISO_HD bool hw_walk_segment(int32_t a0, int32_t c0, int32_t &i, int32_t &j, Load
     return true;
 }
 
+// The same walk with the segment's vectors in REGISTERS (the device's one-word form): the path visits the columns of a segment in
+// descending order and never returns to one, so the columns can be an unrolled loop -- a lane takes part in column c0 + 1 + jj while its
+// j is that column (query-only steps stay in the column), and VPs / HPs are only ever indexed by compile-time constants.
+template <int W>
+ISO_HD bool hw_walk_segment_regs(int32_t a0, int32_t c0, int32_t &i, int32_t &j, const uint64_t (&VPs)[HW_SEG][W], const uint64_t (&HPs)[HW_SEG][W])
+{
+    bool ok = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int jj = HW_SEG - 1; jj >= 0; --jj) {
+        if (ok && i > 0 && j == c0 + jj + 1) {
+            for (;;) {
+                const int32_t hb = i - a0 - j, vb = hb - 1;
+                if (hb < 0 || hb >= 64 * W) { ok = false; break; }
+                if (vb >= 0 && hw_bit<W>(VPs[jj], vb)) {
+                    --i;
+                    if (i == 0) break;
+                    continue;
+                }
+                if (hw_bit<W>(HPs[jj], hb)) --j;
+                else { --i; --j; }
+                break;
+            }
+        }
+    }
+    return ok;
+}
+
 // Packed column store (one word of band, pairs at distance h <= 14): the walk only visits cells whose diagonal offset j - i lies
 // in [-h, h], i.e. window bits kmax - h - 1 .. kmax + h of VP and HP -- at most 32 of each, so both fit ONE 64-bit word
 // (VP part low, HP part high) instead of two: half the bytes of the column store, which is what the finish kernel is bound by.

@@ -122,9 +122,14 @@ static void tile(const char *q, int P, int nl, const char **ts, const int *tl, c
                     else for (int w = 0; w < W; ++w) { L2.VP[w] = ck[((size_t)sg * 2) * W + w]; L2.VN[w] = ck[((size_t)sg * 2 + 1) * W + w]; }
                     uint32_t wl = 0, wh = 0;
                     for (int x = 0; x < 32; ++x) { wl |= T[l].bit(T[l].lo, s0 + c0 + x) << x; wh |= T[l].bit(T[l].hi, s0 + c0 + x) << x; }
-                    hw_trace_segment<W>(C, c0, L2, f_lo, f_hi, wl, wh,
-                                        [&](int jj, int w, uint64_t vp, uint64_t hp) { seg[(jj * 2) * W + w] = vp; seg[(jj * 2 + 1) * W + w] = hp; });
-                    ok = hw_walk_segment<W>(C.a0, c0, wi, wj, [&](int jj, int which, int w) -> uint64_t { return seg[(jj * 2 + which) * W + w]; });
+                    uint64_t VPs[HW_SEG][W], HPs[HW_SEG][W];
+                    hw_trace_segment<W>(C, c0, L2, f_lo, f_hi, wl, wh, [&](int jj, int w, uint64_t vp, uint64_t hp) {
+                        seg[(jj * 2) * W + w] = vp; seg[(jj * 2 + 1) * W + w] = hp;
+                        VPs[jj][w] = vp; HPs[jj][w] = hp;
+                    });
+                    // one word: the walk on registers, as k_hw_finish<1> does; two words: through the buffer (LDS on the device)
+                    if (W == 1) ok = hw_walk_segment_regs<W>(C.a0, c0, wi, wj, VPs, HPs);
+                    else ok = hw_walk_segment<W>(C.a0, c0, wi, wj, [&](int jj, int which, int w) -> uint64_t { return seg[(jj * 2 + which) * W + w]; });
                 }
                 lead = !ok ? -1 : (wj == 0 ? wi : 0);
             }
