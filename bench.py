@@ -49,6 +49,8 @@ HBM_PEAK_GBS = 8000.0                       # MI355X HBM3E spec (MI355X_MICROARC
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMD-32 x 2.4 GHz, one wave64 VALU instruction per 2 cycles (same guide)
 HALF_RATE_SHARE = 5.0 / 19.0      # of the table kernel's column (static, from its ISA)
 HALF_RATE_COST = 1.72             # issue cost of a half-rate vector instruction relative to a full-rate one (measured)
+STREAM_RATE_OF_NOMINAL = 2.0 / 2.43   # a pure stream of independent v_and_b32, 6 waves per SIMD, every CU busy: 2.43 cycles per instruction
+                                      # at the nominal 2.4 GHz (clock under load + issue overhead): what "all issue slots used" measures as
 MFMA_FP4_PEAK_MACS = 5.0e15                 # ~10 PFLOP/s dense FP4 (same guide, chip-level parameters) = 5e15 multiply-adds / s
 COUNTERS = os.path.join(ROOT, "profiles", "counters.json")   # written by scripts/summarize_profile.py from rocprofv3 --pmc passes
 
@@ -385,7 +387,9 @@ def main():
                 # (v_bfe, v_mad_u32_u24, v_alignbit, v_lshl_add_u64, v_lshrrev_b64) at 1.72x that cost.  The unrolled column of the table kernel
                 # is 14 full-rate + 5 half-rate instructions (ISA of k_nn_scan_refill<8, 1>): frac above counts instructions, this one issue slots.
                 "issue_slots": {"half_rate_share_of_column": HALF_RATE_SHARE, "half_rate_cost": HALF_RATE_COST,
-                                "frac": (achieved / VALU_PEAK_WAVE_INSTR) * (1.0 + HALF_RATE_SHARE * (HALF_RATE_COST - 1.0)) if achieved else None},
+                                "frac": (achieved / VALU_PEAK_WAVE_INSTR) * (1.0 + HALF_RATE_SHARE * (HALF_RATE_COST - 1.0)) if achieved else None,
+                                "stream_rate_of_nominal_peak": STREAM_RATE_OF_NOMINAL,
+                                "frac_of_stream_rate": (achieved / VALU_PEAK_WAVE_INSTR) * (1.0 + HALF_RATE_SHARE * (HALF_RATE_COST - 1.0)) / STREAM_RATE_OF_NOMINAL if achieved else None},
                 "step_kernels_ms": {"bounds (profiles + k_qgram_mm)": pm["bound_kernel_ms"], "seeds (k_ed_lanes)": pm["seed_kernel_ms"],
                                     "survivor lists (k_nn_survivors)": pm["list_kernel_ms"], "tables (k_nn_scan_refill)": k_ms,
                                     "pair per lane (k_ed_lanes)": pm["lanes_kernel_ms"], "all kernels": pm["kernel_ms"]},
