@@ -241,7 +241,7 @@ def get_all_NN(batch_of_queries, global_index_in_matrix, start_index, seq_to_acc
     from .nearest_neighbor_graph import _process_group
     group = _process_group()            # one process per GPU: every rank aligns its share of the pairs, all get all results
     if group is None:
-        res = SeqStore(seqs).hw_pairs(q, t, np.full(len(q), max_ed_allowed, dtype=np.int32))
+        res = SeqStore(seqs).hw_pairs(q, t, np.full(len(q), max_ed_allowed, dtype=np.int32), reuse_buffer=True)       # (digested right below)
     else:
         from .dist import sharded_hw_pairs
         res = sharded_hw_pairs(SeqStore(seqs), q, t, max_ed_allowed, dist=group)

@@ -127,7 +127,7 @@ class SeqStore(object):
             _lib.check(rc, "isocon_qgram_bound_matrix")
             return row_ptr, out[:int(row_ptr[-1])]
 
-    def hw_pairs(self, q, t, k, return_ms=False):
+    def hw_pairs(self, q, t, k, return_ms=False, reuse_buffer=False):
         """Infix (edlib "HW", task="path") alignment of sequence q[p] inside sequence t[p] with threshold k[p]:
         int32 [n, 5] = distance (-1 if > k), start, end, leading insertion run, trailing insertion run
         (isocon_hw_pairs; reference call site end_invariant_functions.py:594)."""
@@ -136,7 +136,12 @@ class SeqStore(object):
         kk = np.ascontiguousarray(np.broadcast_to(np.asarray(k, dtype=np.int32), q.shape))
         if len(q) != len(t):
             raise ValueError("pair arrays differ in length")
-        out = np.empty((len(q), 5), dtype=np.int32)          # (every row is written by the call)
+        # (every row is written by the call)  reuse_buffer: the rows land in a pinned buffer that the NEXT such call overwrites -- for
+        # callers that digest the result at once (millions of pairs: 100 MB come down without a staged copy)
+        if reuse_buffer and len(q):
+            out = _host_buffer("hw_out", len(q) * 20, self._L).view(np.int32).reshape(len(q), 5)
+        else:
+            out = np.empty((len(q), 5), dtype=np.int32)
         ms = ctypes.c_float(0)
         _lib.check(self._L.isocon_hw_pairs(self._h, _ptr(q, _lib.u32p), _ptr(t, _lib.u32p), _ptr(kk, _lib.i32p), len(q),
                                            _ptr(out, _lib.i32p), ctypes.byref(ms)), "isocon_hw_pairs")

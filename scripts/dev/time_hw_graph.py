@@ -23,7 +23,7 @@ stg.hw_pairs(gq[:4096], gt[:4096], gk[:4096])
 ref = None
 for rep in range(4):
     if rep == 3: os.environ["ISOCON_DEBUG"] = "1"
-    t0 = time.perf_counter(); gres, g_ms = stg.hw_pairs(gq, gt, gk, return_ms=True); w = time.perf_counter() - t0
+    t0 = time.perf_counter(); gres, g_ms = stg.hw_pairs(gq, gt, gk, return_ms=True, reuse_buffer=True); w = time.perf_counter() - t0
     import hashlib
     dig = hashlib.sha1(gres.tobytes()).hexdigest()[:16]
     print("hw_graph: %d pairs, %d hits, wall %.1f ms, kernels %.1f ms, digest %s" % (len(gq), int((gres[:, 0] >= 0).sum()), w * 1e3, g_ms, dig), flush=True)
