@@ -1,4 +1,4 @@
-/* _pyhelp.c -- two loops over Python strings that cost tens of milliseconds per call in pure Python at 50 000 x 2.5 kb: the
+/* _pyhelp.c -- loops over Python objects that cost tens of milliseconds per call in pure Python at 50 000 x 2.5 kb: the
  * addresses / lengths of a list of ASCII str objects (so that the C ABI's isocon_store_create_ptrs gathers them straight into its
  * pinned staging buffer: no 125 MB "".join), and the inverse, a list of str cut out of one ASCII buffer (the gapped alignments
  * isocon_sg_strings_batch returns).  Host glue of the Python wrappers only; the C ABI itself (include/isocon_hip.h) knows nothing
@@ -51,7 +51,47 @@ static PyObject *split_ascii(PyObject *self, PyObject *args)
     return out;
 }
 
+/* csr_to_dict(keys: list, is_query_addr: int (uint8[n] or 0 = all), best_addr: int (int32[n]), row_ptr_addr: int (int64[n + 1]),
+ *             cols_addr: int (uint32[]), n: int) -> {keys[i]: {keys[c]: best[i] for c in row i}} for the query entries, in entry order and,
+ * inside a row, in column order (the insertion order the reference's loop produces: nearest_neighbor_graph.py:145-178) */
+static PyObject *csr_to_dict(PyObject *self, PyObject *args)
+{
+    PyObject *keys;
+    unsigned long long qa, ba, ra, ca;
+    Py_ssize_t n;
+    if (!PyArg_ParseTuple(args, "OKKKKn", &keys, &qa, &ba, &ra, &ca, &n)) return NULL;
+    if (!PyList_Check(keys) || PyList_GET_SIZE(keys) < n) { PyErr_SetString(PyExc_TypeError, "csr_to_dict: a list of n keys is required"); return NULL; }
+    const uint8_t *isq = (const uint8_t *)(uintptr_t)qa;
+    const int32_t *best = (const int32_t *)(uintptr_t)ba;
+    const int64_t *row_ptr = (const int64_t *)(uintptr_t)ra;
+    const uint32_t *cols = (const uint32_t *)(uintptr_t)ca;
+    PyObject *out = PyDict_New();
+    if (!out) return NULL;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        if (isq && !isq[i]) continue;
+        PyObject *row = PyDict_New(), *val = NULL;
+        if (!row) { Py_DECREF(out); return NULL; }
+        if (row_ptr[i + 1] > row_ptr[i]) {
+            val = PyLong_FromLong((long)best[i]);
+            if (!val) { Py_DECREF(row); Py_DECREF(out); return NULL; }
+        }
+        for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+            if ((Py_ssize_t)cols[e] >= n || PyDict_SetItem(row, PyList_GET_ITEM(keys, (Py_ssize_t)cols[e]), val) < 0) {
+                if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "csr_to_dict: column out of range");
+                Py_XDECREF(val); Py_DECREF(row); Py_DECREF(out);
+                return NULL;
+            }
+        }
+        Py_XDECREF(val);
+        const int rc = PyDict_SetItem(out, PyList_GET_ITEM(keys, i), row);
+        Py_DECREF(row);
+        if (rc < 0) { Py_DECREF(out); return NULL; }
+    }
+    return out;
+}
+
 static PyMethodDef methods[] = {
+    {"csr_to_dict", csr_to_dict, METH_VARARGS, "dict of dicts from the CSR arrays of a nearest-neighbour graph"},
     {"str_pointers", str_pointers, METH_VARARGS, "addresses and lengths of a list of ASCII str"},
     {"split_ascii", split_ascii, METH_VARARGS, "list of str cut out of an ASCII buffer"},
     {NULL, NULL, 0, NULL}};

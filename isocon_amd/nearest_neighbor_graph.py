@@ -71,6 +71,16 @@ def _graph(st, seqs, is_converged=None, is_target=None, depth=2 ** 32):
 
 
 def _rows_to_dict(accs, is_query, best, row_ptr, cols):
+    from . import _lib
+    H = _lib.pyhelp()
+    if H is not None and hasattr(H, "csr_to_dict") and isinstance(accs, list):
+        # 50 000 rows, 80 000 edges: the dict of dicts built in C (isocon_amd/cpy/_pyhelp.c) -- same insertion order as the loop below
+        b = np.ascontiguousarray(best, dtype=np.int32)
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        c = np.ascontiguousarray(cols, dtype=np.uint32)
+        isq = np.ascontiguousarray(is_query, dtype=np.uint8)
+        allq = bool(isq.all())
+        return H.csr_to_dict(accs, 0 if allq else isq.ctypes.data, b.ctypes.data, rp.ctypes.data, c.ctypes.data if len(c) else 0, len(accs))
     out = {}
     nbr = [accs[c] for c in cols.tolist()]            # neighbour accessions in CSR order: rows are slices of it
     row_ptr = row_ptr.tolist()

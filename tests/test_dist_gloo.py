@@ -172,7 +172,7 @@ class FakePairStore(object):
         from oracle import oracle as O
         return np.array([O.ed_bounded(self.seqs[int(x)], self.seqs[int(y)], -1 if k is None else int(k[i])) for i, (x, y) in enumerate(zip(a, b))], dtype=np.int32)
 
-    def hw_pairs(self, q, t, k):
+    def hw_pairs(self, q, t, k, **_unused):
         import sys
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import oracle as O

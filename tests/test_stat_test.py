@@ -97,7 +97,7 @@ class OracleStore(object):
     def __init__(self, seqs):
         self.seqs = list(seqs)
 
-    def hw_pairs(self, q, t, k):
+    def hw_pairs(self, q, t, k, **_unused):
         import numpy as np
         from oracle import oracle as O
         from test_all_nn import hw_row
