@@ -119,7 +119,7 @@ def build_pyhelp(verbose: bool = False):
         return None
     if os.path.exists(PYHELP_SO) and os.path.getmtime(PYHELP_SO) >= os.path.getmtime(src):
         return PYHELP_SO
-    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-I" + sysconfig.get_paths()["include"], "-o", PYHELP_SO, src]
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-pthread", "-I" + sysconfig.get_paths()["include"], "-o", PYHELP_SO, src]
     if verbose:
         print(" ".join(cmd))
     try:

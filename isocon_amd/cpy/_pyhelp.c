@@ -8,6 +8,8 @@
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
+#include <pthread.h>
 
 /* str_pointers(seqs: list[str], ptrs_addr: int, lens_addr: int) -> total bytes; arrays of len(seqs) uint64 each */
 static PyObject *str_pointers(PyObject *self, PyObject *args)
@@ -31,7 +33,21 @@ static PyObject *str_pointers(PyObject *self, PyObject *args)
     return PyLong_FromUnsignedLongLong(total);
 }
 
-/* split_ascii(buf_addr: int, ptr_addr: int, n: int) -> [str(buf[ptr[i]:ptr[i+1]]) for i < n]; ptr = int64[n + 1] */
+/* split_ascii(buf_addr: int, ptr_addr: int, n: int) -> [str(buf[ptr[i]:ptr[i+1]]) for i < n]; ptr = int64[n + 1].
+ * The str objects are created first; their bytes are then copied by up to four threads (no Python API inside them): at 50 000 x 2.9 kb
+ * the copy and the first touch of 146 MB of fresh heap are what the call costs. */
+typedef struct { char **dst; const char *buf; const int64_t *ptr; Py_ssize_t i0, i1; } split_job;
+
+static void *split_worker(void *arg)
+{
+    const split_job *j = (const split_job *)arg;
+    for (Py_ssize_t i = j->i0; i < j->i1; ++i) {
+        const int64_t len = j->ptr[i + 1] - j->ptr[i];
+        if (len > 0) memcpy(j->dst[i], j->buf + j->ptr[i], (size_t)len);
+    }
+    return NULL;
+}
+
 static PyObject *split_ascii(PyObject *self, PyObject *args)
 {
     unsigned long long ba, pa;
@@ -41,13 +57,35 @@ static PyObject *split_ascii(PyObject *self, PyObject *args)
     const int64_t *ptr = (const int64_t *)(uintptr_t)pa;
     PyObject *out = PyList_New(n);
     if (!out) return NULL;
+    char **dst = (char **)malloc((size_t)(n > 0 ? n : 1) * sizeof(char *));
+    if (!dst) { Py_DECREF(out); return PyErr_NoMemory(); }
     for (Py_ssize_t i = 0; i < n; ++i) {
         const int64_t len = ptr[i + 1] - ptr[i];
         PyObject *s = len >= 0 ? PyUnicode_New((Py_ssize_t)len, 127) : NULL;
-        if (!s) { Py_DECREF(out); if (len < 0) PyErr_SetString(PyExc_ValueError, "split_ascii: descending offsets"); return NULL; }
-        if (len) memcpy(PyUnicode_1BYTE_DATA(s), buf + ptr[i], (size_t)len);
+        if (!s) { Py_DECREF(out); free(dst); if (len < 0) PyErr_SetString(PyExc_ValueError, "split_ascii: descending offsets"); return NULL; }
+        dst[i] = (char *)PyUnicode_1BYTE_DATA(s);
         PyList_SET_ITEM(out, i, s);
     }
+    const int64_t total = n > 0 ? ptr[n] - ptr[0] : 0;
+    const int n_thr = total >= ((int64_t)8 << 20) ? 4 : 1;
+    split_job jobs[4];
+    for (int t = 0; t < n_thr; ++t) {
+        jobs[t].dst = dst; jobs[t].buf = buf; jobs[t].ptr = ptr;
+        jobs[t].i0 = n * t / n_thr; jobs[t].i1 = n * (t + 1) / n_thr;
+    }
+    if (n_thr == 1) split_worker(&jobs[0]);
+    else {
+        pthread_t th[4];
+        int started[4] = {0, 0, 0, 0};
+        Py_BEGIN_ALLOW_THREADS
+        for (int t = 0; t < n_thr; ++t) started[t] = pthread_create(&th[t], NULL, split_worker, &jobs[t]) == 0;
+        for (int t = 0; t < n_thr; ++t) {
+            if (started[t]) pthread_join(th[t], NULL);
+            else split_worker(&jobs[t]);
+        }
+        Py_END_ALLOW_THREADS
+    }
+    free(dst);
     return out;
 }
 
