@@ -128,7 +128,34 @@ static PyObject *csr_to_dict(PyObject *self, PyObject *args)
     return out;
 }
 
+/* pair_ids(index: dict[str, int], pairs: list[tuple], a_addr: int, b_addr: int) -> number of pairs looked up (len(pairs)), or -1 - i
+ * when a member of pair i is not a key: a[i], b[i] = index[pairs[i][0]], index[pairs[i][1]] as uint32 */
+static PyObject *pair_ids(PyObject *self, PyObject *args)
+{
+    PyObject *index, *pairs;
+    unsigned long long aa, ba;
+    if (!PyArg_ParseTuple(args, "OOKK", &index, &pairs, &aa, &ba)) return NULL;
+    if (!PyDict_Check(index) || !PyList_Check(pairs)) { PyErr_SetString(PyExc_TypeError, "pair_ids: a dict and a list are required"); return NULL; }
+    uint32_t *a = (uint32_t *)(uintptr_t)aa, *b = (uint32_t *)(uintptr_t)ba;
+    const Py_ssize_t n = PyList_GET_SIZE(pairs);
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *p = PyList_GET_ITEM(pairs, i);
+        if (!PyTuple_Check(p) || PyTuple_GET_SIZE(p) < 2) { PyErr_Format(PyExc_TypeError, "pair %zd is not a 2-tuple", i); return NULL; }
+        PyObject *va = PyDict_GetItemWithError(index, PyTuple_GET_ITEM(p, 0));
+        PyObject *vb = va ? PyDict_GetItemWithError(index, PyTuple_GET_ITEM(p, 1)) : NULL;
+        if (!va || !vb) {
+            if (PyErr_Occurred()) return NULL;
+            return PyLong_FromSsize_t(-1 - i);
+        }
+        const unsigned long xa = PyLong_AsUnsignedLong(va), xb = PyLong_AsUnsignedLong(vb);
+        if ((xa == (unsigned long)-1 || xb == (unsigned long)-1) && PyErr_Occurred()) return NULL;
+        a[i] = (uint32_t)xa; b[i] = (uint32_t)xb;
+    }
+    return PyLong_FromSsize_t(n);
+}
+
 static PyMethodDef methods[] = {
+    {"pair_ids", pair_ids, METH_VARARGS, "ids of the members of a list of pairs"},
     {"csr_to_dict", csr_to_dict, METH_VARARGS, "dict of dicts from the CSR arrays of a nearest-neighbour graph"},
     {"str_pointers", str_pointers, METH_VARARGS, "addresses and lengths of a list of ASCII str"},
     {"split_ascii", split_ascii, METH_VARARGS, "list of str cut out of an ASCII buffer"},
