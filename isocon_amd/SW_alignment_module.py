@@ -16,7 +16,32 @@ TIE_POLICY = 0
 _OPS = "=XID"
 # id(result tuple) -> (the tuple, the batch's CIGAR ops as uint32 array, begin, end) for the alignments of the most recent batch call; lets
 # isocon_amd.functions.filter_exon_differences work on run-length ops instead of re-scanning the gapped strings.
-_OPS_CACHE = {}
+class _OpsCache(object):
+    """the result tuples of the most recent batch with their run-length ops; the id -> position index is built when first asked for"""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.out, self.ops, self.ptr, self._index = None, None, None, None
+
+    def set(self, out, ops, ptr):
+        self.out, self.ops, self.ptr, self._index = out, ops, ptr, None
+
+    def _idx(self):
+        if self._index is None:
+            self._index = {id(t): p for p, t in enumerate(self.out)} if self.out else {}
+        return self._index
+
+    def __contains__(self, key):
+        return key in self._idx()
+
+    def get(self, key):
+        p = self._idx().get(key)
+        return None if p is None else (self.out[p], self.ops, self.ptr[p], self.ptr[p + 1])
+
+
+_OPS_CACHE = _OpsCache()
 
 
 def cigar_to_seq(cigar, query, ref):
@@ -117,10 +142,7 @@ def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed
         aln_b = str(aln_b, "ascii")
         ptr = ptr.tolist()
         out = [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], counts[p]) for p in range(len(pairs))]
-    _OPS_CACHE.clear()
-    op = ops_ptr.tolist()
-    for p, t in enumerate(out):
-        _OPS_CACHE[id(t)] = (t, ops, op[p], op[p + 1])          # (the ops are sliced by whoever asks: ops_of)
+    _OPS_CACHE.set(out, ops, ops_ptr)          # (indexed and sliced by whoever asks: ops_of)
     return out
 
 
@@ -129,7 +151,7 @@ def ops_of(result_tuple):
     c = _OPS_CACHE.get(id(result_tuple))
     if c is None or c[0] is not result_tuple:
         return None
-    return c[1][c[2]:c[3]]
+    return c[1][int(c[2]):int(c[3])]
 
 
 def parasail_alignment(s1, s2, i, j, x_acc="", y_acc="", match_score=2, mismatch_penalty=-3, opening_penalty=2, gap_ext=0):
