@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("ISOCON_LIB", os.path.join(_HERE, "lib", "libisocon_hip.so"))   # override: kernel experiments
@@ -108,33 +109,53 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return SO_PATH
 
 
-PYHELP_SO = os.path.join(_HERE, "_pyhelp.so")
+def _pyhelp_so():
+    # named for THIS interpreter's ABI (sysconfig EXT_SUFFIX): a helper built for another Python is never picked up by mistake
+    import sysconfig
+    return os.path.join(_HERE, "_pyhelp" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
-def build_pyhelp(verbose: bool = False):
-    """The CPython helper of the wrappers (cpy/_pyhelp.c: string lists <-> flat buffers); optional -- pure-Python loops otherwise."""
+PYHELP_SO = _pyhelp_so()
+_pyhelp_warned = False
+
+
+def _warn_pyhelp(why):
+    global _pyhelp_warned
+    if not _pyhelp_warned:
+        _pyhelp_warned = True
+        sys.stderr.write("[isocon_amd] CPython helper unavailable (%s): the wrappers use their pure-Python loops\n" % why)
+
+
+def build_pyhelp(verbose: bool = False, extra_flags=(), out=None):
+    """The CPython helper of the wrappers (cpy/_pyhelp.c: string lists <-> flat buffers); optional -- pure-Python loops otherwise
+    (one line on stderr says so).  extra_flags / out: the sanitizer build of tests/test_pyhelp.py."""
     import sysconfig
     src = os.path.join(_HERE, "cpy", "_pyhelp.c")
+    out = out or PYHELP_SO
     if not os.path.exists(src):
         return None
-    if os.path.exists(PYHELP_SO) and os.path.getmtime(PYHELP_SO) >= os.path.getmtime(src):
-        return PYHELP_SO
-    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-pthread", "-I" + sysconfig.get_paths()["include"], "-o", PYHELP_SO, src]
+    if not extra_flags and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-pthread", "-Wall", "-I" + sysconfig.get_paths()["include"]] + list(extra_flags) + ["-o", out, src]
     if verbose:
         print(" ".join(cmd))
     try:
         subprocess.check_call(cmd)
-    except Exception:
+    except Exception as e:          # (a read-only install, no compiler)
+        _warn_pyhelp("build failed: %s" % e)
         return None
-    return PYHELP_SO
+    return out
 
 
 def pyhelp():
-    """the helper module, or None"""
+    """the helper module, or None (ISOCON_NO_PYHELP=1 forces None: the tests run the wrappers both ways)"""
+    if os.environ.get("ISOCON_NO_PYHELP", "") not in ("", "0"):
+        return None
     try:
         from . import _pyhelp
         return _pyhelp
-    except Exception:
+    except Exception as e:
+        _warn_pyhelp("import failed: %s" % e)
         return None
 
 

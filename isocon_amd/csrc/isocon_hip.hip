@@ -18,6 +18,7 @@
 #include "nn.hpp"
 #include "nn_list.hpp"
 #include "nn_finalize.hpp"
+#include "nn_finalize_host.hpp"
 #include "sg.hpp"
 #include "msa.hpp"
 #include "hw.hpp"
@@ -30,11 +31,27 @@ thread_local std::string g_last_error;
 
 using namespace isocon;
 
+// What the pool's nearest-neighbour slots currently hold, next to the slots themselves (no free-floating state: a store reaches it
+// through its pool, and whoever overwrites or releases a slot invalidates the tag in the same place).
+// BoundTag: the q-gram bound matrix of the last seed phase (slots SLOT_NN_LB / SLOT_NN_LBROW): the main phase of the SAME store and
+// shard that follows uses it instead of computing it again.  Identified by the store's serial number (not its address).
+struct BoundTag {
+    bool valid = false, has_order = false;
+    uint64_t serial = 0;
+    uint32_t q_begin = 0, q_end = 0, q_stride = 0, depth = 0;
+    int32_t kcap = 0;
+    unsigned long long lb_total = 0;
+};
+// HeldHits: candidate edges of a sharded search that stay in device memory from phase to phase (SLOT_NN_ACC_HITS), tagged with their store.
+struct HeldHits { uint64_t store_serial = 0; uint64_t rows = 0; };
+
 // Grow-only device scratch owned by the store: repeated calls reuse their buffers instead of paying
 // hipMalloc/hipFree (tens of ms for the multi-GB trace scratch) every time.
 struct ScratchPool {
     struct Slot { void *p = nullptr; size_t cap = 0; };
     Slot slots[112];
+    BoundTag bound_tag;
+    HeldHits held_hits;
     void *get(int idx, size_t bytes)
     {
         Slot &s = slots[idx];
@@ -52,6 +69,8 @@ struct ScratchPool {
     void release()
     {
         for (Slot &s : slots) { if (s.p) (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+        bound_tag = BoundTag();
+        held_hits = HeldHits();
     }
 };
 
@@ -69,18 +88,6 @@ static_assert(SLOT_COUNT <= 112, "ScratchPool::slots too small");
 // One pool per process (one process drives one GPU): scratch outlives the individual stores, because the Python
 // wrappers create a fresh store per call (the reference's functions are stateless).
 static ScratchPool g_scratch;
-
-// The q-gram bound matrix of the last isocon_nn_partial seed phase (slots SLOT_NN_LB / SLOT_NN_LBROW of the scratch pool): the main
-// phase of the SAME store and shard that follows uses it instead of computing it again.  Identified by the store's serial number (not
-// its address), overwritten by every build, dropped with the scratch.
-struct BoundTag {
-    bool valid = false, has_order = false;
-    uint64_t serial = 0;
-    uint32_t q_begin = 0, q_end = 0, q_stride = 0, depth = 0;
-    int32_t kcap = 0;
-    unsigned long long lb_total = 0;
-};
-static BoundTag g_bound_tag;
 
 static uint64_t g_store_serial = 0;
 
@@ -264,7 +271,7 @@ int isocon_device_count(void)
     return n;
 }
 
-void isocon_release_scratch(void) { g_scratch.release(); g_stage.release(); g_bound_tag.valid = false; }
+void isocon_release_scratch(void) { g_scratch.release(); g_stage.release(); }
 
 int isocon_init(int device_ordinal)
 {
@@ -714,7 +721,7 @@ extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, cons
     if ((rc = d_prof.alloc((size_t)n_pad * (QM_K / 2))) || (rc = d_sum.alloc((size_t)n * 4)) || (rc = d_a.alloc(n_pairs * 4)) || (rc = d_b.alloc(n_pairs * 4)) ||
         (rc = d_out.alloc(n_pairs * 4)))
         return rc;
-    g_bound_tag.valid = false;          // the profile slot is shared with the bound matrix builds
+    s->pool.bound_tag.valid = false;          // the profile slot is shared with the bound matrix builds
     ISO_HIP_CHECK(copy_h2d(d_a.p, a, n_pairs * 4));
     ISO_HIP_CHECK(copy_h2d(d_b.p, b, n_pairs * 4));
     hipLaunchKernelGGL(k_qgram_profile4, dim3(n), dim3(256), 0, 0, s->dev, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad);

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -259,19 +260,21 @@ _HOST_BUFFERS = {}
 
 def _host_buffer(name, nbytes, L):
     """A grow-only uint8 buffer in pinned host memory (isocon_host_alloc) that the NEXT call of the same wrapper overwrites;
-    ordinary memory if pinning fails."""
+    ordinary memory if pinning fails.  A block that is outgrown is NOT freed here: views handed out earlier (the result rows of
+    hw_pairs(reuse_buffer=True), the gapped strings of sg_strings) may still be alive, so the block is released by a finalizer
+    once the last of them is gone."""
     cur = _HOST_BUFFERS.get(name)
-    if cur is not None and cur[1] >= nbytes:
-        return cur[2][:nbytes]
-    if cur is not None and cur[0]:
-        L.isocon_host_free(cur[0])
-    cap = int(nbytes + nbytes // 8 + 4096)
+    if cur is not None and cur[0] >= nbytes:
+        return cur[1][:nbytes]
+    cap = int(nbytes + nbytes // 2 + 4096)
     addr = L.isocon_host_alloc(cap)
     if addr:
-        arr = np.frombuffer((ctypes.c_uint8 * cap).from_address(addr), dtype=np.uint8)
+        block = (ctypes.c_uint8 * cap).from_address(addr)
+        weakref.finalize(block, L.isocon_host_free, addr)          # runs when every numpy view / memoryview of the block is gone
+        arr = np.frombuffer(block, dtype=np.uint8)
     else:
-        addr, arr = 0, np.empty(cap, dtype=np.uint8)
-    _HOST_BUFFERS[name] = (addr, cap, arr)
+        arr = np.empty(cap, dtype=np.uint8)
+    _HOST_BUFFERS[name] = (cap, arr)
     return arr[:nbytes]
 
 

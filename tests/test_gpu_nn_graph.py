@@ -399,3 +399,54 @@ def test_device_resident_entry_points_argument_checks_and_long_rows():
             st.nn_finalize_dev(b_d.data_ptr(), 0, 5)                   # rows announced, no buffer
     finally:
         st.close()
+
+
+def test_few_close_pairs_plus_far_reads_keep_both_kinds_of_edge():
+    """n >= 1024, the 64-row pass finds fewer than 4096 edges (they stay on the device, in the list the wide-band stages
+    write to from its start again), and some reads only have neighbours 64..600 edits away: the edges of BOTH passes must
+    reach the graph (NNG:155-178 for every row) -- compared with the host-finalize variant and with the oracle loop."""
+    import os
+    import random
+    from isocon_amd import synth
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    rng = random.Random(91)
+    nrng = np.random.Generator(np.random.PCG64(92))
+    seqs = set()
+    for f in range(520):          # twins 1-3 substitutions apart, every family at its own length
+        L = 100 + 2 * f
+        root = "".join(rng.choice("ACGT") for _ in range(L))
+        twin = list(root)
+        for _ in range(rng.randrange(1, 4)):
+            i = rng.randrange(L)
+            twin[i] = rng.choice("ACGT".replace(root[i], ""))
+        seqs.add(root)
+        seqs.add("".join(twin))
+    far_base = "".join(rng.choice("ACGT") for _ in range(1900))
+    for rate in (0.05, 0.09, 0.15):          # neighbours at ~ 90 / 170 / 280 edits: 128- to 512-row bands
+        prof = dict(rate=rate, ins=0.4, dele=0.3, sub=0.3)
+        for _ in range(3):
+            seqs.add(synth.mutate(nrng, np.frombuffer(far_base.encode(), np.uint8), prof).tobytes().decode())
+    for j in range(3):                       # unrelated reads of the same length: beyond 511
+        seqs.add("".join(rng.choice("ACGT") for _ in range(1895 + 3 * j)))
+    seqs = sorted(seqs, key=len)
+    assert len(seqs) >= 1024
+    st = SeqStore(seqs)
+    try:
+        dev = st.nn_graph()
+        os.environ["ISOCON_NN_HOST_FINALIZE"] = "1"
+        try:
+            host = st.nn_graph()
+        finally:
+            del os.environ["ISOCON_NN_HOST_FINALIZE"]
+    finally:
+        st.close()
+    assert dev[3]["fallback_queries"] > 0
+    assert all((x == y).all() for x, y in zip(dev[:3], host[:3]))
+    best, row_ptr, cols = dev[:3]
+    assert (np.diff(row_ptr)[best >= 0] > 0).all()          # a row with a bound has its edges
+    S = {"r%d" % i: s for i, s in enumerate(seqs)}
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+    accs = list(S)
+    got = {accs[i]: {accs[int(c)]: int(best[i]) for c in cols[row_ptr[i]:row_ptr[i + 1]]} for i in range(len(accs))}
+    assert ordered(got) == ordered(g_cpu)

@@ -1,0 +1,168 @@
+"""The CPython helper of the wrappers (isocon_amd/cpy/_pyhelp.c: raw addresses from Python ints, CPython objects, pthreads) against
+pure-Python equivalents -- no GPU needed.  The same checks run a second time in a child interpreter against a build with
+-fsanitize=address,undefined (libasan preloaded), the way the wave emulators are built with -fsanitize=undefined."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _helper():
+    sys.path.insert(0, ROOT)
+    if os.environ.get("ISOCON_PYHELP_UNDER_TEST"):          # the sanitizer child: import the instrumented build by path
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_pyhelp", os.environ["ISOCON_PYHELP_UNDER_TEST"])
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    from isocon_amd import _lib
+    assert _lib.build_pyhelp() is not None
+    H = _lib.pyhelp()
+    assert H is not None
+    return H
+
+
+def check_str_pointers(H):
+    import ctypes
+    for seqs in ([], [""], ["ACGT", "", "A" * 5000, "TTGACA"], ["ACGT"[i % 4] * (i % 17) for i in range(3000)]):
+        ptrs = np.zeros(max(len(seqs), 1), dtype=np.uint64)
+        lens = np.full(max(len(seqs), 1), 99, dtype=np.uint64)
+        total = H.str_pointers(seqs, ptrs.ctypes.data, lens.ctypes.data)
+        assert total == sum(len(s) for s in seqs)
+        for i, s in enumerate(seqs):
+            assert int(lens[i]) == len(s)
+            assert ctypes.string_at(int(ptrs[i]), len(s)) == s.encode()
+    ptrs = np.zeros(4, dtype=np.uint64)
+    lens = np.zeros(4, dtype=np.uint64)
+    with pytest.raises(ValueError):          # non-ASCII: what the store reports as a symbol outside ACGT
+        H.str_pointers(["ACGT", "ACéT"], ptrs.ctypes.data, lens.ctypes.data)
+    with pytest.raises(TypeError):
+        H.str_pointers(["ACGT", b"ACGT"], ptrs.ctypes.data, lens.ctypes.data)
+    with pytest.raises(TypeError):
+        H.str_pointers(("ACGT",), ptrs.ctypes.data, lens.ctypes.data)
+
+
+def check_split_ascii(H):
+    rng = np.random.Generator(np.random.PCG64(5))
+    for n, mean in ((0, 0), (1, 0), (7, 30), (4000, 100), (3000, 3200)):          # the last one is > 8 MB: the threaded copy
+        lens = rng.integers(0, 2 * mean + 1, size=n)
+        if n > 2:
+            lens[1] = 0          # zero-length strings inside
+            lens[-1] = 0
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=ptr[1:])
+        buf = rng.integers(0, 4, size=int(ptr[n]) + 1).astype(np.uint8)
+        buf = np.frombuffer(b"ACG-", dtype=np.uint8)[buf].copy()
+        out = H.split_ascii(buf.ctypes.data, ptr.ctypes.data, n)
+        raw = buf.tobytes()
+        assert out == [raw[ptr[i]:ptr[i + 1]].decode() for i in range(n)]
+        if n > 2000 and mean > 3000:
+            assert int(ptr[n]) >= 8 << 20
+    # a window that does not start at 0
+    buf = np.frombuffer(b"xxACGTTTGA", dtype=np.uint8).copy()
+    ptr = np.array([2, 6, 6, 10], dtype=np.int64)
+    assert H.split_ascii(buf.ctypes.data, ptr.ctypes.data, 3) == ["ACGT", "", "TTGA"]
+    with pytest.raises(ValueError):
+        H.split_ascii(buf.ctypes.data, np.array([4, 2], dtype=np.int64).ctypes.data, 1)
+
+
+def check_csr_to_dict(H):
+    keys = ["k%d" % i for i in range(6)]
+    best = np.array([3, -1, 2, 2, 7, -1], dtype=np.int32)
+    row_ptr = np.array([0, 2, 2, 3, 5, 6, 6], dtype=np.int64)
+    cols = np.array([2, 1, 0, 5, 4, 0], dtype=np.uint32)
+
+    def plain(isq):
+        return {keys[i]: {keys[int(c)]: int(best[i]) for c in cols[row_ptr[i]:row_ptr[i + 1]]} for i in range(6) if isq is None or isq[i]}
+
+    got = H.csr_to_dict(keys, 0, best.ctypes.data, row_ptr.ctypes.data, cols.ctypes.data, 6)
+    assert [(k, list(v.items())) for k, v in got.items()] == [(k, list(v.items())) for k, v in plain(None).items()]
+    isq = np.array([1, 0, 1, 1, 0, 1], dtype=np.uint8)
+    got = H.csr_to_dict(keys, isq.ctypes.data, best.ctypes.data, row_ptr.ctypes.data, cols.ctypes.data, 6)
+    assert [(k, list(v.items())) for k, v in got.items()] == [(k, list(v.items())) for k, v in plain(isq).items()]
+    assert H.csr_to_dict([], 0, best.ctypes.data, np.zeros(1, dtype=np.int64).ctypes.data, 0, 0) == {}
+    bad = cols.copy()
+    bad[3] = 6          # a column outside the key list
+    with pytest.raises(ValueError):
+        H.csr_to_dict(keys, 0, best.ctypes.data, row_ptr.ctypes.data, bad.ctypes.data, 6)
+    with pytest.raises(TypeError):
+        H.csr_to_dict(keys[:3], 0, best.ctypes.data, row_ptr.ctypes.data, cols.ctypes.data, 6)
+    # a large one against the loop
+    rng = np.random.Generator(np.random.PCG64(6))
+    n = 5000
+    deg = rng.integers(0, 4, size=n)
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    c = rng.integers(0, n, size=int(rp[n])).astype(np.uint32)
+    b = rng.integers(1, 60, size=n).astype(np.int32)
+    ks = ["acc_%d" % i for i in range(n)]
+    got = H.csr_to_dict(ks, 0, b.ctypes.data, rp.ctypes.data, c.ctypes.data, n)
+    want = {ks[i]: {ks[int(x)]: int(b[i]) for x in c[rp[i]:rp[i + 1]]} for i in range(n)}
+    assert list(got) == list(want) and all(list(got[k].items()) == list(want[k].items()) for k in want)
+
+
+def check_pair_ids(H):
+    index = {"s%d" % i: i for i in range(100)}
+    pairs = [("s%d" % (i % 100), "s%d" % ((7 * i) % 100)) for i in range(1000)]
+    a = np.zeros(1000, dtype=np.uint32)
+    b = np.zeros(1000, dtype=np.uint32)
+    assert H.pair_ids(index, pairs, a.ctypes.data, b.ctypes.data) == 1000
+    assert a.tolist() == [index[x] for x, _ in pairs] and b.tolist() == [index[y] for _, y in pairs]
+    assert H.pair_ids(index, [], a.ctypes.data, b.ctypes.data) == 0
+    assert H.pair_ids(index, pairs[:5] + [("s1", "nope")], a.ctypes.data, b.ctypes.data) == -1 - 5
+    assert H.pair_ids(index, [("nope", "s1")], a.ctypes.data, b.ctypes.data) == -1
+    with pytest.raises(TypeError):
+        H.pair_ids(index, [("s1",)], a.ctypes.data, b.ctypes.data)
+    with pytest.raises(TypeError):
+        H.pair_ids(index, [(["unhashable"], "s1")], a.ctypes.data, b.ctypes.data)
+    with pytest.raises(TypeError):
+        H.pair_ids(list(index), pairs, a.ctypes.data, b.ctypes.data)
+
+
+def test_str_pointers():
+    check_str_pointers(_helper())
+
+
+def test_split_ascii():
+    check_split_ascii(_helper())
+
+
+def test_csr_to_dict():
+    check_csr_to_dict(_helper())
+
+
+def test_pair_ids():
+    check_pair_ids(_helper())
+
+
+def test_forced_off_and_abi_named():
+    sys.path.insert(0, ROOT)
+    import sysconfig
+    from isocon_amd import _lib
+    assert _lib.PYHELP_SO.endswith(sysconfig.get_config_var("EXT_SUFFIX"))
+    os.environ["ISOCON_NO_PYHELP"] = "1"
+    try:
+        assert _lib.pyhelp() is None
+    finally:
+        del os.environ["ISOCON_NO_PYHELP"]
+    assert _lib.pyhelp() is not None
+
+
+def test_under_address_and_undefined_sanitizers(tmp_path):
+    sys.path.insert(0, ROOT)
+    from isocon_amd import _lib
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan with this gcc")
+    so = str(tmp_path / "_pyhelp.so")
+    assert _lib.build_pyhelp(extra_flags=("-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"), out=so) == so
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
+               ISOCON_PYHELP_UNDER_TEST=so)
+    code = ("import sys; sys.path.insert(0, %r); import test_pyhelp as T; H = T._helper(); "
+            "T.check_str_pointers(H); T.check_split_ascii(H); T.check_csr_to_dict(H); T.check_pair_ids(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
