@@ -28,7 +28,9 @@ Extra objects on the JSON line:
                 fp4 MFMA): multiply-adds / s against the dense fp4 peak.  `algorithmic` = SURVEY 8(d)'s byte model, for
                 reference only (it charges bytes the kernels never move through HBM).
   cpu_baseline  the reference's loop on this host's cores: real edlib if the wheel imports ("edlib"), else the C
-                restatement under a Pool ("port").  Reported, not the target.
+                restatement under a Pool ("port").  Reported, not the target.  `ed_pairs` / `sw_pairs`: the pair-list half of the
+                metric -- the reference's Pool pattern of edlib_align_sequences / sw_align_sequences on a sample of the partition
+                pairs the wrappers below were timed on.
   wrappers      wall time of the PUBLIC functions end to end (string handling, H2D, kernels, D2H, dict rebuild).
 """
 from __future__ import annotations
@@ -52,6 +54,10 @@ HALF_RATE_COST = 1.72             # issue cost of a half-rate vector instruction
 STREAM_RATE_OF_NOMINAL = 2.0 / 2.43   # a pure stream of independent v_and_b32, 6 waves per SIMD, every CU busy: 2.43 cycles per instruction
                                       # at the nominal 2.4 GHz (clock under load + issue overhead): what "all issue slots used" measures as
 MFMA_FP4_PEAK_MACS = 5.0e15                 # ~10 PFLOP/s dense FP4 (same guide, chip-level parameters) = 5e15 multiply-adds / s
+# digest of the C3 graph every row of which was recomputed with the reference loop on the CPU (tests/golden/g17_c3_graph.npz, written by
+# tests/golden/make_golden_g17.py; tests/test_oracle_golden.py checks that this constant is that fixture's digest): a step that
+# produces another graph is not a measurement
+EXPECTED_GRAPH_DIGEST_C3 = "65944c838d76a6c9"
 COUNTERS = os.path.join(ROOT, "profiles", "counters.json")   # written by scripts/summarize_profile.py from rocprofv3 --pmc passes
 
 
@@ -154,9 +160,10 @@ def _cpu_chunk_edlib(start):
     return int(start), out, calls
 
 
-def cpu_baseline(seqs, lens, budget_s=15.0):
+def cpu_baseline(seqs, lens, budget_s=15.0, keep_pool=False):
     """Times get_nearest_neighbors (NNG:110-198) on random chunks of CHUNK consecutive queries against the full set,
-    Pool(processes=usable cores) as the reference does with nr_cores (NNG:30)."""
+    Pool(processes=usable cores) as the reference does with nr_cores (NNG:30).  keep_pool: the workers -- forked here, before this
+    process touches the GPU -- stay for the pair-list legs (cpu_pair_legs), returned under "_pool"."""
     from multiprocessing import Pool
     cores = usable_cores()
     n = len(seqs)
@@ -172,7 +179,8 @@ def cpu_baseline(seqs, lens, budget_s=15.0):
         kind, fn, what = "port", _cpu_chunk_port, "oracle/isocon_oracle.c orc_nn_1set (C restatement of the edlib-based loop; the edlib wheel does not import here)"
     starts = (np.random.Generator(np.random.PCG64(7)).permutation(max(n // CHUNK, 1)) * CHUNK).tolist()
     done = []
-    with Pool(processes=cores) as pool:    # fork: the sequence list is inherited, not pickled per task
+    pool = Pool(processes=cores)           # fork: the sequence list is inherited, not pickled per task
+    try:
         pos = 0
         t0 = time.perf_counter()
         while pos < len(starts):
@@ -182,6 +190,10 @@ def cpu_baseline(seqs, lens, budget_s=15.0):
             if time.perf_counter() - t0 > budget_s:
                 break
         dt = time.perf_counter() - t0
+    finally:
+        if not keep_pool:
+            pool.close()
+            pool.join()
     idx = np.concatenate([np.arange(s, s + len(b)) for s, b, _ in done])
     best = np.concatenate([np.asarray(b, dtype=np.int64) for _, b, _ in done])
     calls = int(sum(d[2] for d in done))
@@ -189,10 +201,73 @@ def cpu_baseline(seqs, lens, budget_s=15.0):
     lo = np.searchsorted(lens, lens[idx] - np.where(has, best, 0), "left")
     hi = np.searchsorted(lens, lens[idx] + np.where(has, best, 0), "right")
     pairs = int(((hi - lo - 1) * has).sum())
-    return {"value": pairs / dt, "unit": "alignments/s", "cores": cores, "kind": kind,
-            "sample": "%d of %d queries (%d random chunks of %d consecutive queries, seed 7) against the full %d-sequence set, %.1f s wall, "
-                      "%d edlib-style calls (%.0f calls/s); %s; multiprocessing.Pool(%d)"
-                      % (len(idx), n, len(done), CHUNK, n, dt, calls, calls / dt, what, cores)}
+    out = {"value": pairs / dt, "unit": "alignments/s", "cores": cores, "kind": kind,
+           "sample": "%d of %d queries (%d random chunks of %d consecutive queries, seed 7) against the full %d-sequence set, %.1f s wall, "
+                     "%d edlib-style calls (%.0f calls/s); %s; multiprocessing.Pool(%d)"
+                     % (len(idx), n, len(done), CHUNK, n, dt, calls, calls / dt, what, cores)}
+    if keep_pool:
+        out["_pool"] = pool
+    return out
+
+
+def _cpu_ed_task(task):
+    """one pair of edlib_align_sequences' Pool (EAM:32: the task carries both sequences, the result carries them back)"""
+    (s1, s2, i, j), kw = task
+    try:
+        import edlib
+        return s1, s2, edlib.align(s1, s2, "NW")["editDistance"]          # EAM:111
+    except ImportError:
+        from oracle import oracle as O
+        return O._eam_task(task)
+
+
+def _cpu_sw_task(task):
+    """one pair of sw_align_sequences' Pool (SWM:144): parasail_alignment = full-matrix semi-global DP + traceback + cigar_to_seq +
+    the two column scans (SWM:64-86)"""
+    from oracle import oracle as O
+    return O._swm_task(task)
+
+
+def cpu_pair_legs(pool, cores, pair_ed, budget_s=10.0):
+    """The pair-list half of the metric on this host's cores: the reference's Pool pattern of edlib_align_sequences (EAM:25-47) and
+    sw_align_sequences (SWM:121-162) -- pool.map_async over one task per pair, each task pickling its two sequences in and the
+    results (for SW: two gapped strings more) out -- on a sample of the SAME partition pairs the GPU wrappers were timed on.
+    pair_ed: [(centre, member, edit distance)].  The arithmetic is real edlib if the wheel imports, else the oracle's C restatement;
+    parasail does not import here (profiles/r02_probe_real_libs.json): the SW leg is the restatement (`kind: "port"`)."""
+    from oracle import oracle as O
+    try:
+        import edlib  # noqa: F401
+        ed_kind = "reference"
+    except ImportError:
+        ed_kind = "port"
+    out = {}
+    # edit distances: fast per pair -> a large sample
+    n_ed = min(len(pair_ed), 8192)
+    tasks = [((s1, s2, i, 0), {}) for i, (s1, s2, _) in enumerate(pair_ed[:n_ed])]
+    t0 = time.perf_counter()
+    res = pool.map_async(_cpu_ed_task, tasks).get(999999999)
+    dt = time.perf_counter() - t0
+    assert all(r[2] == p[2] for r, p in zip(res, pair_ed[:n_ed])), "CPU edit distances differ from the GPU's"
+    out["ed_pairs"] = {"value": n_ed / dt, "unit": "pairs/s", "cores": cores, "kind": ed_kind,
+                       "sample": "%d of %d partition pairs (the first, in dict order), unbounded global edit distance, Pool(%d).map_async with one task "
+                                 "per pair as EAM:25-47, %.2f s wall; distances equal to the GPU's" % (n_ed, len(pair_ed), cores, dt)}
+    # alignments with traceback: ~6 M cells per pair -> doubled batches until the budget is used
+    done = 0
+    t_sw = 0.0
+    batch = max(4 * cores, 64)
+    while done < len(pair_ed) and t_sw < budget_s:
+        part = pair_ed[done:done + batch]
+        tasks = [((s1, s2, i, 0), {"mismatch_penalty": O.mismatch_penalty_for(ed, len(s1), len(s2))}) for i, (s1, s2, ed) in enumerate(part)]
+        t0 = time.perf_counter()
+        res = pool.map_async(_cpu_sw_task, tasks).get(999999999)
+        t_sw += time.perf_counter() - t0
+        done += len(part)
+        batch *= 2
+    out["sw_pairs"] = {"value": done / t_sw, "unit": "pairs/s", "cores": cores, "kind": "port",
+                       "sample": "%d of %d partition pairs (the first, in dict order), full-matrix semi-global alignment + traceback + gapped strings + counts "
+                                 "(oracle orc_sg_trace, tie policy 0), Pool(%d).map_async with one task per pair as SWM:121-162, %.2f s wall"
+                                 % (done, len(pair_ed), cores, t_sw)}
+    return out
 
 
 def self_launch(args):
@@ -272,8 +347,10 @@ def main():
 
     # CPU baseline first: its fork()ed workers must exist (and be gone) before this process touches the GPU
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(seqs, lens, budget_s=args.cpu_budget)
+    cpu_pool = None
+    if rank == 0 and not args.no_cpu_baseline:          # (rank 0 of any world size; the others wait at the first barrier)
+        cpu = cpu_baseline(seqs, lens, budget_s=args.cpu_budget, keep_pool=world == 1 and not args.no_extras)
+        cpu_pool = cpu.pop("_pool", None)
 
     import torch
     n_dev = max(torch.cuda.device_count(), 1)
@@ -427,27 +504,54 @@ def main():
             result["other_kernels"] = other_kernels(store, seqs, lens, last, true_isoforms, ctr if is_default else {})
         except Exception as e:  # the headline line must still be printed
             result["other_kernels"] = {"error": repr(e)}
+        pair_ed = []
         try:
-            result["wrappers"] = wrappers(accs, seqs_all)
+            result["wrappers"] = wrappers(accs, seqs_all, pair_ed)
         except Exception as e:
             result["wrappers"] = {"error": repr(e)}
+        if cpu_pool is not None and pair_ed:
+            try:
+                cpu.update(cpu_pair_legs(cpu_pool, cpu["cores"], pair_ed))
+                w = result["wrappers"]
+                w["edlib_align_sequences_vs_cpu_baseline"] = w["edlib_align_sequences_pairs_per_s"] / cpu["ed_pairs"]["value"]
+                w["sw_align_sequences_vs_cpu_baseline"] = w["sw_align_sequences_pairs_per_s"] / cpu["sw_pairs"]["value"]
+            except Exception as e:
+                cpu["pair_legs_error"] = repr(e)
+    if cpu_pool is not None:
+        cpu_pool.close()
+        cpu_pool.join()
     if cpu is not None:
         result["cpu_baseline"] = cpu
         result["speedup_vs_cpu_baseline"] = value / cpu["value"] if cpu["value"] else None
+    if is_default:
+        result["config"]["graph_digest_expected"] = EXPECTED_GRAPH_DIGEST_C3
+        result["config"]["graph_equals_reference_loop_fixture"] = result["config"]["graph_digest"] == EXPECTED_GRAPH_DIGEST_C3
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+    if is_default and result["config"]["graph_digest"] != EXPECTED_GRAPH_DIGEST_C3:
+        raise SystemExit("bench.py: the graph of the default workload has digest %s, the reference-loop fixture %s: the result is WRONG, the line above is not a measurement"
+                         % (result["config"]["graph_digest"], EXPECTED_GRAPH_DIGEST_C3))
 
 
-def _fracs(ctr, key, ms):
-    """VALU-issue and HBM fractions of one profiled dispatch class at this run's live kernel time."""
+def _fracs(ctr, key, ms, own_time=False):
+    """VALU-issue and HBM fractions of one profiled dispatch class.  own_time False: the class is (practically) the whole call, the
+    denominators are this run's live kernel time.  own_time True: the class is ONE kernel of a call that runs several (k_sg_band of
+    band + walk + compact + expand): its counters are divided by ITS OWN duration in the profiled run (`kernel_ms_profiled`), not by
+    the call's kernel time."""
     c = ctr.get(key, {})
     out = {}
-    if c.get("SQ_INSTS_VALU") and ms and ms > 0:
-        out["valu_frac"] = float(c["SQ_INSTS_VALU"]) / (ms / 1e3) / VALU_PEAK_WAVE_INSTR
-    if c.get("hbm_bytes") and ms and ms > 0:
-        out["hbm_frac"] = float(c["hbm_bytes"]) / (ms / 1e3) / 1e9 / HBM_PEAK_GBS
+    t_valu = t_hbm = ms
+    if own_time:
+        t_valu = c["dur_ns_sq_pass"] / 1e6 if c.get("dur_ns_sq_pass") else None
+        t_hbm = c["dur_ns_fetch_pass"] / 1e6 if c.get("dur_ns_fetch_pass") else t_valu
+        if t_valu:
+            out["kernel_ms_profiled"] = t_valu
+    if c.get("SQ_INSTS_VALU") and t_valu and t_valu > 0:
+        out["valu_frac"] = float(c["SQ_INSTS_VALU"]) / (t_valu / 1e3) / VALU_PEAK_WAVE_INSTR
+    if c.get("hbm_bytes") and t_hbm and t_hbm > 0:
+        out["hbm_frac"] = float(c["hbm_bytes"]) / (t_hbm / 1e3) / 1e9 / HBM_PEAK_GBS
         out["hbm_bytes"] = float(c["hbm_bytes"])
     return out
 
@@ -516,8 +620,10 @@ def other_kernels(store, seqs, lens, last, true_isoforms, ctr):
         "sw_banded_pairs_per_s_kernel": len(q) / (swb_ms / 1e3) if swb_ms > 0 else None, "sw_banded_wall_ms": swb_wall * 1e3,
         "sw_banded_equals_full": same,
         # VALU-issue / HBM fractions of the profiled dispatches of THIS batch (profiles/counters.json), at the live kernel times
-        "sw_full": dict(kernel="k_sg_forward (4096 pairs, full matrix)", kernel_ms=sw_ms, **_fracs(ctr, "sg_full", sw_ms)),
-        "sw_banded": dict(kernel="k_sg_band (4096 pairs, edit-distance band hints: the band's diagonals on the lanes)", kernel_ms=swb_ms, **_fracs(ctr, "sg_banded", swb_ms)),
+        # (call_kernel_ms = all kernels of the call: forward / band + walk + compact + expand; the fractions belong to the named kernel alone)
+        "sw_full": dict(kernel="k_sg_forward (4096 pairs, full matrix)", call_kernel_ms=sw_ms, **_fracs(ctr, "sg_full", sw_ms, own_time=True)),
+        "sw_banded": dict(kernel="k_sg_band (4096 pairs, edit-distance band hints: the band's diagonals on the lanes)", call_kernel_ms=swb_ms,
+                          **_fracs(ctr, "sg_banded", swb_ms, own_time=True)),
         "hw_k25": dict(kernel="infix kernel, 4096 pairs, k = 25", kernel_ms=hw25_ms, **_fracs(ctr, "hw_k25", hw25_ms)),
         "hw_k63": dict(kernel="infix kernel, 4096 pairs, k = 63", kernel_ms=hw63_ms, **_fracs(ctr, "hw_k63", hw63_ms)),
         "hw_graph": dict(kernel="k_hw_locate + k_hw_finish, candidate-vs-candidate graph (%d candidates, k = 25)" % len(cseqs), pairs=int(len(gq)),
@@ -526,7 +632,7 @@ def other_kernels(store, seqs, lens, last, true_isoforms, ctr):
     return out
 
 
-def wrappers(accs, seqs_all):
+def wrappers(accs, seqs_all, pair_ed_out=None):
     """SURVEY 8(d) "Timers": perf_counter() around the PUBLIC functions (string handling, packing, H2D, kernels, D2H and the
     dict rebuild included) -- NNG:237-296, EAM:10-49, SWM:89-164 -- on the workload and on its partition pair list."""
     from isocon_amd import SW_alignment_module as SWM
@@ -553,6 +659,8 @@ def wrappers(accs, seqs_all):
     del sw
     t0 = time.perf_counter(); sw = SWM.sw_align_sequences(ed); t_sw = time.perf_counter() - t0
     n_sw = sum(len(v) for v in sw.values())
+    if pair_ed_out is not None:          # the pair list with its distances, for the CPU legs (cpu_pair_legs)
+        pair_ed_out.extend((s1, s2, d) for s1, row in ed.items() for s2, d in row.items())
     return {"compute_nearest_neighbor_graph_wall_ms": t_nn * 1e3, "compute_nearest_neighbor_graph_kernel_ms": kern, "nn_edges": n_edges,
             "partition_centres": len(partition), "partition_pairs": n_pairs,
             "edlib_align_sequences_wall_ms": t_ed * 1e3, "edlib_align_sequences_pairs_per_s": n_pairs / t_ed if t_ed > 0 else None,

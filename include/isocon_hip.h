@@ -89,13 +89,13 @@ int isocon_qgram_params(int32_t *out);
 int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound);
 
 /*
- * The bound matrix the main pass of isocon_nn_graph / isocon_nn_partial consults for the shard q_begin, q_begin + q_stride, ... < q_end
- * (length-sorted store), read back for tests: row r belongs to the entry q = q_begin + r * q_stride, its bytes
+ * The bound matrix the main pass of isocon_nn_graph / isocon_nn_partial consults for the shard (q_begin, q_end, q_stride, q_block) --
+ * see isocon_nn_partial -- of a length-sorted store, read back for tests: row r belongs to the shard's r-th entry q, its bytes
  * out_bounds[out_row_ptr[r] .. out_row_ptr[r + 1]) are min(255, bound) of the pairs (q, p), p = q + 1, q + 2, ... while
  * len(p) - len(q) <= 63 and p - q <= depth (the pairs the upward scan of modules/nearest_neighbor_graph.py:136-153 can reach within
  * 63 edits).  out_row_ptr has (number of rows + 1) entries.  ISOCON_E_CAPACITY + *n_bounds_needed when bounds_cap is too small.
  */
-int isocon_qgram_bound_matrix(isocon_store *s, uint32_t q_begin, uint32_t q_end, uint32_t q_stride, uint64_t depth,
+int isocon_qgram_bound_matrix(isocon_store *s, uint32_t q_begin, uint32_t q_end, uint32_t q_stride, uint32_t q_block, uint64_t depth,
                               uint64_t *out_row_ptr, uint8_t *out_bounds, uint64_t bounds_cap, uint64_t *n_bounds_needed);
 
 /* statistics block filled by the nearest-neighbour entry points (all counters are for the one call) */
@@ -140,8 +140,12 @@ int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t 
 
 /*
  * Sharded variant for one-process-per-GPU runs (the reference has no distributed path; its Pool chunking is
- * modules/nearest_neighbor_graph.py:33-35).  A rank OWNS the entries q_begin, q_begin + q_stride, ... < q_end (rank r of
- * N: q_begin = r, q_end = n, q_stride = N -- a cyclic split balances the very uneven windows automatically).
+ * modules/nearest_neighbor_graph.py:33-35).  A rank OWNS the entries x of the length-sorted order with q_begin <= x < q_end and
+ * (x - q_begin) mod q_stride < q_block (q_block a power of two, 1 <= q_block <= q_stride):
+ *     rank r of N, block-cyclic:  q_begin = 256 r, q_end = n, q_stride = 256 N, q_block = 256 -- blocks of 256 consecutive entries
+ *                                 (one tile row of the bound matrix) dealt round-robin: the very uneven windows balance by themselves
+ *                                 and a rank's tiles stay as dense as on one GPU (what isocon_amd/dist.py uses);
+ *     cyclic:                     q_begin = r, q_stride = N, q_block = 1;       contiguous: q_stride = q_block = 1.
  * best_inout[n] is IN/OUT (0x3fffffff = no neighbour known yet).
  *   phase 0: seed pass -- every owned entry against its 64 nearest longer neighbours (64-row band).  Pass best_inout all
  *            0x3fffffff.  (No-op for the 2-set graph.)
@@ -157,7 +161,7 @@ int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t 
  * min-reduces best over ranks after each phase, all-gathers the triples and calls isocon_nn_finalize.
  */
 int isocon_nn_partial(isocon_store *s, const uint8_t *is_converged, const uint8_t *is_target, uint64_t depth,
-                      uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t phase, int32_t *best_inout,
+                      uint32_t q_begin, uint32_t q_end, uint32_t q_stride, uint32_t q_block, int32_t phase, int32_t *best_inout,
                       int32_t *out_hits, uint64_t hits_cap, uint64_t *n_hits, isocon_nn_stats *stats);
 int isocon_nn_finalize(uint32_t n, const int32_t *best, const int32_t *hits, uint64_t n_hits,
                        int32_t *out_best, uint64_t *out_row_ptr, uint32_t *out_cols, uint64_t cols_cap,
@@ -176,7 +180,7 @@ int isocon_nn_finalize(uint32_t n, const int32_t *best, const int32_t *hits, uin
  *   isocon_nn_finalize_dev isocon_nn_finalize from device buffers (rows with a negative endpoint are skipped); n = size of the store.
  */
 int isocon_nn_partial_dev(isocon_store *s, const uint8_t *is_converged, const uint8_t *is_target, uint64_t depth,
-                          uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t phase, int32_t *best_inout_dev,
+                          uint32_t q_begin, uint32_t q_end, uint32_t q_stride, uint32_t q_block, int32_t phase, int32_t *best_inout_dev,
                           int32_t keep_hits, uint64_t *n_hits_held, isocon_nn_stats *stats);
 int isocon_nn_hits_dev(isocon_store *s, const int32_t *best_dev, int32_t *out_hits_dev, uint64_t cap_rows, uint64_t *n_kept);
 int isocon_nn_finalize_dev(isocon_store *s, const int32_t *best_dev, const int32_t *hits_dev, uint64_t n_rows,

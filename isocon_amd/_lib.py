@@ -57,17 +57,17 @@ SYMBOLS = {
     "isocon_ed_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, i32p, ctypes.c_uint64, i32p, f32p]),
     "isocon_qgram_params": (ctypes.c_int, [i32p]),
     "isocon_qgram_bound_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, i32p]),
-    "isocon_qgram_bound_matrix": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, u64p, u8p,
+    "isocon_qgram_bound_matrix": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, u64p, u8p,
                                                  ctypes.c_uint64, u64p]),
     "isocon_nn_graph": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, i32p, u64p, u32p, ctypes.c_uint64,
                                        u64p, ctypes.POINTER(NNStats)]),
     "isocon_nn_partial": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
-                                         ctypes.c_uint32, ctypes.c_int32, i32p, i32p, ctypes.c_uint64, u64p,
+                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, i32p, i32p, ctypes.c_uint64, u64p,
                                          ctypes.POINTER(NNStats)]),
     "isocon_nn_finalize": (ctypes.c_int, [ctypes.c_uint32, i32p, i32p, ctypes.c_uint64, i32p, u64p, u32p,
                                           ctypes.c_uint64, u64p]),
     "isocon_nn_partial_dev": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
-                                             ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, u64p, ctypes.POINTER(NNStats)]),
+                                             ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, u64p, ctypes.POINTER(NNStats)]),
     "isocon_nn_hits_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, u64p]),
     "isocon_nn_finalize_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, i32p, u64p, u32p,
                                               ctypes.c_uint64, u64p]),

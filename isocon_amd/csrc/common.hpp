@@ -22,6 +22,38 @@ struct DevStore {
     uint32_t nchunks;
 };
 
+// Which entries of the length-sorted order a shard owns as rows ("launch slots") of the search: the entries x in [begin, end) with
+// (x - begin) mod stride < block, numbered in ascending order -- slot s <-> entry begin + (s / block) * stride + s mod block.
+//   one GPU:       begin 0, stride 1, block 1                      (slot = entry)
+//   cyclic:        begin r, stride N, block 1                      (rank r of N: r, r + N, ...)
+//   block-cyclic:  begin r * B, stride N * B, block B = 256        (blocks of one tile row of the bound matrix dealt round-robin: a
+//                  rank's 256-slot tiles are as dense as on one GPU, and an entry's window is a run of consecutive slots)
+// block is a power of two (block_log2).  The map is monotone, so an interval of entries is an interval of slots.
+struct QMap {
+    uint32_t begin, end, stride, block_log2;
+    __host__ __device__ __forceinline__ uint32_t block() const { return 1u << block_log2; }
+    __host__ __device__ __forceinline__ uint64_t entry(uint32_t s) const
+    {
+        return (uint64_t)begin + (uint64_t)(s >> block_log2) * stride + (s & (block() - 1u));
+    }
+    // x owned: its slot in s
+    __host__ __device__ __forceinline__ bool slot_of(uint32_t x, uint32_t &s) const
+    {
+        if (x < begin || x >= end) return false;
+        const uint32_t d = x - begin, b = d / stride, r = d - b * stride;
+        s = (b << block_log2) + r;
+        return r < block();
+    }
+    __host__ __device__ __forceinline__ bool owns(uint32_t x) const { uint32_t s; return slot_of(x, s); }
+    __host__ __device__ __forceinline__ uint32_t count() const
+    {
+        if (end <= begin) return 0u;
+        const uint32_t span = end - begin, full = span / stride, rem = span - full * stride;
+        return (full << block_log2) + (rem < block() ? rem : block());
+    }
+    __host__ __device__ __forceinline__ bool same(const QMap &o) const { return begin == o.begin && end == o.end && stride == o.stride && block_log2 == o.block_log2; }
+};
+
 extern thread_local std::string g_last_error;
 
 #define ISO_HIP_CHECK(expr)                                                                    \

@@ -31,9 +31,9 @@ struct NNParams {
     uint32_t depth;                // largest admissible sorted-order offset (NNG:190)
     // k_nn_scan_refill, few queries ("sparse" launch): one workgroup per LISTED query, which takes its neighbours on BOTH
     // sides (a listed neighbour below it keeps the pair for its own workgroup); of those pairs a rank evaluates the ones
-    // whose lower index it owns (own_begin + i * own_stride).  q_list == nullptr: one workgroup per entry, upward scan.
+    // whose lower index it owns (own).  q_list == nullptr: one workgroup per entry, upward scan.
     const uint32_t *q_list;
-    uint32_t own_begin, own_stride;
+    QMap own;
     // q-gram lower bounds of the main pass' pairs (qgram.hpp; nullptr = none): lb[lb_row[launch slot] + (p - q - 1)]
     const uint8_t *lb;
     const unsigned long long *lb_row;
@@ -125,12 +125,13 @@ __device__ __forceinline__ void nn_flush_acc(const NNParams &P, const WaveAcc &a
 // W = 1: seed pass.  W = 2, 4, 8: the wide-band phase -- only entries flagged as (still unresolved) queries make a
 // pair active, every other tile is skipped after its role/threshold loads.
 template <int W>
-__global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint32_t q_begin, uint32_t q_end, uint32_t q_stride,
+__global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, QMap Q,
                                                      int32_t tile_begin, int32_t tile_end, int32_t wpq)
 {
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
-    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)((blockIdx.x * 4u + (uint32_t)wave) / (uint32_t)wpq) * q_stride;
+    const uint32_t q_end = Q.end;
+    const uint64_t q64 = Q.entry((blockIdx.x * 4u + (uint32_t)wave) / (uint32_t)wpq);
     const uint32_t q = q64 < (uint64_t)q_end ? (uint32_t)q64 : q_end;
     WaveAcc acc = {0, 0, 0, 0};
     if (q < q_end) {
@@ -151,13 +152,14 @@ __global__ __launch_bounds__(256) void k_nn_scan_up(DevStore S, NNParams P, uint
 // Same scan with the query's window table in LDS (see band_tile_run<1, true>): one workgroup of NWAVES waves per
 // entry q; dynamic LDS = 16 B x (maxlen + 192).  This is the main-pass kernel of the 1-set search.
 template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParams P, uint32_t q_begin, uint32_t q_end, uint32_t q_stride,
+__global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParams P, QMap Q,
                                                               int32_t tile_begin, int32_t tile_end)
 {
     extern __shared__ uint4 wtab[];
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
-    const uint64_t q64 = (uint64_t)q_begin + (uint64_t)blockIdx.x * q_stride;
+    const uint32_t q_end = Q.end;
+    const uint64_t q64 = Q.entry(blockIdx.x);
     const uint32_t q = q64 < (uint64_t)q_end ? (uint32_t)q64 : q_end;
     WaveAcc acc = {0, 0, 0, 0};
     if (q >= q_end) return;
@@ -276,7 +278,7 @@ __device__ __forceinline__ int32_t diag_value_w(const BandLane<W> &L, int32_t nv
 // narrow mode, nn_list.hpp): one table dword and 12 instead of 22 vector instructions per column.
 template <int NWAVES, int W, bool HALF = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNParams P, const uint32_t *__restrict__ text, uint32_t text_stride,
-                                                                      uint32_t q_begin, uint32_t q_end, uint32_t q_stride, int32_t tile_begin)
+                                                                      QMap Q, int32_t tile_begin)
 {
     static_assert(W >= 1 && W <= 8, "band widths: 64 .. 512 rows");
     static_assert(!HALF || W == 1, "the 32-row band is the narrow form of the 64-row kernel");
@@ -294,8 +296,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     unsigned long long l_begin = 0;
     if (listed) { l_count = P.chunks[blockIdx.x].count; l_begin = P.chunks[blockIdx.x].begin; }
     const uint32_t slot = listed ? P.chunks[blockIdx.x].slot : (!sparse && P.slot_order != nullptr) ? P.slot_order[blockIdx.x] : blockIdx.x;
-    const uint64_t q64 = listed ? (uint64_t)slot : sparse ? (uint64_t)P.q_list[blockIdx.x] : (uint64_t)q_begin + (uint64_t)slot * q_stride;
-    if (q64 >= (listed ? (uint64_t)S.n : (uint64_t)q_end)) return;
+    const uint64_t q64 = listed ? (uint64_t)slot : sparse ? (uint64_t)P.q_list[blockIdx.x] : Q.entry(slot);
+    if (q64 >= (listed ? (uint64_t)S.n : (uint64_t)Q.end)) return;
     const uint32_t q = (uint32_t)q64;
     const int32_t m = S.lens[q];
     int64_t pbase = (int64_t)q + 1 + (int64_t)tile_begin * 64;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                 // the pair's lower index
                 const uint32_t lowi = pid < q ? pid : q;
                 const bool mine = pid != q && off <= (int64_t)P.depth && (pid > q || P.qflag[pid] == 0) &&
-                                  lowi >= P.own_begin && (lowi - P.own_begin) % P.own_stride == 0;
+                                  P.own.owns(lowi);
                 within = within && mine;
             }
             us = within && q_isq && P.tflag[pid];

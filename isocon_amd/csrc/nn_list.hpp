@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, c
 // surviving pair is kept by exactly one of its two ends.  Kept pairs are staged in LDS; NN_LIST_CHUNK staged pairs become a chunk
 // of `list` (one k_nn_scan_refill workgroup with x's table), what is left at the end becomes a last chunk if it has NN_LIST_MIN
 // pairs, else flat pairs for the one-pair-per-lane kernel.
-__global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint32_t *__restrict__ meta, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
+__global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint32_t *__restrict__ meta, QMap Q, uint32_t nq,
                                                        uint32_t *__restrict__ list, unsigned long long list_cap, NNChunk *__restrict__ chunks, unsigned long long chunks_cap,
                                                        uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min,
                                                        int32_t force_narrow)
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
     uint32_t up_len = 0, dn_len = 0, dn_slo = 0;
     unsigned long long up_off = 0, dn_off = 0;
     if (x < S.n && (x_isq || x_ist)) {
-        if (x >= q_begin && (x - q_begin) % q_stride == 0 && (x - q_begin) / q_stride < nq) {
-            const uint32_t s = (x - q_begin) / q_stride;
+        uint32_t s;
+        if (Q.slot_of(x, s) && s < nq) {
             up_len = B.row_len[s];
             up_off = B.row_off[s];
         }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
             for (int u = 0; u < U; ++u) {
                 const uint32_t e = c0 + 64u * u + (uint32_t)lane;
                 const uint32_t ec = e < len ? e : len - 1;
-                y[u] = side == 0 ? x + 1u + ec : q_begin + (dn_slo + ec) * q_stride;
+                y[u] = side == 0 ? x + 1u + ec : (uint32_t)Q.entry(dn_slo + ec);
                 my[u] = meta[y[u]];
                 lbv[u] = row[ec];
             }

@@ -127,7 +127,7 @@ __device__ __forceinline__ void qm_glds16(const uint8_t *gsrc, uint32_t lds_dst)
 }
 
 // One workgroup = one 256 x 256 tile of the bound matrix: columns = the entries p = 256 J .. + 255 (operand A), rows = the launch
-// slots s = 256 I .. + 255 of the main pass, i.e. the entries q = q_begin + s * q_stride (operand B).  8 waves, wave (wp, wq) owns
+// slots s = 256 I .. + 255 of the main pass, i.e. the entries q = Q.entry(s) (operand B).  8 waves, wave (wp, wq) owns
 // 128 p x 64 q = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator registers).  The profiles stream through a ring of QM_STAGES K-blocks
 // in LDS (LDS-DMA, prefetch distance QM_STAGES - 1, one barrier per K-block); a row of a K-block is 4 slots of 16 B, slot sl of
 // tile row r sits at physical slot sl ^ ((r >> 2) & 3), which makes the ds_read_b128 of a fragment (32 rows x one slot, 16 lanes
@@ -140,7 +140,7 @@ __device__ __forceinline__ void qm_glds16(const uint8_t *gsrc, uint32_t lds_dst)
 // keys as in k_qgram_seed_pairs.
 __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__ prof4, const uint32_t *__restrict__ psum, uint32_t n, uint32_t n_pad,
                                                       const uint2 *__restrict__ tiles, const unsigned long long *__restrict__ row_off,
-                                                      const uint32_t *__restrict__ row_len, uint8_t *__restrict__ lb, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
+                                                      const uint32_t *__restrict__ row_len, uint8_t *__restrict__ lb, QMap Q, uint32_t nq,
                                                       const uint8_t *__restrict__ qflag, const uint8_t *__restrict__ tflag,
                                                       unsigned long long *__restrict__ rowmin, unsigned long long *__restrict__ colmin,
                                                       const unsigned long long *__restrict__ offT, const uint32_t *__restrict__ sloT, const uint32_t *__restrict__ lenT,
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
         m_lenT[tid] = tp ? lenT[p] : 0u;
         m_offT[tid] = tp ? offT[p] : 0ull;
         const uint32_t s = I * QM_TILE + tid;
-        const uint64_t qq = (uint64_t)q_begin + (uint64_t)s * q_stride;
+        const uint64_t qq = Q.entry(s);
         const bool have = s < nq && qq < n;
         m_q[tid] = have ? (uint32_t)qq : 0xffffffffu;
         m_sB[tid] = have ? psum[qq] : 0u;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
         uint64_t ent;
         if (it < 2) ent = (uint64_t)J * QM_TILE + row;            // operand A: columns p (n_pad covers every tile)
         else {
-            ent = (uint64_t)q_begin + ((uint64_t)I * QM_TILE + row) * q_stride;
+            ent = Q.entry(I * QM_TILE + (uint32_t)row);
             if (ent >= n_pad) ent = n_pad - 1;
         }
         gsrc[it] = prof4 + ent * QM_ROWB + ls * 16;
@@ -446,35 +446,93 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     }
 }
 
+// Row layout of the transposed matrix (nn_host.inc, build_bounds): for entry p the launch slots whose window holds p -- the slots s with
+// q(s) < p <= q(s) + row_len[s], a run because both q(s) and q(s) + row_len[s] ascend with s: sloT[p] = its first slot, lenT[p] = its
+// length, padT[p] = the bytes of its storage (from slot sloT & ~15 to the next multiple of 16 behind its last slot).  k_lbt_offsets
+// turns the exclusive prefix sums of padT into the address of the first slot.
+__global__ __launch_bounds__(256) void k_lbt_rows(QMap Q, uint32_t nq, const uint32_t *__restrict__ row_len, uint32_t n, uint32_t *__restrict__ sloT,
+                                                   uint32_t *__restrict__ lenT, uint32_t *__restrict__ padT)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    QMap below = Q;                          // the owned entries below p: the slots 0 .. b - 1
+    below.end = Q.end < p ? Q.end : p;
+    uint32_t b = below.count();
+    if (b > nq) b = nq;
+    uint32_t lo = 0, hi = b;                 // first slot whose window reaches p
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (Q.entry(mid) + row_len[mid] < (uint64_t)p) lo = mid + 1; else hi = mid;
+    }
+    sloT[p] = lo;
+    lenT[p] = b - lo;
+    padT[p] = b > lo ? ((b + 15u) & ~15u) - (lo & ~15u) : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_lbt_offsets(uint32_t n, const uint32_t *__restrict__ sloT, unsigned long long *__restrict__ offT)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p < n) offT[p] += sloT[p] & 15u;
+}
+
 // Seed pairs from the smallest bounds: entry x with the neighbours of its row minima (if x owns a row) and with the row entries of
-// its column minima (QM_SEEDS of each: one per class of tiles), unless that row proposes the very pair itself.  pa / pb hold
-// 2 QM_SEEDS n slots, 0xffffffff = none.
+// its column minima (one per class of tiles), unless that row proposes the very pair itself.  The pairs are APPENDED to pa / pb
+// (2 QM_SEEDS n slots, pre-filled with 0xffffffff = none; *count = pairs written): a rank of a sharded search owns 1 / N of the rows,
+// so most of its row slots would be empty and the one-pair-per-lane kernel would run half-empty waves.
+// col_classes (1, 2 or QM_SEEDS): the column minima of the QM_SEEDS tile classes are merged into this many candidates.  One GPU keeps
+// all of them; N ranks each see only their own rows of a column, so together they would propose N QM_SEEDS candidates per column --
+// N times the seed work of one GPU, constant per rank: with QM_SEEDS / N classes (at least one) the total stays near one GPU's.
 __global__ __launch_bounds__(256) void k_qgram_seed_pairs(const unsigned long long *__restrict__ rowmin, const unsigned long long *__restrict__ colmin,
-                                                           uint32_t n, uint32_t q_begin, uint32_t q_stride, uint32_t nq,
-                                                           uint32_t *__restrict__ pa, uint32_t *__restrict__ pb)
+                                                           uint32_t n, QMap Q, uint32_t nq, uint32_t col_classes,
+                                                           uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long *__restrict__ count)
 {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
-    if (x >= n) return;
-    const bool has_row = x >= q_begin && (x - q_begin) % q_stride == 0 && (x - q_begin) / q_stride < nq;
-    const uint32_t s = has_row ? (x - q_begin) / q_stride : 0u;
-#pragma unroll
-    for (int c = 0; c < QM_SEEDS; ++c) {
-        uint32_t a0 = 0xffffffffu, b0 = 0xffffffffu, a1 = 0xffffffffu, b1 = 0xffffffffu;
+    const int lane = threadIdx.x & 63;
+    uint32_t sa[2 * QM_SEEDS], sb[2 * QM_SEEDS];
+    uint32_t m = 0;
+    if (x < n) {
+        uint32_t s = 0u;
+        const bool has_row = Q.slot_of(x, s) && s < nq;
         if (has_row) {
-            const unsigned long long kr = rowmin[(size_t)s * QM_SEEDS + c];
-            if (kr != ~0ull) { a0 = x; b0 = x + 1u + (uint32_t)kr; }
+#pragma unroll
+            for (int c = 0; c < QM_SEEDS; ++c) {
+                const unsigned long long kr = rowmin[(size_t)s * QM_SEEDS + c];
+                if (kr != ~0ull) { sa[m] = x; sb[m] = x + 1u + (uint32_t)kr; ++m; }
+            }
         }
-        const unsigned long long kc = colmin[(size_t)x * QM_SEEDS + c];
-        if (kc != ~0ull) {
-            // a row entry: q = q_begin + s * q_stride by construction; skipped when it is that row's own candidate for x's class of tiles
-            const uint32_t q = (uint32_t)kc;
-            const unsigned long long kq = rowmin[(size_t)((q - q_begin) / q_stride) * QM_SEEDS + (x / QM_TILE) % QM_SEEDS];
-            if (kq == ~0ull || q + 1u + (uint32_t)kq != x) { a1 = q; b1 = x; }
+        const uint32_t per = (uint32_t)QM_SEEDS / col_classes;          // tile classes merged into one candidate
+        for (uint32_t g = 0; g < col_classes; ++g) {
+            unsigned long long kc = ~0ull;
+            for (uint32_t c = g; c < g + per * col_classes; c += col_classes) {          // classes g, g + col_classes, ...
+                const unsigned long long v = colmin[(size_t)x * QM_SEEDS + c];
+                kc = v < kc ? v : kc;
+            }
+            if (kc != ~0ull) {
+                // a row entry: q = Q.entry(its slot) by construction; skipped when it is that row's own candidate for x's class of tiles
+                const uint32_t q = (uint32_t)kc;
+                uint32_t sq = 0u;
+                (void)Q.slot_of(q, sq);
+                const unsigned long long kq = rowmin[(size_t)sq * QM_SEEDS + (x / QM_TILE) % QM_SEEDS];
+                if (kq == ~0ull || q + 1u + (uint32_t)kq != x) { sa[m] = q; sb[m] = x; ++m; }
+            }
         }
-        const size_t at = ((size_t)x * QM_SEEDS + c) * 2;
-        pa[at] = a0; pb[at] = b0;
-        pa[at + 1] = a1; pb[at + 1] = b1;
     }
+    // wave-aggregated append
+    uint32_t inc = m;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+        if ((uint32_t)lane >= d) inc += o;
+    }
+    const uint32_t wave_total = (uint32_t)__shfl((int)inc, 63, 64);
+    if (wave_total == 0) return;
+    unsigned long long base = 0;
+    if (lane == 63) base = atomicAdd(count, (unsigned long long)wave_total);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 63, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 63, 64);
+    const unsigned long long at = base + (inc - m);
+#pragma unroll
+    for (uint32_t i = 0; i < 2 * QM_SEEDS; ++i)
+        if (i < m) { pa[at + i] = sa[i]; pb[at + i] = sb[i]; }
 }
 
 // The same bound for an explicit pair list (one wave per pair; tests and diagnostics: isocon_qgram_bound_pairs).

@@ -1,9 +1,12 @@
 """One-process-per-GPU sharding of the nearest-neighbour search (torch.distributed; backend "nccl" = RCCL on ROCm).
 
 The packed sequence set is replicated on every GPU (31 MB for 50 k x 2.5 kb).  The 1-set search evaluates each
-unordered pair once, on the rank that owns the pair's LOWER index; rank r of N owns the entries r, r+N, r+2N, ... of the
-length-sorted order (a cyclic split: every rank gets the same mix of dense and sparse length regions, so the very uneven
-windows balance by themselves; `shard_ranges` is the contiguous alternative, balanced by estimated window sizes).
+unordered pair once, on the rank that owns the pair's LOWER index; ownership is BLOCK-CYCLIC: the length-sorted order is cut into
+blocks of SHARD_BLOCK = 256 consecutive entries (one tile row of the bound matrix) dealt round-robin, rank r of N owns the blocks
+r, r + N, ... (`shard_of`).  Every rank gets the same mix of dense and sparse length regions, so the very uneven windows balance
+by themselves (195 blocks at 50 000 reads), and a rank's 256 x 256 bound tiles are as dense as on one GPU -- with entry-cyclic
+ownership (r, r + N, ...: rounds 2-3) a tile's 256 rows spanned N times the columns and the bound phase hardly scaled.
+`shard_ranges` is the contiguous alternative, balanced by estimated window sizes.
 Phase 0 = q-gram bounds of the rank's rows and the seeds they give; phase 1 = survivor lists and alignments of those rows;
 phase 2 = 128/256/512-row bands and the un-banded kernel, only if the reduced bounds leave a query unresolved.  Exchange steps
 (the only data-path collectives):
@@ -45,6 +48,39 @@ def shard_ranges(lens, world_size, kcap=63, two_set_targets=None):
     cuts.append(n)
     cuts = np.maximum.accumulate(np.asarray(cuts))
     return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world_size)]
+
+
+SHARD_BLOCK = 256          # = QM_TILE of csrc/qgram_mm.hpp: one tile row of the bound matrix
+
+
+def shard_of(rank, world, n):
+    """(q_begin, q_end, q_stride, q_block) of include/isocon_hip.h for rank `rank` of `world`: block-cyclic ownership.  Blocks of
+    SHARD_BLOCK entries; on small sets the block shrinks (a power of two) until every rank has at least four blocks, so that the
+    round-robin still balances -- a function of (n, world) only: the same on every rank."""
+    block = SHARD_BLOCK
+    while block > 1 and n < 4 * world * block:
+        block //= 2
+    return rank * block, n, world * block, block
+
+
+def _device_path_agreed(store, n, dist, device):
+    """The device-resident protocol is used only if EVERY rank can and the collectives run on the GPU: decided once per store and
+    group with one all_reduce(MIN) of a capability flag (a rank deciding from its local state alone could pair a CUDA tensor with a
+    CPU tensor in the same collective)."""
+    import torch
+    world = dist.get_world_size()
+    cached = getattr(store, "_dist_device_path", None)
+    if cached is not None and cached[0] == world and cached[1] == device.type:
+        return cached[2]
+    can = (device.type == "cuda" and hasattr(store, "nn_partial_dev") and n > 0 and len(_lib.hip_runtimes_loaded()) == 1 and torch.cuda.is_available())
+    t = torch.tensor([1 if can else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    agreed = bool(int(t.item()))
+    try:
+        store._dist_device_path = (world, device.type, agreed)
+    except AttributeError:
+        pass
+    return agreed
 
 
 def _all_gather_rows(dist, rows, device):
@@ -118,6 +154,7 @@ def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap):
     if torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev):
         raise RuntimeError("sharded_nn_graph: call it on the default stream (the library's kernels run there)")
     n = store.n
+    qb, qe, qs, qk = shard_of(rank, world, n)
     tl = time.perf_counter()
     cache = store.__dict__.setdefault("_dist_device", {})
     t = cache.get("reduce")
@@ -143,8 +180,8 @@ def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap):
         err = None
         tl = time.perf_counter()
         try:
-            held, stats = store.nn_partial_dev(rank, n, phase, t.data_ptr(), phase > 0, is_converged=is_converged, is_target=is_target,
-                                               depth=depth, q_stride=world)
+            held, stats = store.nn_partial_dev(qb, qe, phase, t.data_ptr(), phase > 0, is_converged=is_converged, is_target=is_target,
+                                               depth=depth, q_stride=qs, q_block=qk)
         except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
             err, stats = e, {}
         tl = lap("nn_partial_phase%d" % phase, tl)
@@ -188,7 +225,7 @@ def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap):
 def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, dist=None, device=None, return_stats=False, laps=None):
     """Exact NN graph of `store` (length-sorted) computed by all ranks of the default process group.
 
-    `store` needs .n, .lens and .nn_partial(q_begin, q_end, phase, best, is_converged=, is_target=, depth=, q_stride=).
+    `store` needs .n, .lens and .nn_partial(q_begin, q_end, phase, best, is_converged=, is_target=, depth=, q_stride=, q_block=).
     Every rank returns the full (best, row_ptr, cols).  laps: optional dict that receives the seconds spent per protocol part."""
     import time
     import torch
@@ -216,10 +253,10 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         except AttributeError:
             pass
     tl = lap("fingerprint", tl)
-    if hasattr(store, "nn_partial_dev") and n > 0 and len(_lib.hip_runtimes_loaded()) == 1 and torch.cuda.is_available():
+    if _device_path_agreed(store, n, dist, device):
         out = _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap)
         return out if return_stats else out[:3]
-    qb, qe, qs = rank, n, world          # cyclic ownership
+    qb, qe, qs, qk = shard_of(rank, world, n)          # block-cyclic ownership
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
     nb = len(best)
@@ -246,7 +283,7 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         tl = time.perf_counter()
         try:
             hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth,
-                                           q_stride=qs)
+                                           q_stride=qs, q_block=qk)
         except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
             err, hits, stats = e, np.zeros((0, 3), np.int32), {}
         tl = lap("nn_partial_phase%d" % phase, tl)

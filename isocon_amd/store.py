@@ -109,18 +109,18 @@ class SeqStore(object):
                    "isocon_qgram_bound_pairs")
         return out
 
-    def qgram_bound_matrix(self, q_begin=0, q_end=None, q_stride=1, depth=2 ** 32):
-        """The bound matrix the NN main pass consults for the shard q_begin, q_begin + q_stride, ... (isocon_qgram_bound_matrix; tests):
-        (row_ptr[rows + 1], bytes) -- row r = entry q_begin + r * q_stride against the entries behind it within 63 of its length."""
+    def qgram_bound_matrix(self, q_begin=0, q_end=None, q_stride=1, depth=2 ** 32, q_block=1):
+        """The bound matrix the NN main pass consults for the shard (q_begin, q_end, q_stride, q_block) (isocon_qgram_bound_matrix; tests):
+        (row_ptr[rows + 1], bytes) -- row r = the shard's r-th entry (shard_entries) against the entries behind it within 63 of its length."""
         q_end = self.n if q_end is None else min(int(q_end), self.n)
-        rows = 0 if q_begin >= q_end else (q_end - q_begin + q_stride - 1) // q_stride
+        rows = len(shard_entries(q_begin, q_end, q_stride, q_block))
         row_ptr = np.zeros(rows + 1, dtype=np.uint64)
         needed = ctypes.c_uint64(0)
         cap = 1 << 20
         depth = int(min(depth, 2 ** 63 - 1))
         while True:
             out = np.empty(cap, dtype=np.uint8)
-            rc = self._L.isocon_qgram_bound_matrix(self._h, q_begin, q_end, q_stride, depth, _ptr(row_ptr, _lib.u64p), _ptr(out, _lib.u8p), cap,
+            rc = self._L.isocon_qgram_bound_matrix(self._h, q_begin, q_end, q_stride, q_block, depth, _ptr(row_ptr, _lib.u64p), _ptr(out, _lib.u8p), cap,
                                                    ctypes.byref(needed))
             if rc == _lib.ISOCON_E_CAPACITY:
                 cap = int(needed.value)
@@ -171,7 +171,7 @@ class SeqStore(object):
             _lib.check(rc, "isocon_nn_graph")
             return best[:n], row_ptr.astype(np.int64), cols[:int(row_ptr[n])], stats.as_dict()
 
-    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1):
+    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1):
         """One shard / one phase (see include/isocon_hip.h).  `best` is updated in place; returns (hits[k,3], stats)."""
         conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
         targ = None if is_target is None else np.ascontiguousarray(is_target, dtype=np.uint8)
@@ -183,7 +183,7 @@ class SeqStore(object):
         best0 = best.copy()
         while True:
             hits = np.empty((cap, 3), dtype=np.int32)
-            rc = self._L.isocon_nn_partial(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), depth, q_begin, q_end, q_stride, phase,
+            rc = self._L.isocon_nn_partial(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), depth, q_begin, q_end, q_stride, q_block, phase,
                                            _ptr(best, _lib.i32p), _ptr(hits, _lib.i32p), cap, ctypes.byref(n_hits),
                                            ctypes.byref(stats))
             if rc == _lib.ISOCON_E_CAPACITY:
@@ -194,7 +194,7 @@ class SeqStore(object):
             return hits[:int(n_hits.value)], stats.as_dict()
 
     # the same protocol with best[] and the candidate edges resident in device memory (isocon_amd/dist.py on a GPU)
-    def nn_partial_dev(self, q_begin, q_end, phase, best_dev_ptr, keep_hits, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1):
+    def nn_partial_dev(self, q_begin, q_end, phase, best_dev_ptr, keep_hits, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1):
         """One shard / one phase on best[] in device memory (an int: the device address of n int32).  The phase's candidate edges join
         the list the library holds on the device (keep_hits False: a new list).  Returns (edges held, stats)."""
         conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
@@ -202,7 +202,7 @@ class SeqStore(object):
         held = ctypes.c_uint64(0)
         stats = _lib.NNStats()
         _lib.check(self._L.isocon_nn_partial_dev(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), int(min(depth, 2 ** 63 - 1)), q_begin, q_end,
-                                                 q_stride, phase, ctypes.c_void_p(int(best_dev_ptr)), 1 if keep_hits else 0, ctypes.byref(held),
+                                                 q_stride, q_block, phase, ctypes.c_void_p(int(best_dev_ptr)), 1 if keep_hits else 0, ctypes.byref(held),
                                                  ctypes.byref(stats)), "isocon_nn_partial_dev")
         return int(held.value), stats.as_dict()
 
@@ -253,6 +253,15 @@ class SeqStore(object):
             _lib.check(rc, "isocon_sg_trace_batch")
             out = (ops[:int(ops_ptr[n])], ops_ptr.astype(np.int64), res[:n])
             return out + (ms.value,) if return_ms else out
+
+
+def shard_entries(q_begin, q_end, q_stride=1, q_block=1):
+    """The entries a shard owns, in slot order (include/isocon_hip.h, isocon_nn_partial): q_begin <= x < q_end with
+    (x - q_begin) mod q_stride < q_block."""
+    if q_begin >= q_end:
+        return np.zeros(0, dtype=np.int64)
+    x = np.arange(q_begin, q_end, dtype=np.int64)
+    return x[(x - q_begin) % q_stride < q_block]
 
 
 _HOST_BUFFERS = {}

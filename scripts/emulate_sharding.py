@@ -5,8 +5,12 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from isocon_amd import synth, _lib
+from isocon_amd.dist import shard_of
 from isocon_amd.store import SeqStore, nn_finalize
-accs, seqs, _ = synth.make_reads(50000, 2500, 10, 30001)
+if len(sys.argv) > 1 and sys.argv[1] == "c5":          # 200 000 mixed-length reads, 6 % errors (BASELINE.json configs[4])
+    accs, seqs, _ = synth.make_reads(200000, 0, 50, 50001, profile=synth.ONT_PROFILE, families=5, length_range=(1000, 5000))
+else:
+    accs, seqs, _ = synth.make_reads(50000, 2500, 10, 30001)
 seqs = sorted(dict.fromkeys(seqs), key=len)
 st = SeqStore(seqs)
 n = st.n
@@ -22,12 +26,16 @@ for world in (2, 4, 8):
         bests = []; kms = []
         for r in range(world):
             b = best.copy()
-            t = time.time(); hits, stats = st.nn_partial(r, n, phase, b, q_stride=world); walls.append(time.time() - t)
+            if os.environ.get("CYCLIC"):          # entry-cyclic ownership of rounds 2-3, for comparison
+                qb, qe, qs, qk = r, n, world, 1
+            else:
+                qb, qe, qs, qk = shard_of(r, world, n)
+            t = time.time(); hits, stats = st.nn_partial(qb, qe, phase, b, q_stride=qs, q_block=qk); walls.append(time.time() - t)
             bests.append(b); kms.append(stats["kernel_ms"]); tot_cols += stats["cells_columns"]; tot_pairs += stats["pairs_evaluated"]
             hits_all.append(hits)
         best = np.minimum.reduce(bests)
         crit += max(kms)
-        print("  world %d phase %d: per-rank kernel ms max %.2f mean %.2f; call wall max %.2f ms" % (world, phase, max(kms), np.mean(kms), 1e3 * max(walls[-world:])))
+        print("  world %d phase %d: per-rank kernel ms max %.2f mean %.2f (max/mean %.3f); call wall max %.2f ms" % (world, phase, max(kms), np.mean(kms), max(kms) / max(np.mean(kms), 1e-9), 1e3 * max(walls[-world:])))
     hits = np.concatenate(hits_all)
     keep = (hits[:, 2] >= 0) & (hits[:, 2] == best[hits[:, 0]])
     out = nn_finalize(n, best, hits[keep])

@@ -23,8 +23,10 @@ class FakeStore(object):
         self.n = len(seqs)
         self.lens = np.array([len(s) for s in seqs], dtype=np.int64)
 
-    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1):
+    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1):
         from oracle import oracle as O
+        from isocon_amd.store import shard_entries
+        owned = [int(x) for x in shard_entries(q_begin, min(q_end, self.n), q_stride, q_block)]
         hits = []
         n = self.n
         if is_target is not None:
@@ -33,7 +35,7 @@ class FakeStore(object):
         if phase == 0:      # seed pass: nothing in this stand-in
             pass
         elif phase in (1, 3):    # pairs owned through their lower index, band limit 63
-            for q in range(q_begin, q_end, q_stride):
+            for q in owned:
                 for t in range(q + 1, n):
                     if self.lens[t] - self.lens[q] > 63:
                         break
@@ -45,7 +47,7 @@ class FakeStore(object):
                             best[e] = d
                             hits.append((e, o, d))
         else:               # owned queries still unresolved: unbounded distances inside |len diff| <= len(q)
-            for q in range(q_begin, q_end, q_stride):
+            for q in owned:
                 if conv[q] or best[q] != NN_INF:
                     continue
                 for t in range(n):

@@ -99,17 +99,21 @@ def test_sharded_partial_matches_single_call():
     n = len(seqs)
     best1, rp1, cols1, _ = st.nn_graph()
     cut = n // 3
-    for shards in (((0, cut, 1), (cut, n, 1)),              # contiguous ranges
-                   ((0, n, 3), (1, n, 3), (2, n, 3))):      # cyclic ownership (what dist.sharded_nn_graph uses)
+    from isocon_amd.dist import shard_of
+    assert shard_of(1, 3, n)[3] > 1
+    for shards in (((0, cut, 1, 1), (cut, n, 1, 1)),              # contiguous ranges
+                   ((0, n, 3, 1), (1, n, 3, 1), (2, n, 3, 1)),    # entry-cyclic ownership
+                   tuple(shard_of(r, 3, n) for r in range(3)),    # block-cyclic ownership (what dist.sharded_nn_graph uses)
+                   ((0, n, 48, 16), (16, n, 48, 16), (32, n - 5, 48, 16))):
         for phases in ((0, 1, 2),      # seed, 64-row band, wide bands; min-reduction after each
                        (3, 2)):        # seeds + 64-row band in one call (what dist.sharded_nn_graph runs), wide bands
             hits = []
             red = np.full(n, _lib.NN_INF, dtype=np.int32)
             for phase in phases:
                 bests = []
-                for (b, e, stride) in shards:
+                for (b, e, stride, block) in shards:
                     best = red.copy()
-                    h, _ = st.nn_partial(b, e, phase, best, q_stride=stride)
+                    h, _ = st.nn_partial(b, e, phase, best, q_stride=stride, q_block=block)
                     bests.append(best); hits.append(h)
                 red = np.minimum.reduce(bests)
             best2, rp2, cols2 = nn_finalize(n, red, np.concatenate(hits))
@@ -290,6 +294,7 @@ def test_device_resident_phases_equal_the_single_call():
     bounds into a fixed-size block, and the blocks are concatenated like the all_gather."""
     import torch
     from isocon_amd import _lib, synth
+    from isocon_amd.dist import shard_of
     from isocon_amd.store import SeqStore
     accs, seqs, _ = synth.make_reads(2500, 700, 4, seed=91)
     seqs = sorted(dict.fromkeys(seqs), key=len) + ["ACGT" * 40 + "TTTTGGGGCCCCAAAA" * 30]          # a read far from all others: phase 2
@@ -305,7 +310,8 @@ def test_device_resident_phases_equal_the_single_call():
             outs = []
             for r in range(world):
                 b = reduced[-1].clone()
-                st.nn_partial_dev(r, n, phase, b.data_ptr(), False, is_converged=conv, q_stride=world)
+                qb, qe, qs, qk = shard_of(r, world, n)
+                st.nn_partial_dev(qb, qe, phase, b.data_ptr(), False, is_converged=conv, q_stride=qs, q_block=qk)
                 outs.append(b)
             reduced.append(torch.stack(outs).min(dim=0).values)
         final = reduced[-1]
@@ -314,7 +320,8 @@ def test_device_resident_phases_equal_the_single_call():
             held = 0
             for phase in (0, 1, 2):
                 b = reduced[phase].clone()
-                held, stats = st.nn_partial_dev(r, n, phase, b.data_ptr(), phase > 0, is_converged=conv, q_stride=world)
+                qb, qe, qs, qk = shard_of(r, world, n)
+                held, stats = st.nn_partial_dev(qb, qe, phase, b.data_ptr(), phase > 0, is_converged=conv, q_stride=qs, q_block=qk)
             assert held > 0
             with pytest.raises(RuntimeError):
                 st.nn_hits_dev(final.data_ptr(), torch.empty((held - 1, 3), dtype=torch.int32, device=dev).data_ptr(), held - 1)

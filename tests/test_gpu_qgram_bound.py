@@ -46,12 +46,13 @@ def test_bound_equals_the_restatement_and_never_exceeds_the_distance():
     assert (got > 0).sum() > 1000          # the bound is not vacuous
 
 
-def _check_matrix(st, seqs, B, q_begin, q_end, q_stride, depth):
+def _check_matrix(st, seqs, B, q_begin, q_end, q_stride, depth, q_block=1):
     """every byte of the matrix the main pass reads (isocon_qgram_bound_matrix) against the restatement"""
     lens = np.array([len(s) for s in seqs])
     n = len(seqs)
-    row_ptr, got = st.qgram_bound_matrix(q_begin, q_end, q_stride, depth)
-    qs = list(range(q_begin, min(q_end, n), q_stride))
+    from isocon_amd.store import shard_entries
+    row_ptr, got = st.qgram_bound_matrix(q_begin, q_end, q_stride, depth, q_block)
+    qs = [int(x) for x in shard_entries(q_begin, min(q_end, n), q_stride, q_block)]
     assert len(row_ptr) == len(qs) + 1
     total = 0
     for r, q in enumerate(qs):
@@ -70,7 +71,7 @@ def _check_matrix(st, seqs, B, q_begin, q_end, q_stride, depth):
 
 def test_every_byte_of_the_bound_matrix():
     """The product kernel k_qgram_mm (tiles of 256 x 256 pairs on the matrix cores, rows laid out for the main pass) against the numpy
-    restatement: 1-set, strided shards, a last row block that is not full, finite depths, n not a multiple of the tile."""
+    restatement: 1-set, strided and block-cyclic shards, a last row block that is not full, finite depths, n not a multiple of the tile."""
     import random
     import qgram_ref as R
     from isocon_amd import synth
@@ -89,6 +90,10 @@ def test_every_byte_of_the_bound_matrix():
         assert total > 1000000
         for q_begin, q_stride in ((0, 3), (1, 3), (2, 3), (5, 7)):
             _check_matrix(st, seqs, B, q_begin, n, q_stride, 2 ** 32)
+        # block-cyclic shards (isocon_amd/dist.py: blocks of one tile row dealt round-robin), a smaller block, a last block cut by q_end
+        for q_begin, q_stride, q_block in ((0, 768, 256), (256, 768, 256), (512, 768, 256), (64, 256, 64), (8, 24, 8)):
+            _check_matrix(st, seqs, B, q_begin, n, q_stride, 2 ** 32, q_block)
+        _check_matrix(st, seqs, B, 256, n - 100, 512, 150, 256)
         _check_matrix(st, seqs, B, 0, n, 1, 300)
         _check_matrix(st, seqs, B, 1, n - 7, 2, 37)
         _check_matrix(st, seqs, B, n - 40, n, 1, 2 ** 32)
@@ -159,7 +164,7 @@ def test_sharded_phases_with_the_filter():
             parts = []
             for r in ((0, 1, 2) if phase != 1 else (2, 0, 1)):
                 b = best.copy()
-                hits, stats = st.nn_partial(r, n, phase, b, depth=400, q_stride=3)
+                hits, stats = st.nn_partial(r * 64, n, phase, b, depth=400, q_stride=192, q_block=64)
                 filtered += stats.get("pairs_prefiltered", 0)
                 # the main phase that directly follows its own shard's seed phase finds the bound matrix still in place
                 reused += phase == 1 and stats["pairs_prefiltered"] > 0 and stats["bound_kernel_ms"] == 0
