@@ -242,20 +242,20 @@ def cpu_pair_legs(pool, cores, pair_ed, budget_s=10.0):
         ed_kind = "port"
     out = {}
     # edit distances: fast per pair -> a large sample
-    n_ed = min(len(pair_ed), 8192)
+    n_ed = len(pair_ed)
     tasks = [((s1, s2, i, 0), {}) for i, (s1, s2, _) in enumerate(pair_ed[:n_ed])]
     t0 = time.perf_counter()
     res = pool.map_async(_cpu_ed_task, tasks).get(999999999)
     dt = time.perf_counter() - t0
     assert all(r[2] == p[2] for r, p in zip(res, pair_ed[:n_ed])), "CPU edit distances differ from the GPU's"
     out["ed_pairs"] = {"value": n_ed / dt, "unit": "pairs/s", "cores": cores, "kind": ed_kind,
-                       "sample": "%d of %d partition pairs (the first, in dict order), unbounded global edit distance, Pool(%d).map_async with one task "
+                       "sample": "%d of %d partition pairs, unbounded global edit distance, Pool(%d).map_async with one task "
                                  "per pair as EAM:25-47, %.2f s wall; distances equal to the GPU's" % (n_ed, len(pair_ed), cores, dt)}
     # alignments with traceback: ~6 M cells per pair -> doubled batches until the budget is used
     done = 0
     t_sw = 0.0
     batch = max(4 * cores, 64)
-    while done < len(pair_ed) and t_sw < budget_s:
+    while done < len(pair_ed) and t_sw < budget_s / 3:          # (batches double: the next one alone takes as long as all before it)
         part = pair_ed[done:done + batch]
         tasks = [((s1, s2, i, 0), {"mismatch_penalty": O.mismatch_penalty_for(ed, len(s1), len(s2))}) for i, (s1, s2, ed) in enumerate(part)]
         t0 = time.perf_counter()
@@ -400,7 +400,7 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    phase_ms = {k: [] for k in ("scan_kernel_ms", "seed_kernel_ms", "bound_kernel_ms", "list_kernel_ms", "lanes_kernel_ms", "kernel_ms")}
+    phase_ms = {k: [] for k in ("scan_kernel_ms", "narrow_kernel_ms", "seed_kernel_ms", "bound_kernel_ms", "list_kernel_ms", "lanes_kernel_ms", "kernel_ms")}
     for _ in range(args.steps):
         step()
         for k in phase_ms:          # HIP events on the kernels' own stream (EventTimer, csrc/isocon_hip.hip)
@@ -422,12 +422,17 @@ def main():
     value = n_align / (ms_per_step / 1e3)
 
     # ---- roofline of the dominant kernel on this rank --------------------------------------------------------------
-    st0 = {k: sum(x.get(k, 0) for x in last["stats"]) for k in ("pairs_evaluated", "cells_columns", "pairs_prefiltered", "pairs_lanes", "bound_tiles")}   # this rank, all phases
+    st0 = {k: sum(x.get(k, 0) for x in last["stats"]) for k in ("pairs_evaluated", "cells_columns", "pairs_prefiltered", "pairs_lanes", "bound_tiles",
+                                                                 "narrow_columns", "pairs_narrow")}   # this rank, all phases
     pairs_eval = int(st0["pairs_evaluated"])
-    wave_cols = float(st0["cells_columns"]) / 64.0            # 64-lane DP columns the table kernel executed (its own counter)
+    # the table launches: the 64-row class (the dominant kernel) and the 32-row class (pairs whose threshold is <= 31), each with its own
+    # event time and its own column counter
+    wave_cols_narrow = float(st0["narrow_columns"]) / 64.0
+    wave_cols = float(st0["cells_columns"]) / 64.0 - wave_cols_narrow          # 64-lane DP columns the 64-row table kernel executed (its own counter)
     mean_len = float(lens.mean())
     pm = {k: (float(np.mean(v)) if v else 0.0) for k, v in phase_ms.items()}
-    k_ms = pm["scan_kernel_ms"]
+    tables_ms = pm["scan_kernel_ms"]
+    k_ms = tables_ms - pm["narrow_kernel_ms"]
     is_default = (args.reads, args.length, args.isoforms, args.seed) == (50000, 2500, 10, 30001)
     ctr, ctr_note = load_counters()
     cm = ctr.get("nn_main", {})
@@ -451,9 +456,18 @@ def main():
                       "frac": macs / (pm["bound_kernel_ms"] / 1e3) / MFMA_FP4_PEAK_MACS,
                       "hbm_frac": (float(cb["hbm_bytes"]) / (pm["bound_kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS) if (cb.get("hbm_bytes") and is_default and world == 1) else None,
                       "traffic": float(cb["hbm_bytes"]) if (cb.get("hbm_bytes") and is_default and world == 1) else None}
+    narrow_pass = None
+    if pm["narrow_kernel_ms"] > 0 and wave_cols_narrow > 0:
+        cn = ctr.get("nn_main_narrow", {})
+        ipc_n = float(cn["SQ_INSTS_VALU"]) / float(cn["wave_columns"]) if cn.get("SQ_INSTS_VALU") and cn.get("wave_columns") else None
+        ach_n = ipc_n * wave_cols_narrow / (pm["narrow_kernel_ms"] / 1e3) if ipc_n else None
+        narrow_pass = {"kernel": "isocon::k_nn_scan_refill<8, 1, true> (32-row form: the pairs whose threshold is <= 31)", "bound": "valu",
+                       "kernel_ms": pm["narrow_kernel_ms"], "pairs": int(st0["pairs_narrow"]), "wave_columns_this_run": wave_cols_narrow,
+                       "valu_insts_per_wave_column": ipc_n, "achieved": ach_n, "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instr/s",
+                       "frac": ach_n / VALU_PEAK_WAVE_INSTR if ach_n else None}
     alg_bytes = pairs_eval * (2.0 * mean_len + 8.0)
-    align_ms = k_ms + pm["lanes_kernel_ms"]
-    roofline = {"bound": "valu", "kernel": "isocon::k_nn_scan_refill<8, 1> (table kernel of the main pass, one step)",
+    align_ms = tables_ms + pm["lanes_kernel_ms"]
+    roofline = {"bound": "valu", "kernel": "isocon::k_nn_scan_refill<8, 1, false> (64-row table kernel of the main pass, one step)",
                 "achieved": achieved, "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instr/s",
                 "frac": achieved / VALU_PEAK_WAVE_INSTR if achieved else None, "traffic": traffic,
                 "kernel_ms": k_ms, "valu_insts_per_wave_column": ipc, "wave_columns_this_run": wave_cols, "valu_insts_this_run": insts,
@@ -468,9 +482,10 @@ def main():
                                 "stream_rate_of_nominal_peak": STREAM_RATE_OF_NOMINAL,
                                 "frac_of_stream_rate": (achieved / VALU_PEAK_WAVE_INSTR) * (1.0 + HALF_RATE_SHARE * (HALF_RATE_COST - 1.0)) / STREAM_RATE_OF_NOMINAL if achieved else None},
                 "step_kernels_ms": {"bounds (profiles + k_qgram_mm)": pm["bound_kernel_ms"], "seeds (k_ed_lanes)": pm["seed_kernel_ms"],
-                                    "survivor lists (k_nn_survivors)": pm["list_kernel_ms"], "tables (k_nn_scan_refill)": k_ms,
+                                    "survivor lists (k_nn_survivors)": pm["list_kernel_ms"], "tables, 64-row class (k_nn_scan_refill<8, 1, false>)": k_ms,
+                                    "tables, 32-row class (k_nn_scan_refill<8, 1, true>)": pm["narrow_kernel_ms"],
                                     "pair per lane (k_ed_lanes)": pm["lanes_kernel_ms"], "all kernels": pm["kernel_ms"]},
-                "bound_pass": bound_pass,
+                "bound_pass": bound_pass, "narrow_pass": narrow_pass,
                 "pairs_aligned": pairs_eval, "pairs_aligned_one_per_lane": int(st0["pairs_lanes"]), "pairs_rejected_by_qgram_bound": int(st0["pairs_prefiltered"]),
                 "wave_columns_per_s": wave_cols / (k_ms / 1e3) if k_ms > 0 else None,
                 "hbm": {"achieved": traffic / (k_ms / 1e3) / 1e9 if traffic and k_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

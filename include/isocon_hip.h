@@ -115,10 +115,12 @@ typedef struct {
     float bound_kernel_ms;        /* HIP-event time of the q-gram profile + bound kernels (part of kernel_ms) */
     float list_kernel_ms;         /* ... of the kernel that collects the survivors of the bounds into lists (part of kernel_ms) */
     float lanes_kernel_ms;        /* ... of the one-pair-per-lane launch of the main pass (entries with few pairs; NOT in scan_kernel_ms) */
-    uint32_t reserved_;
+    float narrow_kernel_ms;       /* of scan_kernel_ms: the table launch over the pairs whose threshold is <= 31 (32-row form of the kernel) */
     uint64_t pairs_lanes;         /* pairs of the main pass aligned one pair per lane (the rest went through tables) */
     uint64_t bound_tiles;         /* 256 x 256 tiles of the bound matrix computed (each: 65 536 pairs x isocon_qgram_params() multiply-adds) */
-    uint64_t pairs_wide_to_lanes; /* of pairs_lanes: pairs with a threshold above 31 while the table kernel ran its 32-row form */
+    uint64_t pairs_wide_to_lanes; /* of pairs_lanes: pairs with a threshold above 31 sent there because of it (ISOCON_NN_NARROW=1 only) */
+    uint64_t narrow_columns;      /* of cells_columns: columns run by the 32-row form of the table kernel */
+    uint64_t pairs_narrow;        /* pairs listed in chunks of the 32-row class */
 } isocon_nn_stats;
 
 /*

@@ -203,16 +203,22 @@ static int device_exscan(ScratchPool *pl, const uint32_t *d_in, uint32_t n, OUT 
 }
 
 struct EventTimer {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, em = nullptr;
     float total = 0.f;
+    float marked_total = 0.f;      // time between a mark() and the stop() that follows it, summed (a second launch inside one start / stop pair,
+    bool marked = false;           // timed without a host synchronisation between the two launches)
     bool ok = false;
-    EventTimer() { ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess; }
-    ~EventTimer() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
-    void start() { if (ok) (void)hipEventRecord(e0, 0); }
+    EventTimer() { ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventCreate(&em) == hipSuccess; }
+    ~EventTimer() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (em) (void)hipEventDestroy(em); }
+    void start() { if (ok) (void)hipEventRecord(e0, 0); marked = false; }
+    void mark() { if (ok) { (void)hipEventRecord(em, 0); marked = true; } }
     float stop()
     {
         float ms = 0.f;
-        if (ok) { (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); }
+        if (ok) {
+            (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+            if (marked) { float part = 0.f; (void)hipEventElapsedTime(&part, em, e1); marked_total += part; marked = false; }
+        }
         total += ms;
         return ms;
     }

@@ -31,18 +31,19 @@ static constexpr int NN_STAGE = NN_LIST_CHUNK + 64;
 // counters of the list builder, each on a cache line of its own (they are hot: tens of thousands of atomics per launch)
 struct NNPlanTotals {
     unsigned long long n_pairs, pad0[15], n_list, pad1[15], n_small, pad2[15], n_chunks, pad3[15], n_filtered, pad4[15], overflow, pad5[15];
-    unsigned long long n_wide_entries, n_wide_pairs, narrow, pad6[13];          // written before / by the scan, see nn_narrow_mode
+    unsigned long long n_chunks_narrow, pad6[15];          // chunks of the 32-row class (n_chunks counts the 64-row class)
+    unsigned long long n_wide_pairs, n_narrow_listed, pad7[14];          // pairs sent to the pair-per-lane kernel for their threshold (class mode 1); pairs in narrow chunks
 };
 
-// The narrow mode of the listed launch: when few queries still have a threshold above NN_NARROW_K after the seeds (CCS-like data: the
-// nearest neighbour is a few edits away), the table kernel runs its 32-row form (nn.hpp, HALF) and the pairs whose threshold is
-// larger go to the one-pair-per-lane kernel, which takes any threshold up to 63.  Decided on the device from a count k_nn_entry_meta
-// takes (no extra round trip); the host reads the decision with the totals.
+// Threshold classes of the listed launch.  A pair whose threshold max(k of its two directions) is <= NN_NARROW_K is exact on 32
+// diagonals (a path of cost <= k stays inside k + 1 of them), and on 32-bit vectors the table kernel's column is 12 instead of 21
+// instructions with one table dword instead of two (nn.hpp, HALF).  The class is decided PER PAIR: the list builder files the pairs of
+// an entry under their class, a chunk holds one class, and the host launches k_nn_scan_refill<.., true> over the narrow chunks and
+// <.., false> over the others.  (Round 3 decided per LAUNCH -- narrow only when fewer than n / 16 queries had a threshold above 31 --
+// so C3, whose median threshold is 32, ran every pair on 64 rows.)
+// class_mode: 0 = per pair; -1 = every pair in the 64-row class (A/B runs, tests); +1 = the pairs above NN_NARROW_K leave the lists
+// for the one-pair-per-lane kernel, which takes any threshold up to 63 (the round-3 narrow mode, forced).
 static constexpr int32_t NN_NARROW_K = 31;
-__device__ __forceinline__ bool nn_narrow_mode(unsigned long long wide_entries, uint32_t n, int32_t force)
-{
-    return force > 0 || (force == 0 && wide_entries * 16ull <= (unsigned long long)n);
-}
 
 // the matrix rows of both orientations (qgram_mm.hpp) and the hub scores that decide which end owns a pair
 struct NNBoundRows {
@@ -61,7 +62,6 @@ __device__ __forceinline__ uint32_t nn_meta_score(uint32_t w) { return w >> 23; 
 __global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, const uint32_t *__restrict__ score, uint32_t *__restrict__ meta, NNPlanTotals *__restrict__ totals)
 {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
-    bool wide = false;
     if (x < S.n) {
         const int32_t m = S.lens[x], b = load_relaxed_agent(P.best + x);
         int32_t thr = b < m ? b : m;
@@ -69,10 +69,7 @@ __global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, c
         const uint32_t sc = score[x] >> 5;
         const bool isq = P.qflag[x] != 0;
         meta[x] = ((uint32_t)m & 0x3fffu) | ((uint32_t)thr << 14) | ((P.tflag[x] != 0 ? 1u : 0u) << 21) | ((isq ? 1u : 0u) << 22) | ((sc < 511u ? sc : 511u) << 23);
-        wide = isq && thr > NN_NARROW_K;
     }
-    const uint64_t wm = __ballot(wide);
-    if (wm != 0 && (threadIdx.x & 63u) == 0) atomicAdd(&totals->n_wide_entries, (unsigned long long)__popcll(wm));
 }
 
 // One wave per entry x.  Its pairs are the columns of its own row (partners above x; only if x is one of the launch slots) and the
@@ -84,7 +81,7 @@ __global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, c
 __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint32_t *__restrict__ meta, QMap Q, uint32_t nq,
                                                        uint32_t *__restrict__ list, unsigned long long list_cap, NNChunk *__restrict__ chunks, unsigned long long chunks_cap,
                                                        uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min,
-                                                       int32_t force_narrow)
+                                                       int32_t class_mode)
 {
     __shared__ uint32_t stage[4][NN_STAGE];
     __shared__ uint32_t s_small[4], s_filtered[4], s_kept[4];
@@ -110,19 +107,27 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
     const uint32_t sx = nn_meta_score(mx);
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
     uint32_t *st = stage[wave];
-    uint32_t fill = 0, filtered = 0, kept = 0;
-    const bool narrow = nn_narrow_mode((unsigned long long)__builtin_amdgcn_readfirstlane((int)(uint32_t)totals->n_wide_entries), S.n, force_narrow);
-    if (blockIdx.x == 0 && threadIdx.x == 0) totals->narrow = narrow ? 1ull : 0ull;
-    auto emit_chunk = [&]() {
+    // the staging buffer holds both classes: the 64-row class grows from its front (fill), the 32-row class from its back (fill_n)
+    uint32_t fill = 0, fill_n = 0, filtered = 0, kept = 0;
+    // one class leaves as a chunk: the 64-row chunks in chunks[0 .. chunks_cap), the 32-row chunks in chunks[chunks_cap .. 2 chunks_cap)
+    // (merged: what is left of the 32-row class leaves together with the 64-row class, as a 64-row chunk)
+    auto emit_chunk = [&](bool narrow_class, bool merged = false) {
+        const uint32_t cnt = merged ? fill + fill_n : narrow_class ? fill_n : fill;
         unsigned long long base = 0, ci = 0;
-        if (lane == 0) { base = atomicAdd(&totals->n_list, (unsigned long long)fill); ci = atomicAdd(&totals->n_chunks, 1ull); }
+        if (lane == 0) {
+            base = atomicAdd(&totals->n_list, (unsigned long long)cnt);
+            ci = atomicAdd(narrow_class ? &totals->n_chunks_narrow : &totals->n_chunks, 1ull);
+            if (narrow_class) atomicAdd(&totals->n_narrow_listed, (unsigned long long)cnt);
+        }
         base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
         ci = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ci >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ci);
-        if (base + fill <= list_cap && ci < chunks_cap) {
-            for (uint32_t i = (uint32_t)lane; i < fill; i += 64) list[base + i] = st[i];
-            if (lane == 0) { NNChunk ch; ch.slot = x; ch.count = fill; ch.begin = base; chunks[ci] = ch; }
+        if (base + cnt <= list_cap && ci < chunks_cap) {
+            if (narrow_class) { for (uint32_t i = (uint32_t)lane; i < cnt; i += 64) list[base + i] = st[NN_STAGE - 1 - i]; }
+            else { for (uint32_t i = (uint32_t)lane; i < cnt; i += 64) list[base + i] = i < fill ? st[i] : st[NN_STAGE - 1 - (i - fill)]; }
+            if (lane == 0) { NNChunk ch; ch.slot = x; ch.count = cnt; ch.begin = base; chunks[(narrow_class ? chunks_cap : 0ull) + ci] = ch; }
         } else if (lane == 0) atomicOr(&totals->overflow, 1ull);
-        fill = 0;
+        if (narrow_class || merged) fill_n = 0;
+        if (!narrow_class) fill = 0;
     };
     constexpr int U = 8;                         // batches of 64 partners per iteration: their loads are independent
     for (int side = 0; side < 2; ++side) {
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
                 // owner: larger hub score, ties to the lower index (side 0: x is the lower end)
                 const bool mine = accept && (side == 0 ? sy_u <= sx : sx > sy_u);
                 if (side == 0) { filtered += (uint32_t)__popcll(__ballot(cand && !accept)); kept += (uint32_t)__popcll(__ballot(accept)); }
-                // narrow mode: the (few) pairs with a larger threshold go straight to the pair arrays
-                const bool wide = mine && narrow && k > NN_NARROW_K;
+                // class mode +1: the pairs with a threshold above the 32-row form's go straight to the pair arrays
+                const bool wide = mine && class_mode > 0 && k > NN_NARROW_K;
                 const uint64_t wm = __ballot(wide);
                 if (wm != 0) {
                     const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(wm));
@@ -175,17 +180,27 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
                         pa[at] = x; pb[at] = y[u];
                     }
                 }
-                const uint64_t am = __ballot(mine && !wide);
-                if (am == 0) continue;                                   // wave-uniform
-                if (mine && !wide) st[fill + (uint32_t)__popcll(am & lt_mask)] = y[u] | (xq ? 0x40000000u : 0u) | (yq ? 0x80000000u : 0u);
+                const bool keep = mine && !wide;
+                const bool to_narrow = keep && class_mode >= 0 && k <= NN_NARROW_K;
+                const uint64_t am = __ballot(keep && !to_narrow), an = __ballot(to_narrow);
+                if ((am | an) == 0) continue;                            // wave-uniform
+                const uint32_t word = y[u] | (xq ? 0x40000000u : 0u) | (yq ? 0x80000000u : 0u);
+                if (keep && !to_narrow) st[fill + (uint32_t)__popcll(am & lt_mask)] = word;
+                if (to_narrow) st[NN_STAGE - 1 - (fill_n + (uint32_t)__popcll(an & lt_mask))] = word;
                 fill += (uint32_t)__popcll(am);
-                if (fill >= NN_LIST_CHUNK) emit_chunk();
+                fill_n += (uint32_t)__popcll(an);
+                if (fill + fill_n >= NN_LIST_CHUNK) emit_chunk(fill_n > fill);          // the buffer is full: its larger class leaves (>= half a chunk)
             }
         }
     }
-    if (fill >= list_min) emit_chunk();
+    // the end of the entry's pairs: a class with enough pairs leaves as a chunk of its own; too few of the 32-row class join the 64-row
+    // class (its kernel takes any threshold) before that class is judged
+    if (fill_n >= list_min) emit_chunk(true);
+    if (fill + fill_n >= list_min) emit_chunk(false, true);
+    // what is left of both classes goes to the pair arrays (the pair-per-lane kernel takes any threshold)
+    const uint32_t rest = fill + fill_n;
     // what is left goes to the pair arrays: one allocation per workgroup
-    if (lane == 0) { s_small[wave] = fill; s_filtered[wave] = filtered; s_kept[wave] = kept; }
+    if (lane == 0) { s_small[wave] = rest; s_filtered[wave] = filtered; s_kept[wave] = kept; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t tot = s_small[0] + s_small[1] + s_small[2] + s_small[3];
@@ -200,10 +215,10 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
         if (ksum) atomicAdd(&totals->n_pairs, (unsigned long long)ksum);
     }
     __syncthreads();
-    if (fill && s_base != ~0ull) {
+    if (rest && s_base != ~0ull) {
         unsigned long long base = s_base;
         for (int w = 0; w < wave; ++w) base += s_small[w];
-        for (uint32_t i = (uint32_t)lane; i < fill; i += 64) { pa[base + i] = x; pb[base + i] = st[i] & 0x3fffffffu; }
+        for (uint32_t i = (uint32_t)lane; i < rest; i += 64) { pa[base + i] = x; pb[base + i] = (i < fill ? st[i] : st[NN_STAGE - 1 - (i - fill)]) & 0x3fffffffu; }
     }
 }
 

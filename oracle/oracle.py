@@ -281,9 +281,14 @@ def cigar_to_seq(cigar, query, ref):
     return "".join(q_parts), "".join(r_parts)
 
 
+TIE_POLICY = 0          # the trace-back tie rules every SWM restatement below uses unless told otherwise (scripts/tie_exposure.py varies it)
+
+
 def parasail_alignment(s1, s2, i, j, x_acc="", y_acc="", match_score=2, mismatch_penalty=-3,
-                       opening_penalty=2, gap_ext=0, tie_policy=0):
-    """SWM:64-86 (tie_policy is the oracle's extra knob, see isocon_oracle.c)."""
+                       opening_penalty=2, gap_ext=0, tie_policy=None):
+    """SWM:64-86 (tie_policy is the oracle's extra knob, see isocon_oracle.c; None = the module's TIE_POLICY)."""
+    if tie_policy is None:
+        tie_policy = TIE_POLICY
     r = sg_trace(s1, s2, match_score, mismatch_penalty, opening_penalty, gap_ext, tie_policy)
     s1_aln, s2_aln = cigar_to_seq(r["cigar"], s1, s2)
     mismatches = sum(1 for a, b in zip(s1_aln, s2_aln) if a != b and a != "-" and b != "-")

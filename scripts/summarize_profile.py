@@ -67,8 +67,11 @@ def classify(rows):
     # k_nn_scan_refill (tables), k_ed_lanes<true> (entries with few pairs)
     lanes = [r for r in rows if "k_ed_lanes<true>" in r[1]]
     for r in rows:
-        if "k_nn_scan_refill" in r[1] and "nn_main" not in cls:
+        # the two table launches of a step: the 64-row class (<.., false>) and the 32-row class (<.., true>)
+        if "k_nn_scan_refill" in r[1] and "true>" not in r[1] and "nn_main" not in cls:
             cls["nn_main"] = [r]
+        if "k_nn_scan_refill" in r[1] and "true>" in r[1] and "nn_main_narrow" not in cls:
+            cls["nn_main_narrow"] = [r]
         if "k_qgram_mm" in r[1] and "nn_bound" not in cls:
             cls["nn_bound"] = [r]
         if "k_nn_survivors" in r[1] and "nn_lists" not in cls:
@@ -111,7 +114,10 @@ bj = os.path.join(out, "bench_sq_%s.json" % tag)
 if os.path.exists(bj) and "nn_main" in counters:
     try:
         line = [ln for ln in open(bj) if ln.startswith("{")][-1]
-        counters["nn_main"]["wave_columns"] = json.loads(line)["roofline"]["wave_columns_this_run"]
+        rl = json.loads(line)["roofline"]
+        counters["nn_main"]["wave_columns"] = rl["wave_columns_this_run"]
+        if "nn_main_narrow" in counters and rl.get("narrow_pass"):
+            counters["nn_main_narrow"]["wave_columns"] = rl["narrow_pass"]["wave_columns_this_run"]
     except Exception as ex:
         print("no wave_columns:", ex)
 lines.append("HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE doubled: gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md)")

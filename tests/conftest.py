@@ -41,3 +41,22 @@ def list_to_dd(lst):
 def ordered(dd):
     """dict-of-dict -> nested list, for comparisons that include key order."""
     return [[k1, list(inner.items())] for k1, inner in dd.items()]
+
+
+def g17(which):
+    """The whole-graph fixture of a BASELINE configuration (tests/golden/make_golden_g17.py: every row recomputed with the oracle's
+    statement of the reference loop NNG:110-198 on the CPU) and the entries it belongs to, in the order every test uses:
+    (seqs, best int32[n], row_ptr int64[n + 1], cols uint32[])."""
+    import hashlib
+    import numpy as np
+    from isocon_amd import synth
+    args = {"c2": (5000, 1500, 3, 20001), "c3": (50000, 2500, 10, 30001)}[which]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g17_%s_graph.npz" % which))
+    accs, seqs, _ = synth.make_reads(*args)
+    seqs = sorted(dict.fromkeys(seqs), key=len)
+    h = hashlib.sha1()
+    for x in seqs:
+        h.update(x.encode())
+        h.update(b"\n")
+    assert h.hexdigest() == str(z["inputs_sha1"]), "the synthetic generator no longer produces the set the fixture was made from"
+    return seqs, z["best"], z["row_ptr"], z["cols"]

@@ -154,3 +154,16 @@ def test_sliced_entry_points_return_the_rows_of_the_whole_graph():
         for start in range(0, len(lst), 20):
             merged.update(NNG.get_nearest_neighbors_2set(lst[start:start + 20], start, lst, set(C), 2 ** 32))
         assert ordered(merged) == ordered(list_to_dd(case["graph"]))
+
+
+def test_c2_every_row_equals_the_reference_loop_fixture(c2):
+    """all 5 000 rows of configs[1] against tests/golden/g17_c2_graph.npz (every row recomputed with the oracle's reference loop)"""
+    from conftest import g17
+    S, graph, isolated = c2
+    seqs, accs, best, rows, cols = _graph_arrays(S, graph)
+    fseqs, fbest, frow_ptr, fcols = g17("c2")
+    assert fseqs == seqs
+    assert (best == fbest).all()
+    counts = np.bincount(rows, minlength=len(seqs)) if len(rows) else np.zeros(len(seqs), np.int64)
+    assert (np.concatenate([[0], np.cumsum(counts)]) == frow_ptr).all()
+    assert (cols == fcols).all()          # (rows come out in key order, neighbours in the reference's insertion order)

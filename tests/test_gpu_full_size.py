@@ -62,6 +62,21 @@ def test_c3_sampled_rows_equal_reference_loop(c3):
         assert (e == best[i]).all()
 
 
+def test_c3_every_row_equals_the_reference_loop_fixture(c3):
+    """ALL 50 000 rows -- neighbours, their order, the distance -- against tests/golden/g17_c3_graph.npz, whose rows were each
+    recomputed with the oracle's statement of the reference loop (NNG:110-198) on the CPU; and the digest bench.py asserts."""
+    import bench
+    from conftest import g17
+    seqs, st, best, row_ptr, cols, stats = c3
+    fseqs, fbest, frow_ptr, fcols = g17("c3")
+    assert fseqs == seqs
+    assert (np.diff(frow_ptr) > 0).all() and (fbest > 0).all()
+    assert (best == fbest).all()
+    assert (row_ptr == frow_ptr).all()
+    assert (cols == fcols).all()
+    assert bench.graph_digest(best, row_ptr, cols) == bench.EXPECTED_GRAPH_DIGEST_C3
+
+
 def test_c3_alignments_roundtrip(c3):
     """SW on 256 (read, NN) pairs at full length: un-gapped alignment == input (correction_module.py:273-275),
     counts consistent, score identity."""

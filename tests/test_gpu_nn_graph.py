@@ -337,8 +337,9 @@ def test_device_resident_phases_equal_the_single_call():
 
 
 def test_narrow_mode_on_reads_with_few_errors(monkeypatch):
-    """Reads whose nearest neighbour is a few edits away: the listed launch picks its 32-row form by itself (thresholds <= 31; the few
-    pairs above go one per lane).  Same graph as with the 64-row tables, and the rows of some reads against the reference loop."""
+    """Reads whose nearest neighbour is a few edits away: the list builder files nearly every pair under the 32-row class (thresholds
+    <= 31), the few pairs above go to 64-row chunks or one per lane.  Same graph as with every pair on 64 rows (ISOCON_NN_NARROW=0) and
+    as with the pairs above 31 forced out of the lists (=1), and the rows of some reads against the reference loop."""
     from isocon_amd import synth
     from isocon_amd.store import SeqStore
     from oracle import oracle as O
@@ -347,12 +348,17 @@ def test_narrow_mode_on_reads_with_few_errors(monkeypatch):
     st = SeqStore(seqs)
     try:
         got = st.nn_graph()
-        assert got[3]["pairs_lanes"] > 0 and got[3]["pairs_wide_to_lanes"] * 5 < got[3]["pairs_evaluated"]
+        assert got[3]["pairs_narrow"] > 0 and got[3]["narrow_columns"] > 0 and got[3]["narrow_kernel_ms"] > 0, got[3]
+        assert got[3]["narrow_kernel_ms"] <= got[3]["scan_kernel_ms"] and got[3]["narrow_columns"] <= got[3]["cells_columns"]
         monkeypatch.setenv("ISOCON_NN_NARROW", "0")
         wide = st.nn_graph()
+        monkeypatch.setenv("ISOCON_NN_NARROW", "1")
+        forced = st.nn_graph()
         monkeypatch.delenv("ISOCON_NN_NARROW")
-        assert wide[3]["pairs_wide_to_lanes"] == 0
+        assert wide[3]["pairs_narrow"] == 0 and wide[3]["narrow_columns"] == 0 and wide[3]["pairs_wide_to_lanes"] == 0
+        assert forced[3]["pairs_narrow"] > 0
         assert all((x == y).all() for x, y in zip(got[:3], wide[:3]))
+        assert all((x == y).all() for x, y in zip(got[:3], forced[:3]))
         assert np.median(got[0][got[0] >= 0]) <= 31
         best, row_ptr, cols = got[:3]
         packed = O.pack(seqs)

@@ -90,3 +90,31 @@ def test_sg_trace_score_and_alignment_consistency():
                 qa, ra = O.cigar_to_seq(r["cigar"], a, b)
                 assert qa.replace("-", "") == a and ra.replace("-", "") == b and len(qa) == len(ra)
                 assert r["matches"] + r["mismatches"] + r["indels"] == len(qa)
+
+
+def test_g17_whole_graph_fixtures():
+    """tests/golden/g17_*_graph.npz (make_golden_g17.py): the inputs still hash to what the fixture was made from, the arrays are a
+    well-formed graph in the reference's insertion order, sampled rows equal the oracle loop again, and the C3 fixture's digest is
+    the constant bench.py asserts for its default workload."""
+    import os
+    import numpy as np
+    import bench
+    from conftest import g17
+    from oracle import oracle as O
+    for which in ("c2", "c3"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g17_%s_graph.npz" % which)
+        assert os.path.exists(path), path
+        seqs, best, row_ptr, cols = g17(which)
+        n = len(seqs)
+        assert len(best) == n and len(row_ptr) == n + 1 and row_ptr[0] == 0 and row_ptr[-1] == len(cols)
+        rows = np.repeat(np.arange(n), np.diff(row_ptr))
+        off = np.abs(cols.astype(np.int64) - rows)
+        same = rows[1:] == rows[:-1]
+        assert ((off[1:] > off[:-1]) | ((off[1:] == off[:-1]) & (cols[1:] > cols[:-1])))[same].all()
+        packed = O.pack(seqs)
+        conv = np.zeros(n, np.uint8)
+        for i in np.random.default_rng(17).choice(n, 6 if which == "c3" else 40, replace=False).tolist():
+            rp, c, e, _ = O.nn_1set(seqs, conv, i, 1, packed=packed)
+            assert cols[row_ptr[i]:row_ptr[i + 1]].tolist() == c.tolist() and (e == best[i]).all()
+        if which == "c3":
+            assert bench.graph_digest(best, row_ptr, cols) == bench.EXPECTED_GRAPH_DIGEST_C3
