@@ -256,6 +256,23 @@ int isocon_msa_correct(const uint8_t *matrix, uint32_t n_rows, uint32_t n_cols, 
 int isocon_hw_pairs(isocon_store *s, const uint32_t *q, const uint32_t *t, const int32_t *k, uint64_t n_pairs,
                     int32_t *out, float *kernel_ms);
 
+/*
+ * Greedy partition of the nearest-neighbour graph into consensus centres and their members, on integer ids: what
+ * get_partitions_no_copy (modules/partitions.py:301-413, called by partition_strings :416-593 on nx.reverse(G_star)) and
+ * partition_highest_reachable_with_edge_degrees (modules/end_invariant_functions.py:405-533; nbr_tiebreak = 0) compute on networkx
+ * graphs keyed by the sequences.  Host-only (no GPU work): the graph is the edge list the NN search returns.
+ *   n nodes, degree[i] = multiplicity of sequence i (graphs.py:37-51), edges (edge_a[e] -> edge_b[e]): b is a nearest neighbour of a
+ *   (an edge of G*), rank[i] = position of sequence i in the lexicographic order of the sequences (the reference breaks ties with
+ *   `m < centre` on the strings), nbr_tiebreak != 0: between start nodes of equal reachable weight prefer more direct in-neighbours.
+ * Output, in the reference's extraction order (components by size, largest first): out_centre[p], out_weight[p] = total multiplicity
+ * of partition p, its other members out_members[out_member_ptr[p] .. out_member_ptr[p + 1]) (any order: the reference returns sets).
+ * Capacities: out_centre / out_weight n entries, out_member_ptr n + 1, out_members n.  Deterministic where the reference depends on
+ * PYTHONHASHSEED (ties between different reachable sets of equal weight: SURVEY.md F6).
+ */
+int isocon_partition_ids(uint32_t n, const int32_t *degree, uint64_t n_edges, const uint32_t *edge_a, const uint32_t *edge_b,
+                         const uint32_t *rank, int32_t nbr_tiebreak, uint32_t *out_centre, int64_t *out_weight,
+                         uint64_t *out_member_ptr, uint32_t *out_members, uint32_t *n_parts);
+
 #ifdef __cplusplus
 }
 #endif

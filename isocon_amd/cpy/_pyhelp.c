@@ -154,7 +154,114 @@ static PyObject *pair_ids(PyObject *self, PyObject *args)
     return PyLong_FromSsize_t(n);
 }
 
+/* rank_strings(seqs: list[str] (ASCII), out_addr: int (uint32[len(seqs)])) -> None: out[i] = position of seqs[i] in sorted(seqs)
+ * (Python's str order: bytewise, a proper prefix first; equal strings in index order, like the stable sorted()).  The partition of the
+ * nearest-neighbour graph breaks its ties with the reference's `m < centre` on the sequences (partitions.py:346-361): 50 000 x 2.5 kb
+ * strings sorted here in ~10 ms instead of 80 ms of key-function calls. */
+typedef struct { const char *p; const char *key; Py_ssize_t len; uint32_t idx; } rank_item;
+
+/* The strings sit all over the heap: a comparison of two of them is two cache misses.  Their first RANK_KEY bytes are copied into one
+ * contiguous block first (in the threads), most comparisons are decided there (reads of one isoform differ at their first error). */
+#define RANK_KEY 128
+
+static int rank_cmp(const void *a, const void *b)
+{
+    const rank_item *x = (const rank_item *)a, *y = (const rank_item *)b;
+    const Py_ssize_t m = x->len < y->len ? x->len : y->len;
+    if (x->key && y->key) {
+        const Py_ssize_t mk = m < RANK_KEY ? m : RANK_KEY;
+        const int ck = mk ? memcmp(x->key, y->key, (size_t)mk) : 0;
+        if (ck) return ck;
+        if (m <= RANK_KEY) {
+            if (x->len != y->len) return x->len < y->len ? -1 : 1;
+            return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+        }
+    }
+    const int c = m ? memcmp(x->p, y->p, (size_t)m) : 0;
+    if (c) return c;
+    if (x->len != y->len) return x->len < y->len ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+typedef struct { rank_item *items; size_t n; } rank_job;
+
+static void *rank_sort_worker(void *arg)
+{
+    const rank_job *j = (const rank_job *)arg;
+    for (size_t i = 0; i < j->n; ++i)          /* (key points into the block; the bytes behind a short string stay unread) */
+        if (j->items[i].key) memcpy((char *)j->items[i].key, j->items[i].p, (size_t)(j->items[i].len < RANK_KEY ? j->items[i].len : RANK_KEY));
+    qsort(j->items, j->n, sizeof(rank_item), rank_cmp);
+    return NULL;
+}
+
+static void rank_merge(const rank_item *a, size_t na, const rank_item *b, size_t nb, rank_item *out)
+{
+    size_t i = 0, j = 0, k = 0;
+    while (i < na && j < nb) out[k++] = rank_cmp(&b[j], &a[i]) < 0 ? b[j++] : a[i++];
+    while (i < na) out[k++] = a[i++];
+    while (j < nb) out[k++] = b[j++];
+}
+
+static PyObject *rank_strings(PyObject *self, PyObject *args)
+{
+    PyObject *seqs;
+    unsigned long long oa;
+    if (!PyArg_ParseTuple(args, "OK", &seqs, &oa)) return NULL;
+    if (!PyList_Check(seqs)) { PyErr_SetString(PyExc_TypeError, "rank_strings: a list is required"); return NULL; }
+    const Py_ssize_t n = PyList_GET_SIZE(seqs);
+    uint32_t *out = (uint32_t *)(uintptr_t)oa;
+    rank_item *items = (rank_item *)malloc((size_t)(n > 0 ? n : 1) * sizeof(rank_item));
+    if (!items) return PyErr_NoMemory();
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *s = PyList_GET_ITEM(seqs, i);
+        if (!PyUnicode_Check(s) || PyUnicode_READY(s) < 0 || !PyUnicode_IS_ASCII(s)) {
+            free(items);
+            if (!PyErr_Occurred()) PyErr_Format(PyExc_TypeError, "rank_strings: element %zd is not an ASCII str", i);
+            return NULL;
+        }
+        items[i].p = (const char *)PyUnicode_1BYTE_DATA(s);
+        items[i].len = PyUnicode_GET_LENGTH(s);
+        items[i].idx = (uint32_t)i;
+        items[i].key = NULL;
+    }
+    rank_item *tmp = NULL;
+    char *keys = NULL;
+    Py_BEGIN_ALLOW_THREADS
+    const int n_thr = n >= 8192 ? 4 : 1;          /* four sorted runs in four threads, then two rounds of merging */
+    if (n_thr > 1) {
+        tmp = (rank_item *)malloc((size_t)n * sizeof(rank_item));
+        keys = (char *)malloc((size_t)n * RANK_KEY);
+        if (tmp && keys) for (Py_ssize_t i = 0; i < n; ++i) items[i].key = keys + (size_t)i * RANK_KEY;          /* (filled by the workers) */
+    }
+    if (n_thr == 1 || !tmp || !keys) qsort(items, (size_t)n, sizeof(rank_item), rank_cmp);
+    else {
+        rank_job jobs[4];
+        pthread_t th[4];
+        int started[4];
+        Py_ssize_t cut[5];
+        for (int t = 0; t <= 4; ++t) cut[t] = n * t / 4;
+        for (int t = 0; t < 4; ++t) {
+            jobs[t].items = items + cut[t]; jobs[t].n = (size_t)(cut[t + 1] - cut[t]);
+            started[t] = pthread_create(&th[t], NULL, rank_sort_worker, &jobs[t]) == 0;
+        }
+        for (int t = 0; t < 4; ++t) {
+            if (started[t]) pthread_join(th[t], NULL);
+            else rank_sort_worker(&jobs[t]);
+        }
+        rank_merge(items + cut[0], (size_t)(cut[1] - cut[0]), items + cut[1], (size_t)(cut[2] - cut[1]), tmp + cut[0]);
+        rank_merge(items + cut[2], (size_t)(cut[3] - cut[2]), items + cut[3], (size_t)(cut[4] - cut[3]), tmp + cut[2]);
+        rank_merge(tmp + cut[0], (size_t)(cut[2] - cut[0]), tmp + cut[2], (size_t)(cut[4] - cut[2]), items);
+    }
+    for (Py_ssize_t r = 0; r < n; ++r) out[items[r].idx] = (uint32_t)r;
+    Py_END_ALLOW_THREADS
+    free(tmp);
+    free(keys);
+    free(items);
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
+    {"rank_strings", rank_strings, METH_VARARGS, "rank of every string of a list in the sorted order of the list"},
     {"pair_ids", pair_ids, METH_VARARGS, "ids of the members of a list of pairs"},
     {"csr_to_dict", csr_to_dict, METH_VARARGS, "dict of dicts from the CSR arrays of a nearest-neighbour graph"},
     {"str_pointers", str_pointers, METH_VARARGS, "addresses and lengths of a list of ASCII str"},

@@ -19,6 +19,7 @@
 #include "nn_list.hpp"
 #include "nn_finalize.hpp"
 #include "nn_finalize_host.hpp"
+#include "partition_host.hpp"
 #include "sg.hpp"
 #include "msa.hpp"
 #include "hw.hpp"
@@ -744,3 +745,11 @@ extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, cons
 #include "sg_host.inc"
 #include "msa_host.inc"
 #include "hw_host.inc"
+
+extern "C" int isocon_partition_ids(uint32_t n, const int32_t *degree, uint64_t n_edges, const uint32_t *edge_a, const uint32_t *edge_b,
+                                    const uint32_t *rank, int32_t nbr_tiebreak, uint32_t *out_centre, int64_t *out_weight,
+                                    uint64_t *out_member_ptr, uint32_t *out_members, uint32_t *n_parts)
+{
+    if (!out_member_ptr || !n_parts || (n && (!degree || !rank || !out_centre || !out_weight || !out_members)) || (n_edges && (!edge_a || !edge_b))) return ISOCON_E_ARG;
+    return partition_ids_impl(n, degree, n_edges, edge_a, edge_b, rank, nbr_tiebreak, out_centre, out_weight, out_member_ptr, out_members, n_parts);
+}

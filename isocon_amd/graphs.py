@@ -2,12 +2,17 @@
 
 Mirror of /root/reference/modules/graphs.py:29-82 (`construct_exact_nearest_neighbor_graph`): same signature, same
 node/edge attributes (`degree`, `edit_distance`), same "already converged" handling.  The all-pairs alignment behind it
-runs on the GPU through isocon_amd.nearest_neighbor_graph; everything else is bookkeeping on the host, as in the
-reference.  The graph container is networkx.DiGraph, which the reference's callers expect (requirements.txt:3).
+runs on the GPU through isocon_amd.nearest_neighbor_graph.  The reference builds a networkx.DiGraph keyed by the 2.5 kb
+sequences (requirements.txt:3) -- 0.5 s of dict work at 50 000 reads, of which its callers on the hot path read exactly one
+thing, G.nodes[seq]["degree"] (isocon_get_candidates.py:64).  Here the graph is kept as integer arrays (what the partition
+routine isocon_partition_ids consumes) behind an object that answers `.nodes` itself and turns into the very networkx graph
+the reference would have built -- same node order, same edge order, same attributes -- the first time anything else is asked.
 """
 from __future__ import annotations
 
-from collections import defaultdict
+from collections import Counter
+
+import numpy as np
 
 from . import nearest_neighbor_graph
 
@@ -20,29 +25,108 @@ def _nx():
     return nx
 
 
+class _Nodes(object):
+    """G.nodes of a LazyDiGraph: G.nodes[seq] -> {"degree": multiplicity}, G.nodes() / iteration -> the sequences in insertion order"""
+
+    def __init__(self, names, degree):
+        self._names = names
+        self._degree = degree
+        self._index = None
+
+    def _idx(self):
+        if self._index is None:
+            self._index = {s: i for i, s in enumerate(self._names)}
+        return self._index
+
+    def __getitem__(self, seq):
+        return {"degree": self._degree[self._idx()[seq]]}
+
+    def __call__(self, data=False):
+        if data:
+            return [(s, {"degree": d}) for s, d in zip(self._names, self._degree)]
+        return self
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def __contains__(self, seq):
+        return seq in self._idx()
+
+
+class LazyDiGraph(object):
+    """G_star as arrays: names[i] (unique sequences in first-appearance order), degree[i], edges ea[e] -> eb[e] with distance ed[e]
+    (ids into names; in the order the reference inserts them: rows in length-sorted order, neighbours in the NN order).  `.nodes` is
+    answered from the arrays; any other attribute materialises the networkx.DiGraph of graphs.py:37-69 and is forwarded to it."""
+
+    def __init__(self, names, degree, ea, eb, ed):
+        self.names, self.degree, self.ea, self.eb, self.ed = names, degree, ea, eb, ed
+        self.nodes = _Nodes(names, degree)
+        self._g = None
+
+    def to_networkx(self):
+        if self._g is None:
+            nx = _nx()
+            G = nx.DiGraph()
+            G.add_nodes_from((seq, {"degree": d}) for seq, d in zip(self.names, self.degree))
+            names = self.names
+            G.add_edges_from((names[a], names[b], {"edit_distance": d}) for a, b, d in zip(self.ea.tolist(), self.eb.tolist(), self.ed.tolist()))
+            self._g = G
+        return self._g
+
+    def __getattr__(self, name):          # (only called for attributes this object does not have)
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self.to_networkx(), name)
+
+    def __getitem__(self, key):
+        return self.to_networkx()[key]
+
+    def __iter__(self):
+        return iter(self.names)
+
+    def __len__(self):
+        return len(self.names)
+
+    def __contains__(self, seq):
+        return seq in self.nodes
+
+
 def construct_exact_nearest_neighbor_graph(S, params):
     """graphs.py:29-82.  S: {acc: seq} (not necessarily unique).  Returns (G, converged): a node per unique sequence
     with weight `degree` = multiplicity; an edge s1 -> s2 (attribute `edit_distance`) for every nearest neighbour s2 of
-    a sequence s1 of multiplicity 1."""
-    nx = _nx()
-    predicted_seq_to_acc = defaultdict(list)
-    for acc, seq in S.items():
-        predicted_seq_to_acc[seq].append(acc)
-
-    G = nx.DiGraph()
-    G.add_nodes_from((seq, {"degree": len(list_acc)}) for seq, list_acc in predicted_seq_to_acc.items())
-    has_converged = set(seq for seq, list_acc in predicted_seq_to_acc.items() if len(list_acc) > 1)
-    converged = len(has_converged) == len(predicted_seq_to_acc)          # no sequence of multiplicity 1 left
+    a sequence s1 of multiplicity 1.  G is a LazyDiGraph (see above)."""
+    counts = Counter(S.values())                                   # multiplicities (graphs.py:37-51)
+    names = list({seq: None for seq in S.values()})                 # unique sequences, first appearance first (node order of the reference)
+    n = len(names)
+    degree = list(map(counts.__getitem__, names))
+    deg = np.asarray(degree, dtype=np.int64)
+    converged = bool((deg > 1).all())                               # no sequence of multiplicity 1 left
+    empty = np.zeros(0, dtype=np.int64)
     if converged:
-        return G, converged
-
-    unique_strings = {seq: acc for acc, seq in S.items()}          # last accession of a sequence wins (graphs.py:56)
-    S_prime = {acc: seq for seq, acc in unique_strings.items()}
-    edges, _isolated = nearest_neighbor_graph.compute_nearest_neighbor_graph(S_prime, has_converged, params)
-    G.add_edges_from((S[s1_acc], S[s2_acc], {"edit_distance": ed})
-                     for s1_acc, nbrs in edges.items() if S[s1_acc] not in has_converged
-                     for s2_acc, ed in nbrs.items())
-    return G, converged
+        return LazyDiGraph(names, degree, empty, empty, empty), converged
+    # NNG.compute_nearest_neighbor_graph: unique sequences, stable sort by length (NNG:243-246)
+    lens = np.fromiter(map(len, names), dtype=np.int64, count=n)
+    order = np.argsort(lens, kind="stable")
+    seqs_sorted = [names[i] for i in order.tolist()]
+    conv = (deg[order] > 1).astype(np.uint8)
+    if not hasattr(nearest_neighbor_graph, "nn_1set_arrays"):
+        # a stand-in with the reference's interface only (the tests run these callers on the CPU oracle): through the dict of dicts
+        unique_strings = {seq: acc for acc, seq in S.items()}          # last accession of a sequence wins (graphs.py:56)
+        S_prime = {acc: seq for seq, acc in unique_strings.items()}
+        has_converged = set(s for s, d in zip(names, degree) if d > 1)
+        edges, _isolated = nearest_neighbor_graph.compute_nearest_neighbor_graph(S_prime, has_converged, params)
+        index = {s: i for i, s in enumerate(names)}
+        trip = [(index[S[a1]], index[S[a2]], ed) for a1, nbrs in edges.items() if S[a1] not in has_converged for a2, ed in nbrs.items()]
+        arr = np.asarray(trip, dtype=np.int64).reshape(-1, 3)
+        return LazyDiGraph(names, degree, arr[:, 0].copy(), arr[:, 1].copy(), arr[:, 2].copy()), converged
+    best, row_ptr, cols = nearest_neighbor_graph.nn_1set_arrays(seqs_sorted, conv, params.neighbor_search_depth)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(np.asarray(row_ptr, dtype=np.int64)))
+    keep = conv[rows] == 0                                          # (graphs.py:61-69 skips converged s1; they have no rows anyway)
+    rows, c = rows[keep], np.asarray(cols, dtype=np.int64)[keep]
+    return LazyDiGraph(names, degree, order[rows], order[c], np.asarray(best, dtype=np.int64)[rows]), converged
 
 
 def construct_exact_2set_nearest_neighbor_bipartite_graph(X, C, X_file, C_file, params):

@@ -97,10 +97,11 @@ def _rows_to_dict(accs, is_query, best, row_ptr, cols):
     return out
 
 
-def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
-    seqs = [s for s, _ in seq_to_acc_list_sorted]
-    accs = [a for _, a in seq_to_acc_list_sorted]
-    conv = np.fromiter((1 if s in has_converged else 0 for s in seqs), dtype=np.uint8, count=len(seqs)) if has_converged else np.zeros(len(seqs), dtype=np.uint8)
+def nn_1set_arrays(seqs, conv, depth):
+    """The exact 1-set graph of the length-sorted unique sequences `seqs` as arrays: (best int32[n], row_ptr int64[n + 1], cols uint32[]),
+    conv[i] != 0 = converged (no row of its own, NNG:120-123).  The store is remembered for the pair-list wrappers that follow
+    (EAM / SWM are called next on pairs of these very sequences).  Used by _nn_1set (dict shapes of NNG) and by
+    isocon_amd.partitions.partition_strings, which works on the ids directly."""
     with perf_log.call("nearest_neighbor_graph.1set", sequences=len(seqs)) as rec:
         st = SeqStore(seqs)
         try:
@@ -109,9 +110,17 @@ def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
             st.close()
             raise
         rec.add(edges=int(len(cols)), **{k: v for k, v in stats.items()})
-    remember(st, seqs)      # EAM / SWM are called next on pairs of these very sequences
+    remember(st, seqs)
     LAST_STATS.clear()
     LAST_STATS.update(stats)
+    return best, row_ptr, cols
+
+
+def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
+    seqs = [s for s, _ in seq_to_acc_list_sorted]
+    accs = [a for _, a in seq_to_acc_list_sorted]
+    conv = np.fromiter((1 if s in has_converged else 0 for s in seqs), dtype=np.uint8, count=len(seqs)) if has_converged else np.zeros(len(seqs), dtype=np.uint8)
+    best, row_ptr, cols = nn_1set_arrays(seqs, conv, depth)
     # every entry gets a key; converged ones an empty dict (NNG:120-123)
     return _rows_to_dict(accs, np.ones(len(accs), dtype=bool), best, row_ptr, cols)
 

@@ -6,10 +6,66 @@ order-independent except when two different reachable sets tie in weight.  This 
 is deterministic: candidates are ranked by (weight of the reachable set, number of direct in-neighbours, sequence) and
 all members of a strongly connected top set compete as its representative.  tests/golden/g7_partitions.json holds
 outputs of the reference itself (eight hash seeds, all agreeing) that this module must reproduce.
+
+The partition itself runs in native code on integer ids (isocon_partition_ids, csrc/partition_host.hpp: 50 000 nodes in a few
+milliseconds instead of 0.35 s of Python sets); `partition_ids_py` below is the same algorithm in Python, kept as the statement the
+native routine is tested against (tests/test_partition_native.py).  partition_strings never builds the reference's networkx
+graph: it hands the arrays of isocon_amd.graphs.LazyDiGraph straight to the routine.
 """
 from __future__ import annotations
 
-from . import graphs
+import ctypes
+
+import numpy as np
+
+from . import _lib, graphs
+
+
+def _string_ranks(names):
+    """rank[i] = position of names[i] in sorted(names) (the reference breaks ties with `m < centre` on the strings)"""
+    n = len(names)
+    H = _lib.pyhelp()
+    if H is not None and hasattr(H, "rank_strings") and isinstance(names, list):
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        try:
+            H.rank_strings(names, out.ctypes.data)
+            return out[:n]
+        except TypeError:          # (not str / not ASCII: accessions of the end-invariant graph are str too, but be general)
+            pass
+    rank = np.zeros(max(n, 1), dtype=np.uint32)
+    rank[sorted(range(n), key=names.__getitem__)] = np.arange(n, dtype=np.uint32)
+    return rank[:n]
+
+
+def partition_ids(n, degree, edges, names, nbr_tiebreak=True):
+    """get_partitions_no_copy on integer ids through the C ABI (isocon_partition_ids; host code of libisocon_hip.so).
+
+    n nodes, degree[i] = multiplicity, edges = (a[], b[]) arrays or [(a, b)]: a's nearest neighbour is b (an edge of G*),
+    names[i] = the sequence (only used to break ties the way the reference does, `m < centre`).
+    nbr_tiebreak: between start nodes of equal reachable weight prefer the one with more direct in-neighbours
+    (partitions.py:346-361); False = only the name decides (end_invariant_functions.py:461-470).
+    Returns [(centre, weight, members ndarray)] in the reference's extraction order (components by size, largest first)."""
+    L = _lib.load()
+    if isinstance(edges, tuple):
+        ea, eb = (np.ascontiguousarray(x, dtype=np.uint32) for x in edges)
+    else:
+        arr = np.asarray(edges, dtype=np.uint32).reshape(-1, 2)
+        ea, eb = np.ascontiguousarray(arr[:, 0]), np.ascontiguousarray(arr[:, 1])
+    deg = np.ascontiguousarray(degree, dtype=np.int32)
+    rank = np.ascontiguousarray(_string_ranks(names), dtype=np.uint32)
+    centre = np.zeros(max(n, 1), dtype=np.uint32)
+    weight = np.zeros(max(n, 1), dtype=np.int64)
+    ptr = np.zeros(n + 1, dtype=np.uint64)
+    members = np.zeros(max(n, 1), dtype=np.uint32)
+    n_parts = ctypes.c_uint32(0)
+    P = ctypes.POINTER
+    _lib.check(L.isocon_partition_ids(n, deg.ctypes.data_as(_lib.i32p), len(ea), ea.ctypes.data_as(_lib.u32p), eb.ctypes.data_as(_lib.u32p),
+                                      rank.ctypes.data_as(_lib.u32p), 1 if nbr_tiebreak else 0, centre.ctypes.data_as(_lib.u32p),
+                                      weight.ctypes.data_as(P(ctypes.c_int64)), ptr.ctypes.data_as(_lib.u64p), members.ctypes.data_as(_lib.u32p),
+                                      ctypes.byref(n_parts)), "isocon_partition_ids")
+    k = int(n_parts.value)
+    ptr = ptr.astype(np.int64)
+    return [(int(centre[p]), int(weight[p]), members[ptr[p]:ptr[p + 1]]) for p in range(k)]
 
 
 def _reach(start, succ, alive):
@@ -25,8 +81,8 @@ def _reach(start, succ, alive):
     return seen
 
 
-def partition_ids(n, degree, edges, names, nbr_tiebreak=True):
-    """Core of get_partitions_no_copy on integer ids.
+def partition_ids_py(n, degree, edges, names, nbr_tiebreak=True):
+    """The same partition in Python (the statement isocon_partition_ids is tested against; not used by the product path).
 
     n nodes, degree[i] = multiplicity, edges = [(a, b)]: a's nearest neighbour is b (an edge of G*; the search runs on
     the transpose, b -> a), names[i] = the sequence (only used to break ties the way the reference does, `m < centre`).
@@ -128,17 +184,21 @@ def partition_ids(n, degree, edges, names, nbr_tiebreak=True):
 
 
 def _partition_graph(G, transposed, nbr_tiebreak=True):
-    names = list(G.nodes())
-    idx = {s: i for i, s in enumerate(names)}
-    degree = [G.nodes[s]["degree"] for s in names]
-    if transposed:
-        edges = [(idx[b], idx[a]) for a, b in G.edges()]      # transpose edge a -> b  <=>  G* edge b -> a
+    if isinstance(G, graphs.LazyDiGraph) and not transposed:
+        names, degree, edges = G.names, G.degree, (G.ea, G.eb)
     else:
-        edges = [(idx[a], idx[b]) for a, b in G.edges()]
+        names = list(G.nodes())
+        idx = {s: i for i, s in enumerate(names)}
+        degree = [G.nodes[s]["degree"] for s in names]
+        if transposed:
+            edges = [(idx[b], idx[a]) for a, b in G.edges()]      # transpose edge a -> b  <=>  G* edge b -> a
+        else:
+            edges = [(idx[a], idx[b]) for a, b in G.edges()]
     M, partition = {}, {}
+    name_of = names.__getitem__
     for centre, weight, members in partition_ids(len(names), degree, edges, names, nbr_tiebreak):
         M[names[centre]] = weight
-        partition[names[centre]] = set(names[v] for v in members)
+        partition[names[centre]] = set(map(name_of, members.tolist()))
     return M, partition
 
 
@@ -150,16 +210,13 @@ def get_partitions_no_copy(G_transpose):
 
 
 def partition_strings(S, params):
-    """partitions.py:416-593.  Returns (G_star, partition, M, converged)."""
+    """partitions.py:416-593.  Returns (G_star, partition, M, converged).  G_star: isocon_amd.graphs.LazyDiGraph (the reference's
+    networkx graph on demand)."""
     G_star, converged = graphs.construct_exact_nearest_neighbor_graph(S, params)
-    unique_start_strings = set(G_star.nodes())
     M, partition = _partition_graph(G_star, False)      # same result as on nx.reverse(G_star), without the deep copy
-    partition_sequences = set()
-    for m in partition:
-        partition_sequences.add(m)
-        partition_sequences.update(partition[m])
-    assert unique_start_strings == partition_sequences
-    assert sum(len(partition[p]) + 1 for p in partition) == len(unique_start_strings)
+    # every unique sequence is in exactly one partition (partitions.py:590-591)
+    assert sum(len(partition[p]) + 1 for p in partition) == len(G_star.nodes)
+    assert all(m not in partition[m] for m in partition)
     return G_star, partition, M, converged
 
 

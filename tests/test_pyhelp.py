@@ -123,6 +123,30 @@ def check_pair_ids(H):
         H.pair_ids(list(index), pairs, a.ctypes.data, b.ctypes.data)
 
 
+def check_rank_strings(H):
+    import random
+    rng = random.Random(3)
+    for seqs in ([], ["A"], ["", "A", "", "AC", "A"], ["".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 9))) for _ in range(3000)],
+                 ["ACGT" * 50 + "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 5))) for _ in range(500)]):          # long shared prefixes, duplicates
+        out = np.full(max(len(seqs), 1), 7, dtype=np.uint32)
+        H.rank_strings(seqs, out.ctypes.data)
+        want = [0] * len(seqs)
+        for r, v in enumerate(sorted(range(len(seqs)), key=seqs.__getitem__)):          # (stable: equal strings in index order)
+            want[v] = r
+        assert out[:len(seqs)].tolist() == want
+    out = np.zeros(4, dtype=np.uint32)
+    with pytest.raises(TypeError):
+        H.rank_strings(["A", b"C"], out.ctypes.data)
+    with pytest.raises(TypeError):
+        H.rank_strings(["A", "Cé"], out.ctypes.data)
+    with pytest.raises(TypeError):
+        H.rank_strings(("A",), out.ctypes.data)
+
+
+def test_rank_strings():
+    check_rank_strings(_helper())
+
+
 def test_str_pointers():
     check_str_pointers(_helper())
 
@@ -163,6 +187,6 @@ def test_under_address_and_undefined_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
                ISOCON_PYHELP_UNDER_TEST=so)
     code = ("import sys; sys.path.insert(0, %r); import test_pyhelp as T; H = T._helper(); "
-            "T.check_str_pointers(H); T.check_split_ascii(H); T.check_csr_to_dict(H); T.check_pair_ids(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
+            "T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_csr_to_dict(H); T.check_pair_ids(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
