@@ -243,6 +243,34 @@ int isocon_msa_correct(const uint8_t *matrix, uint32_t n_rows, uint32_t n_cols, 
                        int64_t *out_class_totals, float *kernel_ms);
 
 /*
+ * The same correction with the multi-alignment matrix built ON THE DEVICE from the alignments' CIGAR ops (f1 + f3 fused with a12-a15:
+ * the gapped strings of sw_align_sequences never exist).  Replaces modules/functions.py:543-588 (create_multialignment_matrix),
+ * :598-631 (position_query_to_alignment) and the column layout of :679-767 for the partitions of get_partition_alignments
+ * (modules/isocon_get_candidates.py:37-81) + correct_strings (modules/correction_module.py:12-75).
+ *   isocon_msa_build_ops      rows = the partition: row_ids[0] the centre, row_ids[1 ..] its members (ids of the store); the ops of row r
+ *                             (isocon_sg_trace_batch's encoding; centre = QUERY of the alignment) are ops[ops_ptr[r] .. ops_ptr[r + 1]),
+ *                             ops_ptr[0] = ops_ptr[1] = 0.  Builds the matrix in device memory (kept for the call below) and returns
+ *                             *out_n_cols, out_col_slot[len(centre) + 1] (first column of every insertion slot; optional),
+ *                             out_longest[len(centre) + 1] (longest insertion per slot; optional) and the insertions of the WIDE slots
+ *                             (longest >= 2) as records of 8 uint32 (row, slot, first position in the member, length, the 2-bit codes
+ *                             A C G T = 0 1 2 3 of its first 32 bases in two words, two spare words): where those sit inside
+ *                             their slot is decided by the reference's string heuristics (get_best_solution, functions.py:635-676),
+ *                             which the Python layer applies and hands back as patches.  ISOCON_E_CAPACITY + *n_wide if wide_cap is
+ *                             too small; ISOCON_E_ARG if the ops of a row do not spell both sequences.
+ *   isocon_msa_correct_built  patches (patch_bytes[patch_ptr[i] .. patch_ptr[i + 1]) into row patch_row[i] from column patch_col[i]),
+ *                             then isocon_msa_correct on the built matrix (same outputs).  One build serves one correction.
+ *   isocon_msa_read_built     the built matrix (tests).
+ */
+int isocon_msa_build_ops(isocon_store *s, uint32_t n_rows, const uint32_t *row_ids, const uint32_t *ops, const uint64_t *ops_ptr,
+                         uint32_t *out_n_cols, uint32_t *out_col_slot, uint32_t *out_longest, uint32_t *out_wide, uint64_t wide_cap,
+                         uint64_t *n_wide, float *kernel_ms);
+int isocon_msa_correct_built(isocon_store *s, uint32_t n_rows, uint32_t n_cols, const uint32_t *patch_row, const uint32_t *patch_col,
+                             const uint32_t *patch_ptr, const uint8_t *patch_bytes, uint32_t n_patches, const int32_t *degree,
+                             uint8_t *out_packed, uint64_t packed_cap, uint64_t *out_offsets, int32_t *out_n_cand,
+                             int64_t *out_class_totals, float *kernel_ms);
+int isocon_msa_read_built(isocon_store *s, uint32_t n_rows, uint32_t n_cols, uint8_t *out_matrix);
+
+/*
  * Batched infix ("HW") edit distance with location and path ends == edlib.align(q, t, mode="HW", task="path", k=k)
  * as consumed by edlib_traceback (modules/end_invariant_functions.py:593-620) inside get_all_NN (:622-681), the
  * candidate-vs-candidate graph of the statistical-test phase: the query is aligned globally inside the target, target

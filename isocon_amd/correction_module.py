@@ -70,18 +70,144 @@ def correct_to_consensus(m, partition, seq_to_acc, step, verbose):
     return S_prime_partition
 
 
+def _partition_rows(batch, m):
+    """(row ids, ops, ops_ptr) of the partition of centre m for isocon_msa_build_ops: row 0 the centre, then its surviving members"""
+    rows = batch.rows_of.get(m, [])
+    nr = 1 + len(rows)
+    idx = np.asarray(rows, dtype=np.int64)
+    row_ids = np.concatenate([batch.a[idx[:1]], batch.b[idx]]).astype(np.uint32)
+    cnt = (batch.ops_ptr[idx + 1] - batch.ops_ptr[idx]).astype(np.int64)
+    ops_ptr = np.zeros(nr + 1, dtype=np.uint64)
+    np.cumsum(cnt, out=ops_ptr[2:])
+    # the rows' ops, gathered: pairs of one centre are consecutive in the batch unless the exon filter removed some
+    starts = batch.ops_ptr[idx]
+    if len(idx) and int(starts[-1] + cnt[-1] - starts[0]) == int(cnt.sum()):
+        ops = batch.ops[int(starts[0]):int(starts[0]) + int(cnt.sum())]
+    else:
+        ops = np.concatenate([batch.ops[int(b0):int(b0 + c)] for b0, c in zip(starts.tolist(), cnt.tolist())]) if len(idx) else np.zeros(0, np.uint32)
+    return row_ids, ops, ops_ptr
+
+
+_CODE = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _wide_slot_patches(members, wide, col_slot, longest):
+    """Where the insertions of the wide slots sit (functions.py:722-767): every insertion of a slot whose longest insertion has 2 or
+    more characters is placed inside "-" + the (alphabetically first) longest one + "-" by get_best_solution.  wide: the records of
+    isocon_msa_build_ops (row, slot, position in the member, length, 2-bit codes of the first 32 bases).  Tens of reads insert the
+    same base or two at a wide slot: the placement is computed once per DISTINCT (slot, insertion) -- a numpy unique over the records --
+    and scattered to the rows.  Returns (patch_row, patch_col, patch_ptr, patch_bytes) or four None."""
+    from .functions import get_best_solution
+    if not len(wide):
+        return None, None, None, None
+    wide = np.asarray(wide, dtype=np.uint32)
+    slot, ln = wide[:, 1].astype(np.int64), wide[:, 3].astype(np.int64)
+    codes = wide[:, 4].astype(np.uint64) | (wide[:, 5].astype(np.uint64) << np.uint64(32))
+    # distinct (slot, length, codes[, row for the rare insertions longer than the 32 coded bases])
+    long_ins = ln > 32
+    tie = np.where(long_ins, np.arange(len(wide), dtype=np.int64) + 1, 0)
+    k1, k2 = (slot << 32) | ln, codes.astype(np.int64)
+    order = np.lexsort((tie, k2, k1))
+    new = np.ones(len(order), dtype=bool)
+    new[1:] = (np.diff(k1[order]) != 0) | (np.diff(k2[order]) != 0) | (np.diff(tie[order]) != 0)
+    first = order[new]
+    inv = np.empty(len(order), dtype=np.int64)
+    inv[order] = np.cumsum(new) - 1
+    u_slot, u_len = slot[first], ln[first]
+    # the distinct insertion strings
+    strings = []
+    for i, f in enumerate(first.tolist()):
+        n_b = int(u_len[i])
+        if n_b > 32:
+            r, sp = int(wide[f, 0]), int(wide[f, 2])
+            strings.append(members[r - 1][sp:sp + n_b])
+        else:
+            c = int(codes[f])
+            strings.append(_CODE[[(c >> (2 * j)) & 3 for j in range(n_b)]].tobytes().decode())
+    # per slot: the padded longest insertion (functions.py:722-731), then every distinct insertion inside it
+    by_slot = {}
+    for i, t in enumerate(u_slot.tolist()):
+        by_slot.setdefault(t, []).append(i)
+    width = longest.astype(np.int64) + 2
+    sol_len = width[u_slot]
+    sol_off = np.zeros(len(first) + 1, dtype=np.int64)
+    np.cumsum(sol_len, out=sol_off[1:])
+    sol_bytes = np.empty(int(sol_off[-1]), dtype=np.uint8)
+    for t, members_of_slot in by_slot.items():
+        lg = int(longest[t])
+        mx = "-" + min(strings[i] for i in members_of_slot if len(strings[i]) == lg) + "-"
+        for i in members_of_slot:
+            sol = "".join(get_best_solution(mx, strings[i])).encode()
+            sol_bytes[int(sol_off[i]):int(sol_off[i + 1])] = np.frombuffer(sol, dtype=np.uint8)
+    # one patch per record: the bytes of its distinct insertion's placement, at its slot's first column
+    p_len = sol_len[inv]
+    p_ptr = np.zeros(len(wide) + 1, dtype=np.int64)
+    np.cumsum(p_len, out=p_ptr[1:])
+    src = np.repeat(sol_off[inv] - p_ptr[:-1], p_len) + np.arange(int(p_ptr[-1]), dtype=np.int64)
+    return wide[:, 0], col_slot[slot], p_ptr.astype(np.uint32), sol_bytes[src]
+
+
+def _correct_partition_from_ops(batch, m, partition, seq_to_acc):
+    """correct_to_consensus for a partition whose alignments are CIGAR ops on the device's store (isocon_get_candidates.AlignmentBatch):
+    the matrix is built there (isocon_msa_build_ops), the insertions of the wide slots are placed by get_best_solution here and sent
+    as patches, the correction runs on the built matrix (isocon_msa_correct_built).  Returns {accession: corrected sequence}."""
+    rows = batch.rows_of.get(m, [])
+    st = batch.store
+    members = [batch.pairs[p][1] for p in rows]
+    nr = 1 + len(rows)
+    N_t = partition[m][3] + len(rows)
+    out = {}
+    if not (nr > 1 and N_t > 2):
+        return out
+    row_ids, ops, ops_ptr = _partition_rows(batch, m)
+    n_cols, col_slot, longest, wide = st.msa_build_ops(row_ids, ops, ops_ptr)
+    p_row, p_col, p_ptr, p_bytes = _wide_slot_patches(members, wide, col_slot, longest)
+    deg = np.ones(nr, dtype=np.int32)
+    deg[0] = partition[m][3]
+    packed, off, n_cand = st.msa_correct_built(nr, n_cols, deg, p_row, p_col, p_ptr, p_bytes)
+    if (n_cand < 0).any():
+        raise RuntimeError("isocon_msa_correct left rows unprocessed")
+    todo = np.flatnonzero((deg == 1) & (n_cand > 0))
+    if len(todo):
+        H = _lib.pyhelp()
+        keys = [m] + members
+        if H is not None and hasattr(H, "split_ascii"):
+            # the corrected rows as str objects, cut out of the packed buffer in one call
+            strs = H.split_ascii(packed.ctypes.data, np.ascontiguousarray(off, dtype=np.int64).ctypes.data, nr)
+            for r in todo.tolist():
+                for acc in seq_to_acc[keys[r]]:
+                    out[acc] = strs[r]
+        else:
+            flat = packed[:off[nr]].tobytes().decode()
+            for r in todo.tolist():
+                for acc in seq_to_acc[keys[r]]:
+                    out[acc] = flat[off[r]:off[r + 1]]
+    return out
+
+
 def correct_strings(partition_alignments, seq_to_acc, ccs_dict, step, nr_cores=1, verbose=False):
     """correction_module.py:12-76.  partition_alignments: {centre: {s: (ed, aln_centre, aln_s, degree)}};
-    seq_to_acc: {sequence: [accessions]}.  Returns (S_prime, S_prime_quality) -- the second is always {} here."""
+    seq_to_acc: {sequence: [accessions]}.  Returns (S_prime, S_prime_quality) -- the second is always {} here.
+    A partition_alignments that still carries its alignments as CIGAR ops (isocon_get_candidates.get_partition_alignments on the
+    store the NN search remembered) is corrected from those on the device; gapped strings are never expanded."""
     if ccs_dict:
         raise NotImplementedError("correction with CCS quality values (disabled in the reference, isocon_get_candidates.py:106)")
     S_prime = {}
+    batch = getattr(partition_alignments, "batch", None)
+    from_ops = batch is not None and batch.alive() and _correct_on_device is _CORRECT_ON_DEVICE
     for m, partition in sorted(partition_alignments.items()):
-        acc_of = {m: seq_to_acc[m]}
-        for s in partition:
-            if s in seq_to_acc:
-                acc_of[s] = seq_to_acc[s]
-        for acc, s in correct_to_consensus(m, partition, acc_of, step, verbose).items():
+        if from_ops and len(partition) == 1 + len(batch.rows_of.get(m, [])):          # (unchanged since it was built)
+            part = _correct_partition_from_ops(batch, m, partition, seq_to_acc)
+        else:
+            acc_of = {m: seq_to_acc[m]}
+            for s in partition:
+                if s in seq_to_acc:
+                    acc_of[s] = seq_to_acc[s]
+            part = correct_to_consensus(m, partition, acc_of, step, verbose)
+        for acc, s in part.items():
             assert acc not in S_prime
             S_prime[acc] = s
     return S_prime, {}
+
+
+_CORRECT_ON_DEVICE = _correct_on_device          # (the CPU tests substitute the numpy checker: then the string path runs)

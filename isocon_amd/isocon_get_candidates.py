@@ -11,6 +11,8 @@ from . import functions
 from .SW_alignment_module import sw_align_sequences
 from .edlib_alignment_module import edlib_align_sequences
 
+_EDLIB_ALIGN, _SW_ALIGN = edlib_align_sequences, sw_align_sequences
+
 
 def get_unique_seq_accessions(S):
     """isocon_get_candidates.py:22-35: {seq: [acc, ...]} in first-appearance order."""
@@ -20,10 +22,121 @@ def get_unique_seq_accessions(S):
     return seq_to_acc
 
 
+class AlignmentBatch(object):
+    """The alignments of one get_partition_alignments call as arrays: pair p = (centre a[p], member b[p]) of `store`, its run-length
+    CIGAR ops[ops_ptr[p] : ops_ptr[p + 1]] (isocon_sg_trace_batch), counts res[p, 3:6].  The gapped strings are only made when somebody
+    reads them (LazyAlignment); the correction builds its multi-alignment matrix from the ops on the device (correction_module)."""
+
+    def __init__(self, store, pairs, a, b, ops, ops_ptr, res):
+        self.store, self.pairs, self.a, self.b, self.ops, self.ops_ptr, self.res = store, pairs, a, b, ops, ops_ptr, res
+        self.rows_of = {}          # centre sequence -> indices of its pairs that survived the exon filter
+
+    def strings(self, p):
+        from .SW_alignment_module import _ops_to_alignment
+        m, s = self.pairs[p]
+        return _ops_to_alignment(self.ops[int(self.ops_ptr[p]):int(self.ops_ptr[p + 1])].tolist(), m, s)
+
+    def alive(self):
+        return getattr(self.store, "_h", None) is not None
+
+
+class LazyAlignment(object):
+    """partition_alignments[m][s] = (edit_distance, m_alignment, s_alignment, 1) (isocon_get_candidates.py:74) whose two gapped strings are
+    expanded from the CIGAR ops when first read.  Indexing, iteration, len() and comparison behave like the tuple."""
+    __slots__ = ("_batch", "_p", "_edit", "_strings")
+
+    def __init__(self, batch, p, edit):
+        self._batch, self._p, self._edit, self._strings = batch, p, edit, None
+
+    def _tuple(self):
+        if self._strings is None:
+            self._strings = self._batch.strings(self._p)
+        return (self._edit, self._strings[0], self._strings[1], 1)
+
+    def __getitem__(self, i):
+        if i == 0:
+            return self._edit
+        if i == 3:
+            return 1
+        return self._tuple()[i]
+
+    def __iter__(self):
+        return iter(self._tuple())
+
+    def __len__(self):
+        return 4
+
+    def __eq__(self, other):
+        return self._tuple() == (other._tuple() if isinstance(other, LazyAlignment) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return repr(self._tuple())
+
+
+class PartitionAlignments(dict):
+    """{centre: {s: (edit_distance, aln_centre, aln_s, weight)}} as get_partition_alignments returns it, plus `.batch`: the same
+    alignments as arrays (AlignmentBatch) for consumers inside this package."""
+    batch = None
+
+
+def _partition_alignments_from_ops(graph_partition, M, G_star, exon_filtered, params):
+    """get_partition_alignments without gapped strings: distances, CIGAR ops and counts from the device, the exon filter on the ops
+    (functions.py:23-50 through isocon_exon_filter_from_ops), LazyAlignment values.  Same content as the string path."""
+    import numpy as np
+    from . import _lib
+    from .SW_alignment_module import TIE_POLICY
+    from .store import store_for_pairs
+    pairs = [(m, s) for m, members in graph_partition.items() for s in members]
+    out = PartitionAlignments()
+    if pairs:
+        st, a, b, owned = store_for_pairs(pairs)
+        if owned:          # (not the remembered store: nothing to keep resident -- the plain path)
+            st.close()
+            return None
+        if bool((st.lens[a] == 0).any() or (st.lens[b] == 0).any()):
+            raise ValueError("empty sequence in an alignment pair")
+        ed = st.ed_pairs(a, b, None)                                   # EAM:111, unbounded
+        rate = ed.astype(np.float64) / np.minimum(st.lens[a], st.lens[b]).astype(np.float64)          # SWM:102-109
+        mismatch = np.where(rate <= 0.01, -1, np.where(rate <= 0.09, -2, -4)).astype(np.int8)
+        ops, ops_ptr, res = st.sg_trace(a, b, mismatch, tie_policy=TIE_POLICY, ed_upper=ed)
+        L = _lib.load()
+        flags = np.zeros(len(pairs), dtype=np.uint8)
+        ops_c = np.ascontiguousarray(ops if len(ops) else np.zeros(1, np.uint32), dtype=np.uint32)
+        ptr_c = np.ascontiguousarray(ops_ptr, dtype=np.uint64)
+        _lib.check(L.isocon_exon_filter_from_ops(ops_c.ctypes.data_as(_lib.u32p), ptr_c.ctypes.data_as(_lib.u64p), len(pairs), int(params.min_exon_diff),
+                                                 int(params.ignore_ends_len), flags.ctypes.data_as(_lib.u8p)), "isocon_exon_filter_from_ops")
+        batch = AlignmentBatch(st, pairs, a, b, ops, np.asarray(ops_ptr, dtype=np.int64), res)
+        out.batch = batch
+        edit = (res[:, 4] + res[:, 5]).tolist()                        # mismatches + indels (isocon_get_candidates.py:74)
+        dropped = np.flatnonzero(flags).tolist()
+        for p in dropped:
+            exon_filtered.add(pairs[p][1])
+        keep = flags == 0
+    for m in M:
+        out[m] = {m: (0, m, m, G_star.nodes[m]["degree"])}
+    if pairs:
+        for p in np.flatnonzero(keep).tolist():
+            m, s = pairs[p]
+            out[m][s] = LazyAlignment(batch, p, edit[p])
+            batch.rows_of.setdefault(m, []).append(p)
+    return out
+
+
 def get_partition_alignments(graph_partition, M, G_star, exon_filtered, params):
     """isocon_get_candidates.py:37-81.  graph_partition: {centre: set(members)}, M: {centre: weight}, G_star: the NN
     graph (node attribute `degree`).  Returns {centre: {seq: (edit_distance, aln_centre, aln_seq, weight)}} and adds the
-    sequences dropped for exon-sized differences to `exon_filtered`."""
+    sequences dropped for exon-sized differences to `exon_filtered`.
+    When the partition comes from the store the NN search just remembered (the pipeline's case) the alignments stay CIGAR ops: the
+    gapped strings of a value are expanded when somebody reads them, and correct_strings builds its matrices from the ops on the device."""
+    if edlib_align_sequences is _EDLIB_ALIGN and sw_align_sequences is _SW_ALIGN:          # (tests swap these for the CPU oracle)
+        fast = _partition_alignments_from_ops(graph_partition, M, G_star, exon_filtered, params)
+        if fast is not None:
+            return fast
     exact_edit_distances = edlib_align_sequences(graph_partition, nr_cores=params.nr_cores)
     exact_alignments = sw_align_sequences(exact_edit_distances, nr_cores=params.nr_cores)
     filtered = functions.filter_exon_differences(exact_alignments, params.min_exon_diff, params.ignore_ends_len)

@@ -228,6 +228,57 @@ class SeqStore(object):
             _lib.check(rc, "isocon_nn_finalize_dev")
             return out_best[:n], row_ptr.astype(np.int64), cols[:int(row_ptr[n])]
 
+    # ---- consensus correction with the multi-alignment matrix built on the device (csrc/msa_build.hpp) ----------
+    def msa_build_ops(self, row_ids, ops, ops_ptr):
+        """The partition row_ids[0] (centre) + row_ids[1:] (members) with the members' CIGAR ops against the centre (ops_ptr[0] = ops_ptr[1] = 0)
+        -> (n_cols, col_slot uint32[Lm + 1], longest uint32[Lm + 1], wide uint32[k, 8] = row, slot, position in the member, length, 2-bit codes
+        of the first 32 bases (two words), two spare words).
+        The matrix stays in device memory for msa_correct_built."""
+        row_ids = np.ascontiguousarray(row_ids, dtype=np.uint32)
+        ops = np.ascontiguousarray(ops, dtype=np.uint32)
+        ops_ptr = np.ascontiguousarray(ops_ptr, dtype=np.uint64)
+        nr = len(row_ids)
+        Lm = int(self.lens[int(row_ids[0])])
+        n_cols = ctypes.c_uint32(0)
+        col_slot = np.zeros(Lm + 1, dtype=np.uint32)
+        longest = np.zeros(Lm + 1, dtype=np.uint32)
+        cap = 65536
+        n_wide = ctypes.c_uint64(0)
+        while True:
+            wide = np.empty((cap, 8), dtype=np.uint32)
+            rc = self._L.isocon_msa_build_ops(self._h, nr, _ptr(row_ids, _lib.u32p), _ptr(ops if len(ops) else None, _lib.u32p), _ptr(ops_ptr, _lib.u64p),
+                                              ctypes.byref(n_cols), _ptr(col_slot, _lib.u32p), _ptr(longest, _lib.u32p), _ptr(wide, _lib.u32p), cap,
+                                              ctypes.byref(n_wide), None)
+            if rc == _lib.ISOCON_E_CAPACITY:
+                cap = int(n_wide.value) + 16
+                continue
+            _lib.check(rc, "isocon_msa_build_ops")
+            return int(n_cols.value), col_slot, longest, wide[:int(n_wide.value)]
+
+    def msa_correct_built(self, n_rows, n_cols, degree, patch_row=None, patch_col=None, patch_ptr=None, patch_bytes=None):
+        """Patches into the built matrix, then the correction (isocon_msa_correct_built) -> (packed uint8[], offsets int64[n_rows + 1], n_cand)."""
+        deg = np.ascontiguousarray(degree, dtype=np.int32)
+        n_p = 0 if patch_row is None else len(patch_row)
+        if n_p:
+            patch_row = np.ascontiguousarray(patch_row, dtype=np.uint32)
+            patch_col = np.ascontiguousarray(patch_col, dtype=np.uint32)
+            patch_ptr = np.ascontiguousarray(patch_ptr, dtype=np.uint32)
+            patch_bytes = np.ascontiguousarray(patch_bytes, dtype=np.uint8)
+        cap = int(n_rows) * int(n_cols)
+        packed = np.empty(max(cap, 1), dtype=np.uint8)
+        offsets = np.zeros(n_rows + 1, dtype=np.uint64)
+        n_cand = np.zeros(n_rows, dtype=np.int32)
+        _lib.check(self._L.isocon_msa_correct_built(self._h, n_rows, n_cols, _ptr(patch_row if n_p else None, _lib.u32p), _ptr(patch_col if n_p else None, _lib.u32p),
+                                                    _ptr(patch_ptr if n_p else None, _lib.u32p), _ptr(patch_bytes if n_p else None, _lib.u8p), n_p,
+                                                    _ptr(deg, _lib.i32p), _ptr(packed, _lib.u8p), cap, _ptr(offsets, _lib.u64p), _ptr(n_cand, _lib.i32p),
+                                                    None, None), "isocon_msa_correct_built")
+        return packed, offsets.astype(np.int64), n_cand
+
+    def msa_read_built(self, n_rows, n_cols):
+        M = np.zeros((n_rows, n_cols), dtype=np.uint8)
+        _lib.check(self._L.isocon_msa_read_built(self._h, n_rows, n_cols, _ptr(M, _lib.u8p)), "isocon_msa_read_built")
+        return M
+
     # ---- semi-global affine alignment with traceback ----------------------------------------------------------
     def sg_trace(self, a, b, mismatch, match=2, open_=2, ext=0, tie_policy=0, return_ms=False, ed_upper=None):
         """Returns (ops uint32[], ops_ptr int64[n+1], res int32[n,6]) -- see include/isocon_hip.h."""

@@ -103,6 +103,75 @@ def test_device_correction_equals_host_statement(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("profile", ["ccs", "ont"])
+def test_device_built_matrix_equals_the_host_matrix(profile):
+    """isocon_msa_build_ops (the multi-alignment matrix from CIGAR ops and the packed store, csrc/msa_build.hpp) + the wide-slot patches
+    against functions.msa_matrix on the gapped strings (the reference's layout, functions.py:543-588,679-767): every cell of every
+    partition; CCS-like reads (single-base insertions) and reads with many multi-base insertions (wide slots)."""
+    import numpy as np
+    from isocon_amd import correction_module as COR
+    from isocon_amd import functions as FUN
+    from isocon_amd import isocon_get_candidates as IGC
+    from isocon_amd import partitions, synth
+    if profile == "ccs":
+        accs, seqs, _ = synth.make_reads(900, 700, 3, seed=62)
+    else:
+        accs, seqs, _ = synth.make_reads(400, 500, 3, seed=63, profile=synth.ONT_PROFILE)
+    S = dict(zip(accs, seqs))
+    G, partition, M, converged = partitions.partition_strings(S, Params())
+    pa = IGC.get_partition_alignments(partition, M, G, set(), Params())
+    batch = pa.batch
+    assert batch is not None and batch.alive()
+    checked = wide_total = 0
+    for m in pa:
+        if len(pa[m]) < 2:
+            continue
+        rows = batch.rows_of[m]
+        members = [batch.pairs[p][1] for p in rows]
+        assert [m] + members == list(pa[m])
+        row_ids, ops, ops_ptr = COR._partition_rows(batch, m)
+        n_cols, col_slot, longest, wide = batch.store.msa_build_ops(row_ids, ops, ops_ptr)
+        dev = batch.store.msa_read_built(len(row_ids), n_cols)
+        p_row, p_col, p_ptr, p_bytes = COR._wide_slot_patches(members, wide, col_slot, longest)
+        for i in range(0 if p_row is None else len(p_row)):
+            dev[p_row[i], p_col[i]:p_col[i] + int(p_ptr[i + 1] - p_ptr[i])] = p_bytes[int(p_ptr[i]):int(p_ptr[i + 1])]
+        keys, host = FUN.msa_matrix(m, pa[m])          # (expands the gapped strings of the lazy values)
+        assert keys == [m] + members and host.shape == dev.shape
+        assert (host == dev).all()
+        checked += 1
+        wide_total += len(wide)
+    assert checked >= 3 and (profile == "ccs" or wide_total > 50)
+
+
+@pytest.mark.gpu
+def test_lazy_alignments_behave_like_the_tuples():
+    """partition_alignments values of the ops path: indexing, iteration, equality with the tuples of the string path"""
+    from isocon_amd import isocon_get_candidates as IGC
+    from isocon_amd import partitions, synth
+    accs, seqs, _ = synth.make_reads(300, 400, 2, seed=64)
+    S = dict(zip(accs, seqs))
+    G, partition, M, converged = partitions.partition_strings(S, Params())
+    ex1, ex2 = set(), set()
+    fast = IGC.get_partition_alignments(partition, M, G, ex1, Params())
+    assert isinstance(fast, IGC.PartitionAlignments) and fast.batch is not None
+    IGC._EDLIB_ALIGN = None          # (forces the string path)
+    try:
+        plain = IGC.get_partition_alignments(partition, M, G, ex2, Params())
+    finally:
+        IGC._EDLIB_ALIGN = IGC.edlib_align_sequences
+    assert not hasattr(plain, "batch") or plain.batch is None
+    assert ex1 == ex2 and list(fast) == list(plain)
+    n = 0
+    for m in plain:
+        assert set(fast[m]) == set(plain[m])
+        for s in plain[m]:
+            t, u = plain[m][s], fast[m][s]
+            assert u == t and tuple(u) == t and len(u) == 4 and u[0] == t[0] and u[1] == t[1] and u[2] == t[2] and u[3] == t[3]
+            n += 1
+    assert n > 250
+
+
+@pytest.mark.gpu
 def test_device_correction_rows_beyond_the_lds_list():
     """Rows with more than 2048 correctable positions take the second launch (list in HBM): same result as the checker."""
     import numpy as np
