@@ -118,7 +118,7 @@ typedef struct {
     float narrow_kernel_ms;       /* of scan_kernel_ms: the table launch over the pairs whose threshold is <= 31 (32-row form of the kernel) */
     uint64_t pairs_lanes;         /* pairs of the main pass aligned one pair per lane (the rest went through tables) */
     uint64_t bound_tiles;         /* 256 x 256 tiles of the bound matrix computed (each: 65 536 pairs x isocon_qgram_params() multiply-adds) */
-    uint64_t pairs_wide_to_lanes; /* of pairs_lanes: pairs with a threshold above 31 sent there because of it (ISOCON_NN_NARROW=1 only) */
+    uint64_t pairs_wide_to_lanes; /* of pairs_lanes: pairs with a threshold above 31 sent there because of it (ISOCON_DEBUG_VARIANT=nn_narrow=1 only) */
     uint64_t narrow_columns;      /* of cells_columns: columns run by the 32-row form of the table kernel */
     uint64_t pairs_narrow;        /* pairs listed in chunks of the 32-row class */
 } isocon_nn_stats;

@@ -33,6 +33,35 @@ thread_local std::string g_last_error;
 
 using namespace isocon;
 
+// ISOCON_DEBUG_VARIANT = "name[=value],name,...": the ONE environment switch behind which every diagnostic / A-B variant of the kernel
+// selection sits (tests force fallbacks and superseded paths through it; DESIGN.md section 8 lists the names).  Unset -- production -- every
+// input class has one code path.  variant(name): the name is listed; variant_value(name): its value ("" if listed without one), nullptr if
+// not listed (the pointer is good until eight further calls on this thread).
+static bool variant_lookup(const char *name, std::string *value)
+{
+    const char *e = getenv("ISOCON_DEBUG_VARIANT");
+    if (!e) return false;
+    const size_t ln = strlen(name);
+    for (const char *p = e; *p;) {
+        const char *q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len >= ln && strncmp(p, name, ln) == 0 && (len == ln || p[ln] == '=')) {
+            if (value) *value = len > ln ? std::string(p + ln + 1, len - ln - 1) : std::string();
+            return true;
+        }
+        p += len + (q ? 1 : 0);
+    }
+    return false;
+}
+static bool variant(const char *name) { return variant_lookup(name, nullptr); }
+static const char *variant_value(const char *name)
+{
+    thread_local std::string ring[8];
+    thread_local unsigned at = 0;
+    std::string &slot = ring[at++ % 8];
+    return variant_lookup(name, &slot) ? slot.c_str() : nullptr;
+}
+
 // What the pool's nearest-neighbour slots currently hold, next to the slots themselves (no free-floating state: a store reaches it
 // through its pool, and whoever overwrites or releases a slot invalidates the tag in the same place).
 // BoundTag: the q-gram bound matrix of the last seed phase (slots SLOT_NN_LB / SLOT_NN_LBROW): the main phase of the SAME store and
@@ -567,8 +596,8 @@ int ed_pairs_impl(isocon_store *st, const uint32_t *a, const uint32_t *b, const 
         std::vector<uint64_t> todo = pending, next;
         if (W == 1) {
             // Pairs that share their sequence with fewer than 16 others would leave most lanes of a tile empty: one pair per
-            // lane instead (ed_lanes.hpp; ~1.7x the column cost, every lane busy).  ISOCON_ED_LANES=1 / =0: all / none.
-            const char *e = getenv("ISOCON_ED_LANES");
+            // lane instead (ed_lanes.hpp; ~1.7x the column cost, every lane busy).  ISOCON_DEBUG_VARIANT=ed_lanes=1 / =0: all / none.
+            const char *e = variant_value("ed_lanes");
             const size_t min_group = e ? (atoi(e) ? (size_t)-1 : 0) : 16;
             std::vector<uint64_t> lanes_p, tiles_p;
             for (size_t i = 0; i < todo.size();) {

@@ -38,6 +38,7 @@ struct NNParams {
     const uint8_t *lb;
     const unsigned long long *lb_row;
     const uint32_t *slot_order;    // launch slot handled by workgroup i (nullptr: i itself): entries with the widest windows first
+    uint32_t wg_base;              // k_nn_scan_refill: this launch covers the workgroups wg_base, wg_base + 1, ... of the pass (a long pass is cut into bounded launches)
     // k_nn_scan_refill, "listed" launch (nn_list.hpp; nullptr = not listed): workgroup i aligns the entry chunks[i].slot (its table in
     // LDS) with the partners list[chunks[i].begin .. + count) -- survivors of the q-gram bound, collected before the launch
     const struct NNChunk *chunks;
@@ -294,9 +295,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     const bool listed = P.chunks != nullptr;
     uint32_t l_count = 0;
     unsigned long long l_begin = 0;
-    if (listed) { l_count = P.chunks[blockIdx.x].count; l_begin = P.chunks[blockIdx.x].begin; }
-    const uint32_t slot = listed ? P.chunks[blockIdx.x].slot : (!sparse && P.slot_order != nullptr) ? P.slot_order[blockIdx.x] : blockIdx.x;
-    const uint64_t q64 = listed ? (uint64_t)slot : sparse ? (uint64_t)P.q_list[blockIdx.x] : Q.entry(slot);
+    const uint32_t wg = blockIdx.x + P.wg_base;
+    if (listed) { l_count = P.chunks[wg].count; l_begin = P.chunks[wg].begin; }
+    const uint32_t slot = listed ? P.chunks[wg].slot : (!sparse && P.slot_order != nullptr) ? P.slot_order[wg] : wg;
+    const uint64_t q64 = listed ? (uint64_t)slot : sparse ? (uint64_t)P.q_list[wg] : Q.entry(slot);
     if (q64 >= (listed ? (uint64_t)S.n : (uint64_t)Q.end)) return;
     const uint32_t q = (uint32_t)q64;
     const int32_t m = S.lens[q];

@@ -19,7 +19,7 @@ stg = SeqStore(cseqs)
 gk = np.full(len(gq), 25, dtype=np.int32)
 dev = stg.hw_pairs(gq, gt, gk)
 dev2 = stg.hw_pairs(gq, gt, gk)
-os.environ["ISOCON_HW_HOST_TILES"] = "1"
+os.environ["ISOCON_DEBUG_VARIANT"] = "hw_host_tiles=1"
 host = stg.hw_pairs(gq, gt, gk)
 print("device twice identical:", bool((dev == dev2).all()))
 bad = np.nonzero((dev != host).any(axis=1))[0]
@@ -30,5 +30,5 @@ print("columns differing:", [(int((dev[:, c] != host[:, c]).sum())) for c in ran
 import hashlib, time
 print("digest dev", hashlib.sha1(dev.tobytes()).hexdigest()[:16], "host", hashlib.sha1(host.tobytes()).hexdigest()[:16])
 t0 = time.perf_counter(); stg.hw_pairs(gq, gt, gk); print("host-tile path wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))
-del os.environ["ISOCON_HW_HOST_TILES"]
+del os.environ["ISOCON_DEBUG_VARIANT"]
 t0 = time.perf_counter(); stg.hw_pairs(gq, gt, gk); print("device-tile path wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))

@@ -1,5 +1,5 @@
 """GPU box: the 32-row form of the table kernel on reads with few errors (50 000 x 2.5 kb, CCS split at 0.3 % instead of C3's 1 %):
-step time with the form chosen on the device against the 64-row form forced (ISOCON_NN_NARROW=0)."""
+step time with the form chosen on the device against the 64-row form forced (ISOCON_DEBUG_VARIANT=nn_narrow=0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -11,8 +11,8 @@ seqs = sorted(dict.fromkeys(seqs), key=len)
 st = SeqStore(seqs)
 ref = None
 for env in (None, "0"):
-    if env is None: os.environ.pop("ISOCON_NN_NARROW", None)
-    else: os.environ["ISOCON_NN_NARROW"] = env
+    if env is None: os.environ.pop("ISOCON_DEBUG_VARIANT", None)
+    else: os.environ["ISOCON_DEBUG_VARIANT"] = "nn_narrow=" + env
     ts = []
     for rep in range(4):
         t0 = time.perf_counter(); best, rp, cols, s = st.nn_graph(); ts.append((time.perf_counter() - t0) * 1e3)

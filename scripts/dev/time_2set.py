@@ -20,7 +20,7 @@ merged = sorted([(s, 0) for s in seqs] + [(c, 1) for c in cands], key=lambda x: 
 st = SeqStore([s for s, _ in merged])
 is_t = np.array([f for _, f in merged], dtype=np.uint8)
 ref = None
-for env in ({}, {"ISOCON_NN_NO_LIST": "1"}, {"ISOCON_NN_NO_QGRAM": "1"}):
+for env in ({}, {"ISOCON_DEBUG_VARIANT": "nn_no_list"}, {"ISOCON_DEBUG_VARIANT": "nn_no_qgram"}):
     os.environ.update(env)
     ts = []
     for rep in range(3):

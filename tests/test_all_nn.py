@@ -194,9 +194,9 @@ def test_gpu_hw_pairs_tiles_built_on_the_device(monkeypatch):
     st = SeqStore(seqs)
     try:
         dev = st.hw_pairs(q, t, k)
-        monkeypatch.setenv("ISOCON_HW_HOST_TILES", "1")
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "hw_host_tiles=1")
         host = st.hw_pairs(q, t, k)
-        monkeypatch.delenv("ISOCON_HW_HOST_TILES")
+        monkeypatch.delenv("ISOCON_DEBUG_VARIANT")
         assert (dev == host).all()
         assert (dev[:, 0] >= 0).sum() > 1000 and (dev[:, 0] < 0).sum() > 1000
         for p in range(0, len(q), 45):

@@ -138,7 +138,7 @@ def test_one_pair_per_lane_kernel_equals_the_oracle(monkeypatch):
         blk = 5 + 11 * rng.randrange(8)
         a[i] = blk + rng.randrange(11); b[i] = blk + rng.randrange(11)
     k = np.array([rng.choice([-1, -1, 0, 1, 2, 3, 7, 20, 31, 32, 33, 50, 62, 63]) for _ in range(6000)], dtype=np.int32)
-    monkeypatch.setenv("ISOCON_ED_LANES", "1")
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "ed_lanes=1")
     st = SeqStore(seqs)
     try:
         got = st.ed_pairs(a, b, k)
@@ -149,7 +149,7 @@ def test_one_pair_per_lane_kernel_equals_the_oracle(monkeypatch):
     want_u = O.ed_pairs(seqs, a, b, None)
     assert (got == want).all(), np.nonzero(got != want)[0][:10]
     assert (got_u == want_u).all()
-    monkeypatch.setenv("ISOCON_ED_LANES", "0")
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "ed_lanes=0")
     st = SeqStore(seqs)
     try:
         assert (st.ed_pairs(a, b, k) == want).all()

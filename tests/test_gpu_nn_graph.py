@@ -145,12 +145,12 @@ def test_empty_store_and_single_entry():
 
 
 def test_tile_synchronous_main_pass_still_matches(monkeypatch):
-    """ISOCON_NN_TILES=1 selects the tile-synchronous LDS kernel (+ equal-length regrouping): the fallback for reads too
+    """ISOCON_DEBUG_VARIANT=nn_tiles selects the tile-synchronous LDS kernel (+ equal-length regrouping): the fallback for reads too
     long for the lane-refill kernel's LDS layout must stay exact."""
     from isocon_amd import nearest_neighbor_graph as NNG
     from isocon_amd import synth
     from oracle import oracle as O
-    monkeypatch.setenv("ISOCON_NN_TILES", "1")
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_tiles=1")
     accs, seqs, _ = synth.make_reads(700, 900, 4, seed=21)
     S = dict(zip(accs, seqs))
     g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
@@ -175,12 +175,29 @@ def test_wide_band_refill_kernels(length, rate, lo, hi):
     assert NNG.LAST_STATS["fallback_queries"] > 0
 
 
+def test_wide_band_pass_in_bounded_launches(monkeypatch):
+    """A wide-band pass is issued as launches of a bounded number of workgroups (8192 in production: <= ~2 s at 200 000 reads); here 7
+    per launch on a small set, dense and one-workgroup-per-query forms: the same graph, many launches."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    accs, seqs, _ = synth.make_reads(160, 1300, 2, seed=1300, profile=dict(synth.ONT_PROFILE, rate=0.08))
+    S = dict(zip(accs, seqs))
+    ref, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    launches = NNG.LAST_STATS["scan_launches"]
+    for variant in ("nn_wide_per_launch=7", "nn_wide_per_launch=7,nn_no_sparse"):
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", variant)
+        got, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+        assert ordered(got) == ordered(ref)
+        assert NNG.LAST_STATS["scan_launches"] > launches + 10
+    monkeypatch.delenv("ISOCON_DEBUG_VARIANT")
+
+
 def test_hit_list_overflow_reruns_with_the_bounds_kept(monkeypatch):
     """A hit list that is too small makes the phase run again (larger list, bounds kept): same graph."""
     from isocon_amd import nearest_neighbor_graph as NNG
     from isocon_amd import synth
     from oracle import oracle as O
-    monkeypatch.setenv("ISOCON_HITS_CAP", "64")
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "hits_cap=64")
     accs, seqs, _ = synth.make_reads(500, 700, 3, seed=33)
     S = dict(zip(accs, seqs))
     g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
@@ -217,7 +234,7 @@ def test_every_band_width_in_steps_of_64_rows(first_w, monkeypatch):
     from isocon_amd import nearest_neighbor_graph as NNG
     from isocon_amd import synth
     from oracle import oracle as O
-    monkeypatch.setenv("ISOCON_NN_FIRST_W", str(first_w))
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_first_w=%s" % (first_w,))
     seqs = []
     for length, rate, seed in ((900, 0.07, 1), (1800, 0.07, 2), (2600, 0.08, 3)):
         accs, s, _ = synth.make_reads(90, length, 2, seed=seed, profile=dict(synth.ONT_PROFILE, rate=rate))
@@ -242,7 +259,7 @@ def test_sample_stage_and_one_workgroup_per_query_launches(monkeypatch):
     st = SeqStore(seqs)
     best, row_ptr, cols, stats = st.nn_graph()
     assert stats["fallback_queries"] >= 2048
-    monkeypatch.setenv("ISOCON_NN_NO_SPARSE", "1")
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_no_sparse=1")
     b2, r2, c2, _ = st.nn_graph()
     assert (b2 == best).all() and (r2 == row_ptr).all() and (c2 == cols).all()
     packed = O.pack(seqs)
@@ -274,11 +291,11 @@ def test_device_finalize_matches_the_host_routine():
         st = SeqStore(seqs)
         try:
             dev = st.nn_graph()
-            os.environ["ISOCON_NN_HOST_FINALIZE"] = "1"
+            os.environ["ISOCON_DEBUG_VARIANT"] = "nn_host_finalize=1"
             try:
                 host = st.nn_graph()
             finally:
-                del os.environ["ISOCON_NN_HOST_FINALIZE"]
+                del os.environ["ISOCON_DEBUG_VARIANT"]
             assert dev[3]["hits"] >= 4096
             assert all((x == y).all() for x, y in zip(dev[:3], host[:3])), (family, n_families)
             if family == 400:
@@ -338,7 +355,7 @@ def test_device_resident_phases_equal_the_single_call():
 
 def test_narrow_mode_on_reads_with_few_errors(monkeypatch):
     """Reads whose nearest neighbour is a few edits away: the list builder files nearly every pair under the 32-row class (thresholds
-    <= 31), the few pairs above go to 64-row chunks or one per lane.  Same graph as with every pair on 64 rows (ISOCON_NN_NARROW=0) and
+    <= 31), the few pairs above go to 64-row chunks or one per lane.  Same graph as with every pair on 64 rows (ISOCON_DEBUG_VARIANT=nn_narrow=0) and
     as with the pairs above 31 forced out of the lists (=1), and the rows of some reads against the reference loop."""
     from isocon_amd import synth
     from isocon_amd.store import SeqStore
@@ -350,11 +367,11 @@ def test_narrow_mode_on_reads_with_few_errors(monkeypatch):
         got = st.nn_graph()
         assert got[3]["pairs_narrow"] > 0 and got[3]["narrow_columns"] > 0 and got[3]["narrow_kernel_ms"] > 0, got[3]
         assert got[3]["narrow_kernel_ms"] <= got[3]["scan_kernel_ms"] and got[3]["narrow_columns"] <= got[3]["cells_columns"]
-        monkeypatch.setenv("ISOCON_NN_NARROW", "0")
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_narrow=0")
         wide = st.nn_graph()
-        monkeypatch.setenv("ISOCON_NN_NARROW", "1")
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_narrow=1")
         forced = st.nn_graph()
-        monkeypatch.delenv("ISOCON_NN_NARROW")
+        monkeypatch.delenv("ISOCON_DEBUG_VARIANT")
         assert wide[3]["pairs_narrow"] == 0 and wide[3]["narrow_columns"] == 0 and wide[3]["pairs_wide_to_lanes"] == 0
         assert forced[3]["pairs_narrow"] > 0
         assert all((x == y).all() for x, y in zip(got[:3], wide[:3]))
@@ -447,11 +464,11 @@ def test_few_close_pairs_plus_far_reads_keep_both_kinds_of_edge():
     st = SeqStore(seqs)
     try:
         dev = st.nn_graph()
-        os.environ["ISOCON_NN_HOST_FINALIZE"] = "1"
+        os.environ["ISOCON_DEBUG_VARIANT"] = "nn_host_finalize=1"
         try:
             host = st.nn_graph()
         finally:
-            del os.environ["ISOCON_NN_HOST_FINALIZE"]
+            del os.environ["ISOCON_DEBUG_VARIANT"]
     finally:
         st.close()
     assert dev[3]["fallback_queries"] > 0

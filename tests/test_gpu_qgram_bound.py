@@ -111,37 +111,35 @@ def test_graph_with_the_filter_is_the_graph_without_it_and_the_filter_is_used():
     try:
         best, row_ptr, cols, stats = st.nn_graph(is_converged=conv)
         assert stats["pairs_prefiltered"] > 0 and stats["bound_kernel_ms"] > 0
-        os.environ["ISOCON_NN_NO_QGRAM"] = "1"
+        os.environ["ISOCON_DEBUG_VARIANT"] = "nn_no_qgram=1"
         try:
             best0, row_ptr0, cols0, stats0 = st.nn_graph(is_converged=conv)
         finally:
-            del os.environ["ISOCON_NN_NO_QGRAM"]
+            del os.environ["ISOCON_DEBUG_VARIANT"]
         assert stats0["pairs_prefiltered"] == 0
         assert stats["pairs_evaluated"] < stats0["pairs_evaluated"]
         assert (best == best0).all() and (row_ptr == row_ptr0).all() and (cols == cols0).all()
         # the bounds with the 64-neighbour seed pass instead of the smallest-bound seeds, and the other workgroup shapes / orders
         # ... the survivor lists switched off (the kernel's own admission), every pair through a table / one pair per lane, and lists
         # that do not fit (fallback to the kernel's own admission)
-        for env in ({"ISOCON_NN_OLD_SEED": "1"}, {"ISOCON_NN_WAVES": "8"}, {"ISOCON_NN_ORDER": "0"}, {"ISOCON_NN_ORDER": "1"},
-                    {"ISOCON_NN_NO_LIST": "1"}, {"ISOCON_NN_LIST_MIN": "1"}, {"ISOCON_NN_LIST_MIN": "1000000"}, {"ISOCON_NN_LIST_CAP": "1000"},
-                    {"ISOCON_NN_LIST_WAVES": "4"}, {"ISOCON_NN_HOST_FINALIZE": "1"}, {"ISOCON_NN_NARROW": "1"}, {"ISOCON_NN_NARROW": "0"},
-                    {"ISOCON_NN_NARROW": "1", "ISOCON_NN_LIST_WAVES": "4"}):
-            os.environ.update(env)
+        for env in ("nn_old_seed", "nn_waves=8", "nn_order=0", "nn_order=1", "nn_no_list", "nn_list_min=1", "nn_list_min=1000000", "nn_list_cap=1000",
+                    "nn_list_waves=4", "nn_host_finalize", "nn_narrow=1", "nn_narrow=0", "nn_narrow=1,nn_list_waves=4", "nn_narrow=0,nn_list_waves=4",
+                    "nn_seed_classes=1", "nn_seed_classes=2"):
+            os.environ["ISOCON_DEBUG_VARIANT"] = env          # (the one switch behind which the A/B variants sit: DESIGN.md section 8)
             try:
                 b2, r2, c2, s2 = st.nn_graph(is_converged=conv)
             finally:
-                for k in env:
-                    del os.environ[k]
+                del os.environ["ISOCON_DEBUG_VARIANT"]
             assert s2["pairs_prefiltered"] > 0
             assert (best == b2).all() and (row_ptr == r2).all() and (cols == c2).all(), env
         # the same with a finite depth and a strided shard (the row layout follows the launch slots)
         is_t = np.zeros(len(seqs), np.uint8); is_t[::5] = 1
         g1 = st.nn_graph(is_target=is_t)
-        os.environ["ISOCON_NN_NO_QGRAM"] = "1"
+        os.environ["ISOCON_DEBUG_VARIANT"] = "nn_no_qgram=1"
         try:
             g0 = st.nn_graph(is_target=is_t)
         finally:
-            del os.environ["ISOCON_NN_NO_QGRAM"]
+            del os.environ["ISOCON_DEBUG_VARIANT"]
         assert all((x == y).all() for x, y in zip(g1[:3], g0[:3]))
     finally:
         st.close()

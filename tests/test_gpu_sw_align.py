@@ -187,7 +187,7 @@ def test_wrappers_use_the_hint_and_stay_identical():
 
 
 def test_diagonal_band_kernel_equals_strip_kernel(monkeypatch):
-    """Certified bands of at most 256 diagonals run with the diagonals on the lanes (k_sg_band); ISOCON_SW_STRIPS=1 sends them
+    """Certified bands of at most 256 diagonals run with the diagonals on the lanes (k_sg_band); ISOCON_DEBUG_VARIANT=sw_strips sends them
     through the strip kernel instead.  Read-sized pairs at CCS and at ONT error rates (bands of ~100 .. ~800 diagonals, so
     both kernels are in the default run), every tie policy class, both gap models: identical ops and results."""
     from isocon_amd import synth
@@ -208,11 +208,11 @@ def test_diagonal_band_kernel_equals_strip_kernel(monkeypatch):
     ed = st.ed_pairs(a, b, None)
     mm = np.array([[-1, -2, -4][i % 3] for i in range(len(a))], dtype=np.int8)
     for policy, open_, ext in ((0, 2, 0), (3, 2, 0), (8, 2, 0), (21, 2, 0), (0, 3, 1)):
-        monkeypatch.delenv("ISOCON_SW_STRIPS", raising=False)
+        monkeypatch.delenv("ISOCON_DEBUG_VARIANT", raising=False)
         o1, p1, r1 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy, ed_upper=ed)
-        monkeypatch.setenv("ISOCON_SW_STRIPS", "1")
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "sw_strips=1")
         o2, p2, r2 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy, ed_upper=ed)
-        monkeypatch.delenv("ISOCON_SW_STRIPS", raising=False)
+        monkeypatch.delenv("ISOCON_DEBUG_VARIANT", raising=False)
         o3, p3, r3 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy)          # no hints: the full matrix
         assert (r1 == r2).all() and (p1 == p2).all() and (o1 == o2).all(), (policy, open_, ext)
         assert (r1 == r3).all() and (p1 == p3).all() and (o1 == o3).all(), (policy, open_, ext)
