@@ -665,7 +665,7 @@ def wrappers(accs, seqs_all, pair_ed_out=None):
     kern = float(NNG.LAST_STATS.get("kernel_ms", 0.0))
     n_edges = sum(len(v) for v in G.values())
     del G
-    G_star, partition, M, converged = partitions.partition_strings(S, P())
+    t0 = time.perf_counter(); G_star, partition, M, converged = partitions.partition_strings(S, P()); t_part = time.perf_counter() - t0
     n_pairs = sum(len(v) for v in partition.values())
     t0 = time.perf_counter(); ed = EAM.edlib_align_sequences(partition); t_ed = time.perf_counter() - t0
     # twice: the first call of a process also allocates the pinned output buffers (2 x 146 MB, ~0.1 s, kept for the following
@@ -676,11 +676,27 @@ def wrappers(accs, seqs_all, pair_ed_out=None):
     n_sw = sum(len(v) for v in sw.values())
     if pair_ed_out is not None:          # the pair list with its distances, for the CPU legs (cpu_pair_legs)
         pair_ed_out.extend((s1, s2, d) for s1, row in ed.items() for s2, d in row.items())
+    del sw
+    # one correction iteration of the candidate phase as isocon_get_candidates.find_candidate_transcripts runs it:
+    # partition_strings (NN graph + partition) -> get_partition_alignments (distances, CIGAR ops, exon filter) -> correct_strings
+    from isocon_amd import correction_module as COR
+    from isocon_amd import isocon_get_candidates as IGC
+
+    class Q(P):
+        min_exon_diff = 20
+        ignore_ends_len = 15
+
+    G_star, partition, M, converged = partitions.partition_strings(S, Q())          # (the store of this very set must be the remembered one)
+    t0 = time.perf_counter(); pa = IGC.get_partition_alignments(partition, M, G_star, set(), Q()); t_pa = time.perf_counter() - t0
+    seq_to_acc = IGC.get_unique_seq_accessions(S)
+    t0 = time.perf_counter(); S_prime, _ = COR.correct_strings(pa, seq_to_acc, {}, 1); t_cor = time.perf_counter() - t0
     return {"compute_nearest_neighbor_graph_wall_ms": t_nn * 1e3, "compute_nearest_neighbor_graph_kernel_ms": kern, "nn_edges": n_edges,
             "partition_centres": len(partition), "partition_pairs": n_pairs,
             "edlib_align_sequences_wall_ms": t_ed * 1e3, "edlib_align_sequences_pairs_per_s": n_pairs / t_ed if t_ed > 0 else None,
             "sw_align_sequences_wall_ms": t_sw * 1e3, "sw_align_sequences_first_call_wall_ms": t_sw_first * 1e3,
             "sw_align_sequences_pairs_per_s": n_sw / t_sw if t_sw > 0 else None,
+            "partition_strings_wall_ms": t_part * 1e3, "get_partition_alignments_wall_ms": t_pa * 1e3, "correct_strings_wall_ms": t_cor * 1e3,
+            "corrected_reads": len(S_prime),
             "note": "public functions end to end (dict of 2.5 kb strings in, dict out); the timed region above starts with the store resident"}
 
 

@@ -10,8 +10,12 @@
  *
  * Conventions: plain pointers and sizes only; the caller owns every buffer; every function returns an
  * isocon_status (0 = OK, negative = error) and never throws; all calls block until results are in host memory.
- * Sequences are upper-case ACGT (the reference builds its parasail matrix on "ACGT",
- * modules/SW_alignment_module.py:65); anything else is rejected with ISOCON_E_ALPHABET.
+ * Sequences are upper-case ACGT in all shipped data.  A set over another alphabet of AT MOST FOUR distinct symbols (lower case, RNA ...)
+ * is packed under its own symbol map and serves the distance, nearest-neighbour and infix entry points -- they only compare symbols for
+ * equality, as edlib does with whatever characters it is given (modules/edlib_alignment_module.py:111,
+ * modules/nearest_neighbor_graph.py:105) --, while the alignment and consensus entry points refuse it (the reference builds its parasail
+ * matrix on "ACGT", modules/SW_alignment_module.py:65).  A set with more than four distinct symbols (e.g. ACGT + N) is rejected with
+ * ISOCON_E_ALPHABET by the store constructors: two bits per base cannot hold a fifth symbol.
  */
 #ifndef ISOCON_HIP_H
 #define ISOCON_HIP_H
@@ -25,7 +29,7 @@ extern "C" {
 typedef enum {
     ISOCON_OK = 0,
     ISOCON_E_ARG = -1,        /* bad argument */
-    ISOCON_E_ALPHABET = -2,   /* non-ACGT symbol */
+    ISOCON_E_ALPHABET = -2,   /* more than four distinct symbols in a set / an alignment entry point on a set that is not over ACGT */
     ISOCON_E_HIP = -3,        /* HIP runtime error (isocon_last_error() has the text) */
     ISOCON_E_CAPACITY = -4,   /* caller buffer too small; required size written back */
     ISOCON_E_NODEVICE = -5,   /* no usable GPU */

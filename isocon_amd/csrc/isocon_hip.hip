@@ -116,7 +116,7 @@ enum {
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED, SLOT_MSA_ROWS, SLOT_MSA_OPS, SLOT_MSA_OPTR, SLOT_MSA_LONGEST, SLOT_MSA_WIDTH, SLOT_MSA_CSLOT, SLOT_MSA_LTOT, SLOT_MSA_WIDE, SLOT_MSA_PROW, SLOT_MSA_PCOL, SLOT_MSA_PPTR, SLOT_MSA_PBYTES,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES, SLOT_HW_PQ, SLOT_HW_KEY, SLOT_HW_HIST, SLOT_HW_CURSOR, SLOT_HW_TBASE, SLOT_HW_CLS,
-    SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD, SLOT_SCAN_TMP, SLOT_SCAN_SUMS,
+    SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD, SLOT_PACK_HIST, SLOT_SCAN_TMP, SLOT_SCAN_SUMS,
     SLOT_COUNT
 };
 static_assert(SLOT_COUNT <= 128, "ScratchPool::slots too small");
@@ -134,6 +134,12 @@ struct isocon_store {
     std::vector<int32_t> lens;   // host copy
     uint64_t device_bytes = 0;
     uint64_t *d_planes = nullptr;
+    // The four symbols of the set, code 0 .. 3.  "ACGT" for every shipped data set; a set over another alphabet of at most four
+    // symbols (lower case, RNA) is packed under its own map: distances and the NN graph only compare symbols for equality, exactly
+    // what edlib does with whatever characters it is given (EAM:111, NNG:105).  The entry points that emit letters or score with the
+    // reference's "ACGT" matrix (alignments, consensus) refuse such a store (ISOCON_E_ALPHABET).
+    char alphabet[4] = {'A', 'C', 'G', 'T'};
+    bool acgt = true;
     int32_t *d_lens = nullptr;
     int32_t maxlen = 0;
 };
@@ -262,8 +268,21 @@ struct EventTimer {
 // Packs ASCII sequences into the store's bit-planes: one wavefront per (sequence, 64-base chunk) -- a coalesced 64-byte load,
 // the two code bits of every base become the chunk's two words through two ballots.  *first_bad receives the smallest
 // (sequence << 32 | position) holding a symbol outside ACGT.
+struct PackMap { uint8_t sym[4]; };
+
+// how often every byte value occurs in the uploaded sequences (only looked at when a symbol outside ACGT turned up)
+__global__ __launch_bounds__(256) void k_byte_histogram(const uint8_t *__restrict__ ascii, uint64_t total, unsigned long long *__restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) atomicAdd(&h[ascii[i]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, (unsigned long long)h[threadIdx.x]);
+}
+
 __global__ __launch_bounds__(256) void k_pack_planes(const uint8_t *__restrict__ ascii, const uint64_t *__restrict__ offsets, uint64_t base, uint32_t n,
-                                                      uint32_t nchunks, uint64_t *__restrict__ planes, unsigned long long *__restrict__ first_bad)
+                                                      uint32_t nchunks, uint64_t *__restrict__ planes, unsigned long long *__restrict__ first_bad, PackMap map)
 {
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (uint64_t)nchunks * n) return;
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(256) void k_pack_planes(const uint8_t *__restrict__
     bool bad = false;
     if (pos < len) {
         const uint8_t ch = ascii[off + pos];
-        cd = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
+        cd = ch == map.sym[0] ? 0 : ch == map.sym[1] ? 1 : ch == map.sym[2] ? 2 : ch == map.sym[3] ? 3 : -1;
         bad = cd < 0;
     }
     const unsigned long long lo = __ballot(!bad && (cd & 1)), hi = __ballot(!bad && (cd & 2)), bm = __ballot(bad);
@@ -409,7 +428,7 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
             if (n) {
                 const uint64_t waves = (uint64_t)nchunks * n;
                 hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
-                                   st->d_planes, d_bad.as<unsigned long long>());
+                                   st->d_planes, d_bad.as<unsigned long long>(), PackMap{{'A', 'C', 'G', 'T'}});
             } else {
                 ok = hipMemset(st->d_planes, 0, pbytes) == hipSuccess;
             }
@@ -422,9 +441,49 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
             return ISOCON_E_HIP;
         }
         if (bad != none) {
-            g_last_error = "sequence " + std::to_string((uint32_t)(bad >> 32)) + " position " + std::to_string((uint32_t)bad) + ": symbol outside ACGT";
-            isocon_store_destroy(st);
-            return ISOCON_E_ALPHABET;
+            // A symbol outside ACGT.  edlib takes any characters (EAM:111, NNG:105): if the whole set uses at most four distinct symbols
+            // (lower case, RNA ...) it is packed again under its own map -- A, C, G, T keep their codes if present, the other symbols take
+            // the free codes in byte order -- and serves the distance / NN entry points; more than four symbols cannot be held in 2 bits.
+            DevBuf d_hist(&g_scratch, SLOT_PACK_HIST);
+            unsigned long long hist[256];
+            bool hok = d_hist.alloc(256 * 8) == ISOCON_OK && hipMemset(d_hist.p, 0, 256 * 8) == hipSuccess;
+            if (hok) {
+                hipLaunchKernelGGL(k_byte_histogram, dim3(1024), dim3(256), 0, 0, d_ascii.as<uint8_t>(), (uint64_t)total, d_hist.as<unsigned long long>());
+                hok = hipGetLastError() == hipSuccess && hipMemcpy(hist, d_hist.p, sizeof(hist), hipMemcpyDeviceToHost) == hipSuccess;
+            }
+            int distinct = 0;
+            for (int c = 0; hok && c < 256; ++c) distinct += hist[c] != 0;
+            if (!hok || distinct > 4) {
+                g_last_error = "sequence " + std::to_string((uint32_t)(bad >> 32)) + " position " + std::to_string((uint32_t)bad) + ": symbol outside ACGT" +
+                               (hok ? " (the set uses " + std::to_string(distinct) + " distinct symbols; at most four can be packed)" : "");
+                isocon_store_destroy(st);
+                return ISOCON_E_ALPHABET;
+            }
+            PackMap map{{0, 0, 0, 0}};
+            bool used[4] = {false, false, false, false};
+            const char acgt_sym[4] = {'A', 'C', 'G', 'T'};
+            for (int k = 0; k < 4; ++k) if (hist[(uint8_t)acgt_sym[k]]) { map.sym[k] = (uint8_t)acgt_sym[k]; used[k] = true; }
+            for (int c = 0; c < 256; ++c) {
+                if (!hist[c] || c == 'A' || c == 'C' || c == 'G' || c == 'T') continue;
+                for (int k = 0; k < 4; ++k) if (!used[k]) { map.sym[k] = (uint8_t)c; used[k] = true; break; }
+            }
+            // (free codes keep byte 0, which no sequence holds: C strings)  -- a 0 byte in the input would be one of the four symbols
+            for (int k = 0; k < 4; ++k) if (!used[k]) { for (int c = 1; c < 256; ++c) if (!hist[c] && c != map.sym[0] && c != map.sym[1] && c != map.sym[2] && c != map.sym[3]) { map.sym[k] = (uint8_t)c; break; } }
+            bool rok = hipMemcpy(d_bad.p, &none, 8, hipMemcpyHostToDevice) == hipSuccess;
+            if (rok) {
+                const uint64_t waves = (uint64_t)nchunks * n;
+                hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
+                                   st->d_planes, d_bad.as<unsigned long long>(), map);
+                rok = hipGetLastError() == hipSuccess && hipMemcpy(&bad, d_bad.p, 8, hipMemcpyDeviceToHost) == hipSuccess && bad == none;
+            }
+            if (!rok) {
+                g_last_error = "isocon_store_create: packing under the set's own alphabet failed";
+                (void)hipGetLastError();
+                isocon_store_destroy(st);
+                return ISOCON_E_HIP;
+            }
+            for (int k = 0; k < 4; ++k) st->alphabet[k] = (char)map.sym[k];
+            st->acgt = false;
         }
     }
     st->device_bytes = pbytes + lbytes;
@@ -766,7 +825,7 @@ extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, cons
     s->pool.bound_tag.valid = false;          // the profile slot is shared with the bound matrix builds
     ISO_HIP_CHECK(copy_h2d(d_a.p, a, n_pairs * 4));
     ISO_HIP_CHECK(copy_h2d(d_b.p, b, n_pairs * 4));
-    hipLaunchKernelGGL(k_qgram_profile4, dim3(n), dim3(256), 0, 0, s->dev, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad);
+    hipLaunchKernelGGL(k_qgram_profile4, dim3((n + QP_SEQS - 1) / QP_SEQS), dim3(256), 0, 0, s->dev, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad);
     ISO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_qgram_lb_pairs, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad, d_a.as<uint32_t>(),
                        d_b.as<uint32_t>(), n_pairs, d_out.as<int32_t>());

@@ -59,59 +59,75 @@ __device__ __forceinline__ uint32_t qg_spread8(uint32_t x)
 }
 
 // prof4[kb][row][QM_ROWB]: the 128 elements kb * 128 .. + 127 of every profile, 4 bits each (n_pad rows per K-block);
-// psum[i] = sum of the stored vector.  One workgroup per sequence: presence bitset + excess counters in LDS.
+// psum[i] = sum of the stored vector.  One workgroup per QP_SEQS consecutive sequences: presence bitset + excess counters in LDS, one
+// sequence after the other; the rows of a K-block are adjacent in memory, so the workgroup's QP_SEQS rows leave as pieces of
+// QP_SEQS x 64 contiguous bytes (one sequence per workgroup wrote 64-byte pieces: half a cache line each, 0.50 ms at C3; four: 0.3x ms).
+static constexpr int QP_SEQS = 4;
+
 __global__ __launch_bounds__(256) void k_qgram_profile4(DevStore S, uint8_t *__restrict__ prof4, uint32_t *__restrict__ psum, uint32_t n_pad)
 {
-    __shared__ uint32_t bits[QM_K / 32];            // presence bits, then QG_CAP level bitsets of the excess bins
+    __shared__ uint32_t bits[QP_SEQS][QM_K / 32];            // presence bits, then QG_CAP level bitsets of the excess bins
     __shared__ uint32_t exh[QG_B1];
-    __shared__ uint32_t s_sum;
-    const uint32_t i = blockIdx.x;
-    if (i >= S.n) return;
-    for (int e = threadIdx.x; e < QM_K / 32; e += 256) bits[e] = 0;
-    for (int e = threadIdx.x; e < QG_B1; e += 256) exh[e] = 0;
-    if (threadIdx.x == 0) s_sum = 0;
-    __syncthreads();
-    const int32_t ngrams = S.lens[i] - QG_Q + 1;
-    for (int32_t j = threadIdx.x; j < ngrams; j += 256) {
-        const int32_t c = j >> 6, o = j & 63;
-        const size_t at = ((size_t)c * S.n + i) * 2;
-        uint64_t lo = S.planes[at] >> o, hi = S.planes[at + 1] >> o;
-        if (o > 64 - QG_Q) {
-            const size_t at2 = ((size_t)(c + 1) * S.n + i) * 2;
-            lo |= S.planes[at2] << (64 - o);
-            hi |= S.planes[at2 + 1] << (64 - o);
+    __shared__ uint32_t s_sum[QP_SEQS];
+    const uint32_t i0 = blockIdx.x * (uint32_t)QP_SEQS;
+    if (i0 >= S.n) return;
+    const uint32_t cnt = S.n - i0 < (uint32_t)QP_SEQS ? S.n - i0 : (uint32_t)QP_SEQS;
+    for (int e = threadIdx.x; e < QP_SEQS * (QM_K / 32); e += 256) (&bits[0][0])[e] = 0;
+    if (threadIdx.x < QP_SEQS) s_sum[threadIdx.x] = 0;
+    for (uint32_t r = 0; r < cnt; ++r) {
+        const uint32_t i = i0 + r;
+        for (int e = threadIdx.x; e < QG_B1; e += 256) exh[e] = 0;
+        __syncthreads();
+        const int32_t ngrams = S.lens[i] - QG_Q + 1;
+        for (int32_t j = threadIdx.x; j < ngrams; j += 256) {
+            const int32_t c = j >> 6, o = j & 63;
+            const size_t at = ((size_t)c * S.n + i) * 2;
+            uint64_t lo = S.planes[at] >> o, hi = S.planes[at + 1] >> o;
+            if (o > 64 - QG_Q) {
+                const size_t at2 = ((size_t)(c + 1) * S.n + i) * 2;
+                lo |= S.planes[at2] << (64 - o);
+                hi |= S.planes[at2 + 1] << (64 - o);
+            }
+            const uint32_t mask = (1u << QG_Q) - 1u;
+            const uint32_t bin = qg_bin(((uint32_t)lo & mask) | (((uint32_t)hi & mask) << QG_Q));
+            const uint32_t bit = 1u << (bin & 31u);
+            const uint32_t old = atomicOr(&bits[r][bin >> 5], bit);
+            if (old & bit) atomicAdd(&exh[bin % (uint32_t)QG_B1], 1u);       // every occurrence after the first is excess
         }
-        const uint32_t mask = (1u << QG_Q) - 1u;
-        const uint32_t bin = qg_bin(((uint32_t)lo & mask) | (((uint32_t)hi & mask) << QG_Q));
-        const uint32_t bit = 1u << (bin & 31u);
-        const uint32_t old = atomicOr(&bits[bin >> 5], bit);
-        if (old & bit) atomicAdd(&exh[bin % (uint32_t)QG_B1], 1u);       // every occurrence after the first is excess
-    }
-    __syncthreads();
-    // level bitsets of the excess bins: one ballot per 64 bins and level
-    for (int j0 = (threadIdx.x & ~63); j0 < QG_B1; j0 += 256) {
-        const uint32_t v = exh[j0 + (threadIdx.x & 63)];
+        __syncthreads();
+        // level bitsets of the excess bins: one ballot per 64 bins and level
+        for (int j0 = (threadIdx.x & ~63); j0 < QG_B1; j0 += 256) {
+            const uint32_t v = exh[j0 + (threadIdx.x & 63)];
 #pragma unroll
-        for (int t = 0; t < QG_CAP; ++t) {
-            const unsigned long long m = __ballot(v > (uint32_t)t);
-            if ((threadIdx.x & 63) == 0) {
-                bits[(QG_B0 + t * QG_B1 + j0) / 32] = (uint32_t)m;
-                bits[(QG_B0 + t * QG_B1 + j0) / 32 + 1] = (uint32_t)(m >> 32);
+            for (int t = 0; t < QG_CAP; ++t) {
+                const unsigned long long m = __ballot(v > (uint32_t)t);
+                if ((threadIdx.x & 63) == 0) {
+                    bits[r][(QG_B0 + t * QG_B1 + j0) / 32] = (uint32_t)m;
+                    bits[r][(QG_B0 + t * QG_B1 + j0) / 32 + 1] = (uint32_t)(m >> 32);
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t local = 0;
-    for (int c = threadIdx.x; c < QM_K / 32; c += 256) {
-        const uint32_t w = bits[c];
-        local += (uint32_t)__popc(w);
-        uint4 o;
-        o.x = qg_spread8(w & 0xffu); o.y = qg_spread8((w >> 8) & 0xffu); o.z = qg_spread8((w >> 16) & 0xffu); o.w = qg_spread8(w >> 24);
-        *reinterpret_cast<uint4 *>(prof4 + ((size_t)(c / QM_SLOTS) * n_pad + i) * QM_ROWB + (size_t)(c % QM_SLOTS) * 16) = o;
+    // write: element e = (K-block, sequence, 16-byte slot) in memory order: consecutive threads fill QP_SEQS x 64 contiguous bytes
+    uint32_t local[QP_SEQS];
+#pragma unroll
+    for (int r = 0; r < QP_SEQS; ++r) local[r] = 0;
+    for (int e = threadIdx.x; e < QP_SEQS * (QM_K / 32); e += 256) {
+        const int kb = e / (QP_SEQS * QM_SLOTS), r = (e / QM_SLOTS) % QP_SEQS, sl = e % QM_SLOTS;
+        const uint32_t w = bits[r][kb * QM_SLOTS + sl];
+#pragma unroll
+        for (int rr = 0; rr < QP_SEQS; ++rr) local[rr] += rr == r ? (uint32_t)__popc(w) : 0u;
+        if ((uint32_t)r < cnt) {
+            uint4 o;
+            o.x = qg_spread8(w & 0xffu); o.y = qg_spread8((w >> 8) & 0xffu); o.z = qg_spread8((w >> 16) & 0xffu); o.w = qg_spread8(w >> 24);
+            *reinterpret_cast<uint4 *>(prof4 + ((size_t)kb * n_pad + i0 + (uint32_t)r) * QM_ROWB + (size_t)sl * 16) = o;
+        }
     }
-    atomicAdd(&s_sum, local);
+#pragma unroll
+    for (int r = 0; r < QP_SEQS; ++r) if (local[r]) atomicAdd(&s_sum[r], local[r]);
     __syncthreads();
-    if (threadIdx.x == 0) psum[i] = s_sum;
+    if (threadIdx.x < cnt) psum[i0 + threadIdx.x] = s_sum[threadIdx.x];
 }
 
 typedef int qm_v8i __attribute__((ext_vector_type(8)));

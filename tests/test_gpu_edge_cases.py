@@ -121,3 +121,59 @@ def test_non_acgt_symbols_are_rejected_with_the_first_position():
     st = SeqStore(["", "ACGT", ""])
     assert list(st.ed_pairs([0, 0, 1], [1, 2, 2])) == [4, 0, 4]
     st.close()
+
+
+@pytest.mark.gpu
+def test_sets_over_another_alphabet_of_at_most_four_symbols():
+    """edlib takes any characters (EAM:111, NNG:105): a set in lower case, an RNA set, a two-symbol set and a set that mixes cases within
+    four symbols are packed under their own symbol map; distances equal the textbook DP on the bytes (oracle orc_ed_dp) and the NN graph
+    equals the oracle loop.  The alignment entry points refuse such a store (parasail's matrix is over "ACGT", SWM:65)."""
+    import random
+    from isocon_amd import _lib
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    rng = random.Random(12)
+
+    def family(alphabet, n, L):
+        root = [rng.choice(alphabet) for _ in range(L)]
+        out = []
+        for _ in range(n):
+            s = list(root)
+            for _ in range(rng.randrange(0, 9)):
+                i = rng.randrange(len(s))
+                r = rng.random()
+                if r < 0.4:
+                    s[i] = rng.choice(alphabet)
+                elif r < 0.7:
+                    del s[i]
+                else:
+                    s.insert(i, rng.choice(alphabet))
+            out.append("".join(s))
+        return out
+
+    for alphabet in ("acgt", "ACGU", "AB", "aCgT", "ACG"):
+        seqs = sorted(set(family(alphabet, 40, 150) + family(alphabet, 30, 90)), key=len)
+        st = SeqStore(seqs)
+        try:
+            a = [rng.randrange(len(seqs)) for _ in range(200)]
+            b = [rng.randrange(len(seqs)) for _ in range(200)]
+            got = st.ed_pairs(a, b, None)
+            assert got.tolist() == [O.ed_dp(seqs[x], seqs[y]) for x, y in zip(a, b)], alphabet
+            k = [rng.randrange(0, 12) for _ in range(200)]
+            gk = st.ed_pairs(a, b, k)
+            assert gk.tolist() == [d if d <= kk else -1 for d, kk in zip(got.tolist(), k)]
+            if alphabet != "ACG":          # (a subset of ACGT is an ordinary store)
+                with pytest.raises(_lib.IsoconError) as e:
+                    st.sg_trace(a[:4], b[:4], -2)
+                assert "ACGT" in str(e.value)
+        finally:
+            st.close()
+        S = {"r%d" % i: s for i, s in enumerate(seqs)}
+        g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+        g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+        assert ordered(g_gpu) == ordered(g_cpu), alphabet
+    # a fifth symbol cannot be packed
+    with pytest.raises(_lib.IsoconError) as e:
+        SeqStore(["acgtn", "acgt"])
+    assert "5 distinct symbols" in str(e.value)
