@@ -162,13 +162,16 @@ int isocon_nn_graph(isocon_store *s, const uint8_t *is_converged, const uint8_t 
  *            own rows leave its thresholds loose: summed work x 2 to x 4 on C3, which is why isocon_amd/dist.py reduces after phase 0).
  *   phase 2: 128/256/512-row bands over the pairs whose lower index is owned and that involve an entry still
  *            unresolved in best_inout (= MIN over all ranks' phase-1 results), then the un-banded kernel for the owned
- *            queries whose neighbour is further than 511 edits.
+ *            queries whose neighbour is further than 511 edits.  wide_queries (phase 2 only; NULL = the entries that are unresolved
+ *            at the call): the queries of the WHOLE phase when the caller runs it in sub-steps over sub-shards with a reduction of
+ *            best_inout after each (isocon_amd/dist.py does: a query's threshold then has seen part of its pairs on ALL ranks from
+ *            the second sub-step on) -- wide_queries[i] != 0 for the entries that were unresolved when the phase began.
  * Each call returns up to hits_cap candidate edges (endpoint, neighbour, distance) as int32 triples.  The caller
  * min-reduces best over ranks after each phase, all-gathers the triples and calls isocon_nn_finalize.
  */
 int isocon_nn_partial(isocon_store *s, const uint8_t *is_converged, const uint8_t *is_target, uint64_t depth,
                       uint32_t q_begin, uint32_t q_end, uint32_t q_stride, uint32_t q_block, int32_t phase, int32_t *best_inout,
-                      int32_t *out_hits, uint64_t hits_cap, uint64_t *n_hits, isocon_nn_stats *stats);
+                      int32_t *out_hits, uint64_t hits_cap, uint64_t *n_hits, isocon_nn_stats *stats, const uint8_t *wide_queries);
 int isocon_nn_finalize(uint32_t n, const int32_t *best, const int32_t *hits, uint64_t n_hits,
                        int32_t *out_best, uint64_t *out_row_ptr, uint32_t *out_cols, uint64_t cols_cap,
                        uint64_t *n_cols_needed);
@@ -187,7 +190,7 @@ int isocon_nn_finalize(uint32_t n, const int32_t *best, const int32_t *hits, uin
  */
 int isocon_nn_partial_dev(isocon_store *s, const uint8_t *is_converged, const uint8_t *is_target, uint64_t depth,
                           uint32_t q_begin, uint32_t q_end, uint32_t q_stride, uint32_t q_block, int32_t phase, int32_t *best_inout_dev,
-                          int32_t keep_hits, uint64_t *n_hits_held, isocon_nn_stats *stats);
+                          int32_t keep_hits, uint64_t *n_hits_held, isocon_nn_stats *stats, const uint8_t *wide_queries);
 int isocon_nn_hits_dev(isocon_store *s, const int32_t *best_dev, int32_t *out_hits_dev, uint64_t cap_rows, uint64_t *n_kept);
 int isocon_nn_finalize_dev(isocon_store *s, const int32_t *best_dev, const int32_t *hits_dev, uint64_t n_rows,
                            int32_t *out_best, uint64_t *out_row_ptr, uint32_t *out_cols, uint64_t cols_cap, uint64_t *n_cols_needed);

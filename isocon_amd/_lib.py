@@ -64,7 +64,7 @@ SYMBOLS = {
                                        u64p, ctypes.POINTER(NNStats)]),
     "isocon_nn_partial": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                          ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, i32p, i32p, ctypes.c_uint64, u64p,
-                                         ctypes.POINTER(NNStats)]),
+                                         ctypes.POINTER(NNStats), u8p]),
     "isocon_msa_build_ops": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, u32p, u32p, u64p, u32p, u32p, u32p, u32p, ctypes.c_uint64, u64p, f32p]),
     "isocon_msa_correct_built": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, u8p, ctypes.c_uint32, i32p, u8p,
                                                 ctypes.c_uint64, u64p, i32p, ctypes.POINTER(ctypes.c_int64), f32p]),
@@ -74,7 +74,8 @@ SYMBOLS = {
     "isocon_nn_finalize": (ctypes.c_int, [ctypes.c_uint32, i32p, i32p, ctypes.c_uint64, i32p, u64p, u32p,
                                           ctypes.c_uint64, u64p]),
     "isocon_nn_partial_dev": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
-                                             ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, u64p, ctypes.POINTER(NNStats)]),
+                                             ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, u64p, ctypes.POINTER(NNStats),
+                                             u8p]),
     "isocon_nn_hits_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, u64p]),
     "isocon_nn_finalize_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, i32p, u64p, u32p,
                                               ctypes.c_uint64, u64p]),

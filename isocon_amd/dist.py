@@ -63,6 +63,28 @@ def shard_of(rank, world, n):
     return rank * block, n, world * block, block
 
 
+PHASE2_STEPS = 1          # sub-steps of the wide-band phase of a sharded search (a reduction of best[] after each); see protocol_steps
+
+
+def protocol_steps(rank, world, n, phase2_steps=None):
+    """[(phase, (q_begin, q_end, q_stride, q_block))] of one sharded search.  Phases 0 and 1 cover the rank's shard.  Phase 2 (the
+    128..512-row bands, entered only while a query longer than 63 is still unresolved) has no seeds: a query's threshold tightens only
+    through the pairs a rank itself evaluates, and with N ranks each sees 1 / N of a query's partners until the next reduction -- summed
+    work x1.24 / x1.27 at 4 / 8 ranks on the 200 000-read C5 set.  The phase CAN be run in sub-steps (the rank's blocks dealt into
+    phase2_steps sub-shards, an all_reduce(MIN) of best[] after each, the phase's query set fixed at its start and handed down as
+    `wide_queries`; any order of evaluating the pairs gives the same graph: tests/test_gpu_nn_graph.py).  Measured on 50 000 reads of the
+    C5 shape with four sub-steps (profiles/r04l_phase2_substeps.txt): the summed work falls (x1.28 -> 1.11 at 4 ranks, x1.38 -> 1.25 at 8)
+    but the critical path does not (1.77 -> 2.04 s at 2 ranks, 0.71 -> 0.83 s at 8): every sub-step pays its own sample stage and launch
+    tails, queries that already have a bound run the narrower bands again, and a quarter of a rank's blocks balances worse (max / mean
+    1.2 at 8 ranks).  So the default is ONE step."""
+    qb, qe, qs, qk = shard_of(rank, world, n)
+    steps = [(0, (qb, qe, qs, qk)), (1, (qb, qe, qs, qk))]
+    sub = (PHASE2_STEPS if phase2_steps is None else phase2_steps) if world > 1 else 1
+    for k in range(sub):
+        steps.append((2, (qb + k * qs, qe, qs * sub, qk)))
+    return steps
+
+
 def _device_path_agreed(store, n, dist, device):
     """The device-resident protocol is used only if EVERY rank can and the collectives run on the GPU: decided once per store and
     group with one all_reduce(MIN) of a capability flag (a rank deciding from its local state alone could pair a CUDA tensor with a
@@ -154,7 +176,6 @@ def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap):
     if torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev):
         raise RuntimeError("sharded_nn_graph: call it on the default stream (the library's kernels run there)")
     n = store.n
-    qb, qe, qs, qk = shard_of(rank, world, n)
     tl = time.perf_counter()
     cache = store.__dict__.setdefault("_dist_device", {})
     t = cache.get("reduce")
@@ -173,15 +194,19 @@ def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap):
     tl = lap("setup", tl)
     stats_all = []
     held = 0
-    for phase in (0, 1, 2):
-        if phase == 2 and not bool(((t[:n] == _lib.NN_INF) & far_d).any().item()):
-            stats_all.append({k: 0 for k in stats_all[-1]} if stats_all else {})
-            continue
+    wide = None          # the queries of phase 2: unresolved when the phase begins (the same on every rank: best[] is reduced)
+    for phase, (qb, qe, qs, qk) in protocol_steps(rank, world, n):
+        if phase == 2 and wide is None:
+            wide_d = (t[:n] == _lib.NN_INF) & far_d
+            if not bool(wide_d.any().item()):
+                stats_all.append({k: 0 for k in stats_all[-1]} if stats_all else {})
+                break
+            wide = wide_d.to(torch.uint8).cpu().numpy()
         err = None
         tl = time.perf_counter()
         try:
             held, stats = store.nn_partial_dev(qb, qe, phase, t.data_ptr(), phase > 0, is_converged=is_converged, is_target=is_target,
-                                               depth=depth, q_stride=qs, q_block=qk)
+                                               depth=depth, q_stride=qs, q_block=qk, wide_queries=wide if phase == 2 else None)
         except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
             err, stats = e, {}
         tl = lap("nn_partial_phase%d" % phase, tl)
@@ -256,7 +281,6 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
     if _device_path_agreed(store, n, dist, device):
         out = _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap)
         return out if return_stats else out[:3]
-    qb, qe, qs, qk = shard_of(rank, world, n)          # block-cyclic ownership
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
     nb = len(best)
@@ -271,19 +295,21 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
     # reduction between phases 0 and 1 is what keeps the work constant: a rank's seeds only tighten the entries its own rows reach,
     # and without the exchange every rank aligns against looser thresholds -- measured on C3 with the two phases fused into one call
     # (isocon_nn_partial phase 3): summed DP work x 1.98 / 2.68 / 3.94 at 2 / 4 / 8 ranks (profiles/r03d_emulate_sharding_fused.log).
-    for phase in (0, 1, 2):
-        if phase == 2:
+    wide = None          # the queries of phase 2: unresolved when the phase begins
+    for phase, (qb, qe, qs, qk) in protocol_steps(rank, world, n):          # block-cyclic ownership; phase 2 in sub-steps
+        if phase == 2 and wide is None:
             # best[] is identical on all ranks after the reduction, so all ranks skip (or run) this phase together
-            if not (is_query & (best[:n] == _lib.NN_INF) & (lens_np > 63)).any():
+            wide = (is_query & (best[:n] == _lib.NN_INF) & (lens_np > 63)).astype(np.uint8)
+            if not wide.any():
                 stats_all.append({k: 0 for k in stats_all[-1]} if stats_all else {})
-                continue
+                break
         # A rank that fails here (out of memory, a HIP error) must not leave the others blocked in the collective: its
         # status travels as one more word of the very reduction that follows (MIN: -1 wins), then every rank raises.
         err = None
         tl = time.perf_counter()
         try:
             hits, stats = store.nn_partial(qb, qe, phase, best, is_converged=is_converged, is_target=is_target, depth=depth,
-                                           q_stride=qs, q_block=qk)
+                                           q_stride=qs, q_block=qk, **({"wide_queries": wide} if phase == 2 else {}))
         except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
             err, hits, stats = e, np.zeros((0, 3), np.int32), {}
         tl = lap("nn_partial_phase%d" % phase, tl)

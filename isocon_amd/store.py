@@ -171,7 +171,7 @@ class SeqStore(object):
             _lib.check(rc, "isocon_nn_graph")
             return best[:n], row_ptr.astype(np.int64), cols[:int(row_ptr[n])], stats.as_dict()
 
-    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1):
+    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1, wide_queries=None):
         """One shard / one phase (see include/isocon_hip.h).  `best` is updated in place; returns (hits[k,3], stats)."""
         conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
         targ = None if is_target is None else np.ascontiguousarray(is_target, dtype=np.uint8)
@@ -181,11 +181,12 @@ class SeqStore(object):
         stats = _lib.NNStats()
         depth = int(min(depth, 2 ** 63 - 1))
         best0 = best.copy()
+        wq = None if wide_queries is None else np.ascontiguousarray(wide_queries, dtype=np.uint8)
         while True:
             hits = np.empty((cap, 3), dtype=np.int32)
             rc = self._L.isocon_nn_partial(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), depth, q_begin, q_end, q_stride, q_block, phase,
                                            _ptr(best, _lib.i32p), _ptr(hits, _lib.i32p), cap, ctypes.byref(n_hits),
-                                           ctypes.byref(stats))
+                                           ctypes.byref(stats), _ptr(wq, _lib.u8p))
             if rc == _lib.ISOCON_E_CAPACITY:
                 cap = int(n_hits.value) + 16
                 best[:] = best0
@@ -194,16 +195,18 @@ class SeqStore(object):
             return hits[:int(n_hits.value)], stats.as_dict()
 
     # the same protocol with best[] and the candidate edges resident in device memory (isocon_amd/dist.py on a GPU)
-    def nn_partial_dev(self, q_begin, q_end, phase, best_dev_ptr, keep_hits, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1):
+    def nn_partial_dev(self, q_begin, q_end, phase, best_dev_ptr, keep_hits, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1,
+                       wide_queries=None):
         """One shard / one phase on best[] in device memory (an int: the device address of n int32).  The phase's candidate edges join
         the list the library holds on the device (keep_hits False: a new list).  Returns (edges held, stats)."""
         conv = None if is_converged is None else np.ascontiguousarray(is_converged, dtype=np.uint8)
         targ = None if is_target is None else np.ascontiguousarray(is_target, dtype=np.uint8)
         held = ctypes.c_uint64(0)
         stats = _lib.NNStats()
+        wq = None if wide_queries is None else np.ascontiguousarray(wide_queries, dtype=np.uint8)
         _lib.check(self._L.isocon_nn_partial_dev(self._h, _ptr(conv, _lib.u8p), _ptr(targ, _lib.u8p), int(min(depth, 2 ** 63 - 1)), q_begin, q_end,
                                                  q_stride, q_block, phase, ctypes.c_void_p(int(best_dev_ptr)), 1 if keep_hits else 0, ctypes.byref(held),
-                                                 ctypes.byref(stats)), "isocon_nn_partial_dev")
+                                                 ctypes.byref(stats), _ptr(wq, _lib.u8p)), "isocon_nn_partial_dev")
         return int(held.value), stats.as_dict()
 
     def nn_hits_dev(self, best_dev_ptr, out_dev_ptr, cap_rows):

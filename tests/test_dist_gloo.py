@@ -23,7 +23,7 @@ class FakeStore(object):
         self.n = len(seqs)
         self.lens = np.array([len(s) for s in seqs], dtype=np.int64)
 
-    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1):
+    def nn_partial(self, q_begin, q_end, phase, best, is_converged=None, is_target=None, depth=2 ** 32, q_stride=1, q_block=1, wide_queries=None):
         from oracle import oracle as O
         from isocon_amd.store import shard_entries
         owned = [int(x) for x in shard_entries(q_begin, min(q_end, self.n), q_stride, q_block)]

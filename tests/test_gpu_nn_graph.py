@@ -480,3 +480,43 @@ def test_few_close_pairs_plus_far_reads_keep_both_kinds_of_edge():
     accs = list(S)
     got = {accs[i]: {accs[int(c)]: int(best[i]) for c in cols[row_ptr[i]:row_ptr[i + 1]]} for i in range(len(accs))}
     assert ordered(got) == ordered(g_cpu)
+
+
+def test_wide_band_phase_in_sub_steps_with_reductions():
+    """Phase 2 of the sharded protocol in sub-steps (dist.protocol_steps with phase2_steps = 4; the default is one step, see there): the
+    rank's blocks dealt into sub-shards, best[] min-reduced after every sub-step, the phase's query set fixed at its start (wide_queries).  Three emulated ranks on reads whose neighbours are
+    64..600 edits away plus a dense part: the same graph as the single call, and as phase 2 in one step."""
+    from isocon_amd import _lib, synth
+    from isocon_amd.dist import protocol_steps
+    from isocon_amd.store import SeqStore, nn_finalize
+    prof = dict(synth.ONT_PROFILE, rate=0.07)
+    accs, seqs, _ = synth.make_reads(700, 1100, 3, seed=1907, profile=prof)
+    accs2, seqs2, _ = synth.make_reads(600, 900, 2, seed=1908)
+    seqs = sorted(dict.fromkeys(seqs + seqs2), key=len)
+    st = SeqStore(seqs)
+    try:
+        n, world = st.n, 3
+        want = st.nn_graph()
+        assert want[3]["fallback_queries"] > 100
+        lens = np.asarray(st.lens)[:n]
+        best = np.full(n, _lib.NN_INF, dtype=np.int32)
+        hits_all, wide, phase2_steps = [], None, 0
+        for k in range(len(protocol_steps(0, world, n, 4))):
+            phase = protocol_steps(0, world, n, 4)[k][0]
+            if phase == 2 and wide is None:
+                wide = ((best == _lib.NN_INF) & (lens > 63)).astype(np.uint8)
+                assert wide.sum() > 100
+            parts = []
+            for r in range(world):
+                ph, (qb, qe, qs, qk) = protocol_steps(r, world, n, 4)[k]
+                b = best.copy()
+                hits, stats = st.nn_partial(qb, qe, ph, b, q_stride=qs, q_block=qk, wide_queries=wide if ph == 2 else None)
+                hits_all.append(hits); parts.append(b)
+            best = np.minimum.reduce(parts)
+            phase2_steps += phase == 2
+        assert phase2_steps >= 2
+        hits = np.concatenate(hits_all)
+        got = nn_finalize(n, best, hits[(hits[:, 2] >= 0) & (hits[:, 2] == best[np.clip(hits[:, 0], 0, n - 1)])])
+        assert all((x == y).all() for x, y in zip(got, want[:3]))
+    finally:
+        st.close()
