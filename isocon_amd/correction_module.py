@@ -89,6 +89,8 @@ def _partition_rows(batch, m):
 
 
 _CODE = np.frombuffer(b"ACGT", dtype=np.uint8)
+_PLACEMENT_CACHE = {}          # (padded longest insertion, insertion) -> bytes of get_best_solution: the same few short strings recur in every
+#                                partition and iteration (a function of its two arguments only); bounded below
 
 
 def _wide_slot_patches(members, wide, col_slot, longest):
@@ -107,7 +109,11 @@ def _wide_slot_patches(members, wide, col_slot, longest):
     long_ins = ln > 32
     tie = np.where(long_ins, np.arange(len(wide), dtype=np.int64) + 1, 0)
     k1, k2 = (slot << 32) | ln, codes.astype(np.int64)
-    order = np.lexsort((tie, k2, k1))
+    if int(ln.max()) <= 20 and int(slot.max()) < (1 << 17):
+        # the usual case: slot, length and the bases in ONE 63-bit key (17 + 6 + 40 bits): one sort instead of a three-key lexsort
+        order = np.argsort((slot << 46) | (ln << 40) | (k2 & ((1 << 40) - 1)), kind="stable")
+    else:
+        order = np.lexsort((tie, k2, k1))
     new = np.ones(len(order), dtype=bool)
     new[1:] = (np.diff(k1[order]) != 0) | (np.diff(k2[order]) != 0) | (np.diff(tie[order]) != 0)
     first = order[new]
@@ -137,8 +143,12 @@ def _wide_slot_patches(members, wide, col_slot, longest):
         lg = int(longest[t])
         mx = "-" + min(strings[i] for i in members_of_slot if len(strings[i]) == lg) + "-"
         for i in members_of_slot:
-            sol = "".join(get_best_solution(mx, strings[i])).encode()
-            sol_bytes[int(sol_off[i]):int(sol_off[i + 1])] = np.frombuffer(sol, dtype=np.uint8)
+            sol = _PLACEMENT_CACHE.get((mx, strings[i]))
+            if sol is None:
+                if len(_PLACEMENT_CACHE) > 200000:
+                    _PLACEMENT_CACHE.clear()
+                sol = _PLACEMENT_CACHE[(mx, strings[i])] = np.frombuffer("".join(get_best_solution(mx, strings[i])).encode(), dtype=np.uint8)
+            sol_bytes[int(sol_off[i]):int(sol_off[i + 1])] = sol
     # one patch per record: the bytes of its distinct insertion's placement, at its slot's first column
     p_len = sol_len[inv]
     p_ptr = np.zeros(len(wide) + 1, dtype=np.int64)
@@ -174,9 +184,14 @@ def _correct_partition_from_ops(batch, m, partition, seq_to_acc):
         if H is not None and hasattr(H, "split_ascii"):
             # the corrected rows as str objects, cut out of the packed buffer in one call
             strs = H.split_ascii(packed.ctypes.data, np.ascontiguousarray(off, dtype=np.int64).ctypes.data, nr)
-            for r in todo.tolist():
-                for acc in seq_to_acc[keys[r]]:
-                    out[acc] = strs[r]
+            rows_todo = todo.tolist()
+            acc_lists = list(map(seq_to_acc.__getitem__, map(keys.__getitem__, rows_todo)))
+            if all(map((1).__eq__, map(len, acc_lists))):          # a read that is still being corrected has multiplicity 1: one accession each
+                out.update(zip(map(next, map(iter, acc_lists)), map(strs.__getitem__, rows_todo)))
+            else:
+                for r, accs_of_r in zip(rows_todo, acc_lists):
+                    for acc in accs_of_r:
+                        out[acc] = strs[r]
         else:
             flat = packed[:off[nr]].tobytes().decode()
             for r in todo.tolist():

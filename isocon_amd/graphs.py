@@ -28,10 +28,11 @@ def _nx():
 class _Nodes(object):
     """G.nodes of a LazyDiGraph: G.nodes[seq] -> {"degree": multiplicity}, G.nodes() / iteration -> the sequences in insertion order"""
 
-    def __init__(self, names, degree):
+    def __init__(self, names, degree, counts=None):
         self._names = names
         self._degree = degree
         self._index = None
+        self._counts = counts          # {seq: multiplicity} if the builder has it anyway: degree lookups without an index of the names
 
     def _idx(self):
         if self._index is None:
@@ -39,6 +40,8 @@ class _Nodes(object):
         return self._index
 
     def __getitem__(self, seq):
+        if self._counts is not None:
+            return {"degree": self._counts[seq]}
         return {"degree": self._degree[self._idx()[seq]]}
 
     def __call__(self, data=False):
@@ -53,7 +56,7 @@ class _Nodes(object):
         return len(self._names)
 
     def __contains__(self, seq):
-        return seq in self._idx()
+        return seq in (self._counts if self._counts is not None else self._idx())
 
 
 class LazyDiGraph(object):
@@ -61,9 +64,9 @@ class LazyDiGraph(object):
     (ids into names; in the order the reference inserts them: rows in length-sorted order, neighbours in the NN order).  `.nodes` is
     answered from the arrays; any other attribute materialises the networkx.DiGraph of graphs.py:37-69 and is forwarded to it."""
 
-    def __init__(self, names, degree, ea, eb, ed):
+    def __init__(self, names, degree, ea, eb, ed, counts=None):
         self.names, self.degree, self.ea, self.eb, self.ed = names, degree, ea, eb, ed
-        self.nodes = _Nodes(names, degree)
+        self.nodes = _Nodes(names, degree, counts)
         self._g = None
 
     def to_networkx(self):
@@ -98,7 +101,7 @@ def construct_exact_nearest_neighbor_graph(S, params):
     """graphs.py:29-82.  S: {acc: seq} (not necessarily unique).  Returns (G, converged): a node per unique sequence
     with weight `degree` = multiplicity; an edge s1 -> s2 (attribute `edit_distance`) for every nearest neighbour s2 of
     a sequence s1 of multiplicity 1.  G is a LazyDiGraph (see above)."""
-    counts = Counter(S.values())                                   # multiplicities (graphs.py:37-51)
+    counts = dict(Counter(S.values()))                             # multiplicities (graphs.py:37-51); a plain dict: unknown sequences raise KeyError
     names = list({seq: None for seq in S.values()})                 # unique sequences, first appearance first (node order of the reference)
     n = len(names)
     degree = list(map(counts.__getitem__, names))
@@ -106,7 +109,7 @@ def construct_exact_nearest_neighbor_graph(S, params):
     converged = bool((deg > 1).all())                               # no sequence of multiplicity 1 left
     empty = np.zeros(0, dtype=np.int64)
     if converged:
-        return LazyDiGraph(names, degree, empty, empty, empty), converged
+        return LazyDiGraph(names, degree, empty, empty, empty, counts), converged
     # NNG.compute_nearest_neighbor_graph: unique sequences, stable sort by length (NNG:243-246)
     lens = np.fromiter(map(len, names), dtype=np.int64, count=n)
     order = np.argsort(lens, kind="stable")
@@ -121,12 +124,12 @@ def construct_exact_nearest_neighbor_graph(S, params):
         index = {s: i for i, s in enumerate(names)}
         trip = [(index[S[a1]], index[S[a2]], ed) for a1, nbrs in edges.items() if S[a1] not in has_converged for a2, ed in nbrs.items()]
         arr = np.asarray(trip, dtype=np.int64).reshape(-1, 3)
-        return LazyDiGraph(names, degree, arr[:, 0].copy(), arr[:, 1].copy(), arr[:, 2].copy()), converged
+        return LazyDiGraph(names, degree, arr[:, 0].copy(), arr[:, 1].copy(), arr[:, 2].copy(), counts), converged
     best, row_ptr, cols = nearest_neighbor_graph.nn_1set_arrays(seqs_sorted, conv, params.neighbor_search_depth)
     rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(np.asarray(row_ptr, dtype=np.int64)))
     keep = conv[rows] == 0                                          # (graphs.py:61-69 skips converged s1; they have no rows anyway)
     rows, c = rows[keep], np.asarray(cols, dtype=np.int64)[keep]
-    return LazyDiGraph(names, degree, order[rows], order[c], np.asarray(best, dtype=np.int64)[rows]), converged
+    return LazyDiGraph(names, degree, order[rows], order[c], np.asarray(best, dtype=np.int64)[rows], counts), converged
 
 
 def construct_exact_2set_nearest_neighbor_bipartite_graph(X, C, X_file, C_file, params):
