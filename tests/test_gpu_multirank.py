@@ -34,3 +34,24 @@ def test_bench_two_ranks_equal_one_rank():
     for key in ("alignments_per_step", "edges", "median_nn_distance", "graph_digest"):
         assert one["config"][key] == two["config"][key], key
     assert two["scaling"] == "strong" and two["value"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_rccl_path_at_world_size_one():
+    """The device-resident protocol of isocon_amd.dist with the REAL backend (nccl = RCCL): process group with device_id, the group-wide
+    choice of the device path, all_reduce(MIN) on the int32 bounds in device memory, all_gather_into_tensor of the edge blocks, CSR
+    from the gathered block -- with the one rank this box has (two ranks may not share a GPU under RCCL).  scripts/nccl_selfcheck.py
+    compares the sharded graph, pair distances and alignments with the single calls."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "scripts", "nccl_selfcheck.py")],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=500)
+    assert out.returncode == 0 and "nccl selfcheck ok: world 1" in out.stdout, out.stdout[-3000:]
