@@ -278,6 +278,22 @@ int isocon_msa_correct_built(isocon_store *s, uint32_t n_rows, uint32_t n_cols, 
 int isocon_msa_read_built(isocon_store *s, uint32_t n_rows, uint32_t n_cols, uint8_t *out_matrix);
 
 /*
+ * The same two steps for ALL partitions of a correction step at once (correct_strings, modules/correction_module.py:12-75, loops over the
+ * partitions -- a Pool task each; later steps of a run have hundreds to thousands of small partitions).  Rows of all partitions are
+ * concatenated: partition p = rows first_row[p] .. first_row[p + 1] (its first row is the centre, with no ops), row_ids / ops_ptr / degree
+ * index the concatenation, the slot arrays (out_col_slot, out_longest) are concatenated too (len(centre) + 1 entries per partition, in
+ * partition order).  Wide records as in isocon_msa_build_ops with the row as an index into the concatenation and the partition in word 6;
+ * patches address (row of the concatenation, column of that row's matrix).  out_n_cand[r] = -1 for a row with more correctable positions
+ * than the kernel keeps in LDS: its partition has to be corrected through the single-partition entry points (its output rows are not valid).
+ */
+int isocon_msa_build_ops_batch(isocon_store *s, uint32_t n_parts, const uint32_t *first_row, const uint32_t *row_ids, const uint32_t *ops,
+                               const uint64_t *ops_ptr, uint32_t *out_n_cols, uint32_t *out_col_slot, uint32_t *out_longest, uint32_t *out_wide,
+                               uint64_t wide_cap, uint64_t *n_wide, float *kernel_ms);
+int isocon_msa_correct_built_batch(isocon_store *s, uint32_t n_parts, uint32_t n_rows, const uint32_t *patch_row, const uint32_t *patch_col,
+                                   const uint32_t *patch_ptr, const uint8_t *patch_bytes, uint32_t n_patches, const int32_t *degree,
+                                   uint8_t *out_packed, uint64_t packed_cap, uint64_t *out_offsets, int32_t *out_n_cand, float *kernel_ms);
+
+/*
  * Batched infix ("HW") edit distance with location and path ends == edlib.align(q, t, mode="HW", task="path", k=k)
  * as consumed by edlib_traceback (modules/end_invariant_functions.py:593-620) inside get_all_NN (:622-681), the
  * candidate-vs-candidate graph of the statistical-test phase: the query is aligned globally inside the target, target

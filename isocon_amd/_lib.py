@@ -69,6 +69,9 @@ SYMBOLS = {
     "isocon_msa_correct_built": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, u8p, ctypes.c_uint32, i32p, u8p,
                                                 ctypes.c_uint64, u64p, i32p, ctypes.POINTER(ctypes.c_int64), f32p]),
     "isocon_msa_read_built": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u8p]),
+    "isocon_msa_build_ops_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, u32p, u32p, u32p, u64p, u32p, u32p, u32p, u32p, ctypes.c_uint64, u64p, f32p]),
+    "isocon_msa_correct_built_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, u8p, ctypes.c_uint32, i32p, u8p,
+                                                      ctypes.c_uint64, u64p, i32p, f32p]),
     "isocon_partition_ids": (ctypes.c_int, [ctypes.c_uint32, i32p, ctypes.c_uint64, u32p, u32p, u32p, ctypes.c_int32, u32p, ctypes.POINTER(ctypes.c_int64),
                                             u64p, u32p, u32p]),
     "isocon_nn_finalize": (ctypes.c_int, [ctypes.c_uint32, i32p, i32p, ctypes.c_uint64, i32p, u64p, u32p,

@@ -200,26 +200,120 @@ def _correct_partition_from_ops(batch, m, partition, seq_to_acc):
     return out
 
 
+def _correct_all_from_ops(batch, partition_alignments, centres, seq_to_acc):
+    """correct_to_consensus for ALL the given partitions (centres: sorted list) in one batched build + correct on the device
+    (isocon_msa_build_ops_batch / isocon_msa_correct_built_batch).  Returns ({accession: corrected sequence}, centres whose partition has a
+    row with more correctable positions than the batched kernel keeps: those go through the single-partition path)."""
+    st = batch.store
+    first_row, idx_parts, keys, deg_parts = [0], [], [], []
+    for m in centres:
+        rows = batch.rows_of[m]
+        idx_parts.append(np.asarray(rows, dtype=np.int64))
+        first_row.append(first_row[-1] + 1 + len(rows))
+        keys.append(m)
+        keys.extend(batch.pairs[p][1] for p in rows)
+        d = np.ones(1 + len(rows), dtype=np.int32)
+        d[0] = partition_alignments[m][m][3]
+        deg_parts.append(d)
+    n_parts, n_rows = len(centres), first_row[-1]
+    first_row = np.asarray(first_row, dtype=np.int64)
+    all_idx = np.concatenate(idx_parts)
+    member_row = np.ones(n_rows, dtype=bool)
+    member_row[first_row[:-1]] = False                          # the centres' rows
+    row_ids = np.empty(n_rows, dtype=np.uint32)
+    row_ids[member_row] = batch.b[all_idx]
+    row_ids[first_row[:-1]] = batch.a[np.fromiter((ix[0] for ix in idx_parts), dtype=np.int64, count=n_parts)]
+    cnt = np.zeros(n_rows, dtype=np.int64)
+    cnt[member_row] = batch.ops_ptr[all_idx + 1] - batch.ops_ptr[all_idx]
+    ops_ptr = np.zeros(n_rows + 1, dtype=np.uint64)
+    np.cumsum(cnt, out=ops_ptr[1:])
+    starts = np.zeros(n_rows, dtype=np.int64)
+    starts[member_row] = batch.ops_ptr[all_idx]
+    total = int(ops_ptr[-1])
+    src = np.repeat(starts - ops_ptr[:-1].astype(np.int64), cnt) + np.arange(total, dtype=np.int64)
+    ops = batch.ops[src] if total else np.zeros(0, dtype=np.uint32)
+    n_cols, slot_base, col_slot, longest, wide = st.msa_build_ops_batch(first_row, row_ids, ops, ops_ptr)
+    p_row = p_col = p_ptr = p_bytes = None
+    if len(wide):
+        order = np.argsort(wide[:, 6], kind="stable")
+        wide = wide[order]
+        cut = np.flatnonzero(np.diff(wide[:, 6].astype(np.int64))) + 1
+        rows_l, cols_l, lens_l, bytes_l = [], [], [], []
+        for part in np.split(wide, cut):
+            p = int(part[0, 6])
+            r0 = int(first_row[p])
+            local = part.copy()
+            local[:, 0] -= r0
+            members = keys[r0 + 1:int(first_row[p + 1])]
+            sb = int(slot_base[p])
+            pr, pc, pp, pb = _wide_slot_patches(members, local, col_slot[sb:int(slot_base[p + 1])], longest[sb:int(slot_base[p + 1])])
+            rows_l.append(np.asarray(pr, dtype=np.int64) + r0); cols_l.append(np.asarray(pc, dtype=np.int64)); lens_l.append(np.diff(pp.astype(np.int64))); bytes_l.append(pb)
+        p_row, p_col = np.concatenate(rows_l), np.concatenate(cols_l)
+        p_ptr = np.zeros(len(p_row) + 1, dtype=np.int64)
+        np.cumsum(np.concatenate(lens_l), out=p_ptr[1:])
+        p_bytes = np.concatenate(bytes_l)
+    deg = np.concatenate(deg_parts)
+    lens_rows = st.lens[row_ids].astype(np.int64)
+    packed, off, n_cand = st.msa_correct_built_batch(n_parts, n_rows, deg, int(lens_rows.sum()) + 16 * n_rows + 1024, p_row, p_col, p_ptr, p_bytes)
+    part_of_row = np.repeat(np.arange(n_parts), np.diff(first_row))
+    redo = sorted(set(part_of_row[n_cand < 0].tolist()))
+    ok_row = np.ones(n_rows, dtype=bool)
+    for p in redo:
+        ok_row[int(first_row[p]):int(first_row[p + 1])] = False
+    out = {}
+    todo = np.flatnonzero((deg == 1) & (n_cand > 0) & ok_row)
+    if len(todo):
+        H = _lib.pyhelp()
+        if H is not None and hasattr(H, "split_ascii"):
+            strs = H.split_ascii(packed.ctypes.data, np.ascontiguousarray(off, dtype=np.int64).ctypes.data, n_rows)
+        else:
+            flat = packed[:off[n_rows]].tobytes().decode()
+            strs = [flat[off[r]:off[r + 1]] for r in range(n_rows)]
+        rows_todo = todo.tolist()
+        acc_lists = list(map(seq_to_acc.__getitem__, map(keys.__getitem__, rows_todo)))
+        if all(map((1).__eq__, map(len, acc_lists))):          # a read that is still being corrected has multiplicity 1: one accession each
+            out.update(zip(map(next, map(iter, acc_lists)), map(strs.__getitem__, rows_todo)))
+        else:
+            for r, accs_of_r in zip(rows_todo, acc_lists):
+                for acc in accs_of_r:
+                    out[acc] = strs[r]
+    return out, [centres[p] for p in redo]
+
+
 def correct_strings(partition_alignments, seq_to_acc, ccs_dict, step, nr_cores=1, verbose=False):
     """correction_module.py:12-76.  partition_alignments: {centre: {s: (ed, aln_centre, aln_s, degree)}};
     seq_to_acc: {sequence: [accessions]}.  Returns (S_prime, S_prime_quality) -- the second is always {} here.
     A partition_alignments that still carries its alignments as CIGAR ops (isocon_get_candidates.get_partition_alignments on the
-    store the NN search remembered) is corrected from those on the device; gapped strings are never expanded."""
+    store the NN search remembered) is corrected from those on the device, ALL its partitions in one batched build + correct; gapped
+    strings are never expanded."""
     if ccs_dict:
         raise NotImplementedError("correction with CCS quality values (disabled in the reference, isocon_get_candidates.py:106)")
     S_prime = {}
     batch = getattr(partition_alignments, "batch", None)
     from_ops = batch is not None and batch.alive() and _correct_on_device is _CORRECT_ON_DEVICE
+    single = []          # partitions for the one-at-a-time paths
+    batched = []
     for m, partition in sorted(partition_alignments.items()):
-        if from_ops and len(partition) == 1 + len(batch.rows_of.get(m, [])):          # (unchanged since it was built)
-            part = _correct_partition_from_ops(batch, m, partition, seq_to_acc)
+        n_members = len(batch.rows_of.get(m, [])) if from_ops else 0
+        if from_ops and len(partition) == 1 + n_members:          # (unchanged since it was built)
+            if n_members >= 1 and partition[m][3] + n_members > 2:          # correction_module.py:263: len(partition) > 1 and N_t > 2
+                batched.append(m)
         else:
-            acc_of = {m: seq_to_acc[m]}
-            for s in partition:
-                if s in seq_to_acc:
-                    acc_of[s] = seq_to_acc[s]
-            part = correct_to_consensus(m, partition, acc_of, step, verbose)
-        for acc, s in part.items():
+            single.append(m)
+    if batched:
+        part, redo = _correct_all_from_ops(batch, partition_alignments, batched, seq_to_acc)
+        S_prime.update(part)
+        for m in redo:          # a row with more correctable positions than the batched kernel's list: the single-partition kernels
+            for acc, s in _correct_partition_from_ops(batch, m, partition_alignments[m], seq_to_acc).items():
+                assert acc not in S_prime
+                S_prime[acc] = s
+    for m in single:
+        partition = partition_alignments[m]
+        acc_of = {m: seq_to_acc[m]}
+        for s in partition:
+            if s in seq_to_acc:
+                acc_of[s] = seq_to_acc[s]
+        for acc, s in correct_to_consensus(m, partition, acc_of, step, verbose).items():
             assert acc not in S_prime
             S_prime[acc] = s
     return S_prime, {}

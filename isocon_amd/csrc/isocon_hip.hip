@@ -23,6 +23,7 @@
 #include "sg.hpp"
 #include "msa.hpp"
 #include "msa_build.hpp"
+#include "msa_batch.hpp"
 #include "hw.hpp"
 #include "hw_tiles.hpp"
 #include "ed_lanes.hpp"
@@ -76,6 +77,14 @@ struct BoundTag {
 };
 // MsaTag: the multi-alignment matrix isocon_msa_build_ops left in SLOT_MSA_IN for isocon_msa_correct_built.
 struct MsaTag { bool valid = false; uint64_t serial = 0; uint32_t n_rows = 0, n_cols = 0; };
+// MsaBatchHost: the matrices isocon_msa_build_ops_batch left on the device for isocon_msa_correct_built_batch, with the host's copy of their layout.
+struct MsaBatchHost {
+    bool valid = false;
+    uint64_t serial = 0;
+    uint32_t n_parts = 0, n_rows = 0;
+    std::vector<uint32_t> ncols, col_base, first_row;
+    std::vector<unsigned long long> m_off;
+};
 // HeldHits: candidate edges of a sharded search that stay in device memory from phase to phase (SLOT_NN_ACC_HITS), tagged with their store.
 struct HeldHits { uint64_t store_serial = 0; uint64_t rows = 0; };
 
@@ -83,10 +92,11 @@ struct HeldHits { uint64_t store_serial = 0; uint64_t rows = 0; };
 // hipMalloc/hipFree (tens of ms for the multi-GB trace scratch) every time.
 struct ScratchPool {
     struct Slot { void *p = nullptr; size_t cap = 0; };
-    Slot slots[128];
+    Slot slots[144];
     BoundTag bound_tag;
     HeldHits held_hits;
     MsaTag msa_tag;
+    MsaBatchHost msab;
     void *get(int idx, size_t bytes)
     {
         Slot &s = slots[idx];
@@ -107,6 +117,7 @@ struct ScratchPool {
         bound_tag = BoundTag();
         held_hits = HeldHits();
         msa_tag = MsaTag();
+        msab = MsaBatchHost();
     }
 };
 
@@ -114,12 +125,12 @@ enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
     SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_SLOTORDER, SLOT_NN_LBCHUNKS, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B, SLOT_NN_SEED_N, SLOT_NN_LBT, SLOT_NN_LBT_OFF, SLOT_NN_LBT_SLO, SLOT_NN_LBT_LEN, SLOT_NN_LBT_PAD, SLOT_NN_SCORE, SLOT_NN_LDEST, SLOT_NN_FIN_HITS, SLOT_NN_FIN_CNT, SLOT_NN_FIN_START, SLOT_NN_FIN_CUR, SLOT_NN_FIN_NB, SLOT_NN_FIN_LEN2, SLOT_NN_FIN_ROWPTR, SLOT_NN_FIN_COLS, SLOT_NN_FIN_FLAG, SLOT_NN_FIN_BEST, SLOT_NN_ACC_HITS, SLOT_NN_LTOT, SLOT_NN_LCHUNKS, SLOT_NN_LIST, SLOT_NN_LPA, SLOT_NN_LPB,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
-    SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED, SLOT_MSA_ROWS, SLOT_MSA_OPS, SLOT_MSA_OPTR, SLOT_MSA_LONGEST, SLOT_MSA_WIDTH, SLOT_MSA_CSLOT, SLOT_MSA_LTOT, SLOT_MSA_WIDE, SLOT_MSA_PROW, SLOT_MSA_PCOL, SLOT_MSA_PPTR, SLOT_MSA_PBYTES,
+    SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED, SLOT_MSA_ROWS, SLOT_MSA_OPS, SLOT_MSA_OPTR, SLOT_MSA_LONGEST, SLOT_MSA_WIDTH, SLOT_MSA_CSLOT, SLOT_MSA_LTOT, SLOT_MSA_WIDE, SLOT_MSA_PROW, SLOT_MSA_PCOL, SLOT_MSA_PPTR, SLOT_MSA_PBYTES, SLOT_MSAB_PART, SLOT_MSAB_FIRST, SLOT_MSAB_LM, SLOT_MSAB_SBASE, SLOT_MSAB_NCOLS, SLOT_MSAB_MOFF, SLOT_MSAB_CBASE, SLOT_MSAB_CBP, SLOT_MSAB_CBC,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES, SLOT_HW_PQ, SLOT_HW_KEY, SLOT_HW_HIST, SLOT_HW_CURSOR, SLOT_HW_TBASE, SLOT_HW_CLS,
     SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD, SLOT_PACK_HIST, SLOT_SCAN_TMP, SLOT_SCAN_SUMS,
     SLOT_COUNT
 };
-static_assert(SLOT_COUNT <= 128, "ScratchPool::slots too small");
+static_assert(SLOT_COUNT <= 144, "ScratchPool::slots too small");
 
 // One pool per process (one process drives one GPU): scratch outlives the individual stores, because the Python
 // wrappers create a fresh store per call (the reference's functions are stateless).

@@ -144,6 +144,39 @@ def test_device_built_matrix_equals_the_host_matrix(profile):
 
 
 @pytest.mark.gpu
+def test_batched_correction_equals_one_partition_at_a_time():
+    """correct_strings corrects ALL partitions of a step in one batched build + correct (isocon_msa_*_batch); the same partitions one at
+    a time through isocon_msa_build_ops / _correct_built, and the string path with the numpy checker, give the same reads.  Many small
+    partitions (40 isoforms, ONT-profile reads: wide slots) and a few large ones."""
+    from isocon_amd import correction_module as COR
+    from isocon_amd import isocon_get_candidates as IGC
+    from isocon_amd import partitions, synth
+    from oracle import correction as OC
+    for args, kw in (((1200, 600, 40), dict(seed=71, profile=synth.ONT_PROFILE)), ((1500, 900, 3), dict(seed=72))):
+        accs, seqs, _ = synth.make_reads(*args, **kw)
+        S = dict(zip(accs, seqs))
+        G, partition, M, converged = partitions.partition_strings(S, Params())
+        pa = IGC.get_partition_alignments(partition, M, G, set(), Params())
+        seq_to_acc = IGC.get_unique_seq_accessions(S)
+        batched, _ = COR.correct_strings(pa, seq_to_acc, {}, 1)
+        one_by_one = {}
+        n_parts = 0
+        for m in sorted(pa):
+            if len(pa[m]) > 1 and sum(t[3] for t in pa[m].values()) > 2:
+                one_by_one.update(COR._correct_partition_from_ops(pa.batch, m, pa[m], seq_to_acc))
+                n_parts += 1
+        assert batched == one_by_one and len(batched) > 500
+        assert n_parts >= (20 if args[2] == 40 else 3)
+        kernel = COR._correct_on_device
+        COR._correct_on_device = OC.correct_rows
+        try:
+            host, _ = COR.correct_strings(pa, seq_to_acc, {}, 1)
+        finally:
+            COR._correct_on_device = kernel
+        assert batched == host
+
+
+@pytest.mark.gpu
 def test_lazy_alignments_behave_like_the_tuples():
     """partition_alignments values of the ops path: indexing, iteration, equality with the tuples of the string path"""
     from isocon_amd import isocon_get_candidates as IGC
