@@ -260,7 +260,36 @@ static PyObject *rank_strings(PyObject *self, PyObject *args)
     Py_RETURN_NONE;
 }
 
+/* group_keys_by_value(d: dict) -> {value: [keys with that value, in d's order]}, values in first-appearance order: what
+ * isocon_get_candidates.get_unique_seq_accessions builds with a setdefault loop over 50 000 reads in every correction step
+ * (modules/isocon_get_candidates.py:22-35: {sequence: [accessions]}). */
+static PyObject *group_keys_by_value(PyObject *self, PyObject *args)
+{
+    PyObject *d;
+    if (!PyArg_ParseTuple(args, "O", &d)) return NULL;
+    if (!PyDict_Check(d)) { PyErr_SetString(PyExc_TypeError, "group_keys_by_value: a dict is required"); return NULL; }
+    PyObject *out = PyDict_New();
+    if (!out) return NULL;
+    Py_ssize_t pos = 0;
+    PyObject *key, *value;
+    while (PyDict_Next(d, &pos, &key, &value)) {
+        PyObject *lst = PyDict_GetItemWithError(out, value);          /* borrowed */
+        if (!lst) {
+            if (PyErr_Occurred()) { Py_DECREF(out); return NULL; }
+            lst = PyList_New(1);
+            if (!lst) { Py_DECREF(out); return NULL; }
+            Py_INCREF(key);
+            PyList_SET_ITEM(lst, 0, key);
+            const int rc = PyDict_SetItem(out, value, lst);
+            Py_DECREF(lst);
+            if (rc < 0) { Py_DECREF(out); return NULL; }
+        } else if (PyList_Append(lst, key) < 0) { Py_DECREF(out); return NULL; }
+    }
+    return out;
+}
+
 static PyMethodDef methods[] = {
+    {"group_keys_by_value", group_keys_by_value, METH_VARARGS, "{value: [keys]} of a dict, in insertion order"},
     {"rank_strings", rank_strings, METH_VARARGS, "rank of every string of a list in the sorted order of the list"},
     {"pair_ids", pair_ids, METH_VARARGS, "ids of the members of a list of pairs"},
     {"csr_to_dict", csr_to_dict, METH_VARARGS, "dict of dicts from the CSR arrays of a nearest-neighbour graph"},

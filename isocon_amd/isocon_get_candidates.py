@@ -16,6 +16,10 @@ _EDLIB_ALIGN, _SW_ALIGN = edlib_align_sequences, sw_align_sequences
 
 def get_unique_seq_accessions(S):
     """isocon_get_candidates.py:22-35: {seq: [acc, ...]} in first-appearance order."""
+    from . import _lib
+    H = _lib.pyhelp()
+    if H is not None and hasattr(H, "group_keys_by_value") and type(S) is dict:
+        return H.group_keys_by_value(S)          # (the same loop in C: 50 000 reads per correction step)
     seq_to_acc = {}
     for acc, seq in S.items():
         seq_to_acc.setdefault(seq, []).append(acc)

@@ -143,6 +143,23 @@ def check_rank_strings(H):
         H.rank_strings(("A",), out.ctypes.data)
 
 
+def check_group_keys_by_value(H):
+    for d in ({}, {"a": "X"}, {"a": "X", "b": "Y", "c": "X", "d": "Z", "e": "Y"}, {i: i % 7 for i in range(1000)}):
+        want = {}
+        for k, v in d.items():
+            want.setdefault(v, []).append(k)
+        got = H.group_keys_by_value(d)
+        assert got == want and list(got) == list(want)
+    with pytest.raises(TypeError):
+        H.group_keys_by_value([("a", "X")])
+    with pytest.raises(TypeError):
+        H.group_keys_by_value({"a": ["unhashable"]})
+
+
+def test_group_keys_by_value():
+    check_group_keys_by_value(_helper())
+
+
 def test_rank_strings():
     check_rank_strings(_helper())
 
@@ -187,6 +204,6 @@ def test_under_address_and_undefined_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
                ISOCON_PYHELP_UNDER_TEST=so)
     code = ("import sys; sys.path.insert(0, %r); import test_pyhelp as T; H = T._helper(); "
-            "T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_csr_to_dict(H); T.check_pair_ids(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
+            "T.check_group_keys_by_value(H); T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_csr_to_dict(H); T.check_pair_ids(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
