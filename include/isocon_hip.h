@@ -10,12 +10,18 @@
  *
  * Conventions: plain pointers and sizes only; the caller owns every buffer; every function returns an
  * isocon_status (0 = OK, negative = error) and never throws; all calls block until results are in host memory.
- * Sequences are upper-case ACGT in all shipped data.  A set over another alphabet of AT MOST FOUR distinct symbols (lower case, RNA ...)
- * is packed under its own symbol map and serves the distance, nearest-neighbour and infix entry points -- they only compare symbols for
- * equality, as edlib does with whatever characters it is given (modules/edlib_alignment_module.py:111,
- * modules/nearest_neighbor_graph.py:105) --, while the alignment and consensus entry points refuse it (the reference builds its parasail
- * matrix on "ACGT", modules/SW_alignment_module.py:65).  A set with more than four distinct symbols (e.g. ACGT + N) is rejected with
- * ISOCON_E_ALPHABET by the store constructors: two bits per base cannot hold a fifth symbol.
+ * Alphabet.  Sequences are upper-case ACGT in all shipped data.  edlib compares whatever characters it is given
+ * (modules/edlib_alignment_module.py:111, modules/nearest_neighbor_graph.py:105), so the distance and nearest-neighbour entry points
+ * take ANY bytes, with the same results as a textbook edit distance over those bytes ('N' equals 'N', 'a' differs from 'A'):
+ *   - a set over at most four distinct symbols (lower case, RNA ...) is packed in two bits per base under its own symbol map and runs
+ *     through the same kernels as ACGT (distances, nearest neighbours, infix alignments);
+ *   - a set with MORE than four distinct symbols (ACGT + N, mixed case) keeps its bytes on the device beside the 2-bit planes; a pair
+ *     in which a sequence holds a symbol outside ACGT is aligned on the bytes by a separate kernel (one wavefront per pair, exact, much
+ *     slower per pair than the bit-vector kernels -- isocon_nn_stats.pairs_bytes counts them), all other pairs are not affected.
+ *     isocon_ed_pairs and the nearest-neighbour entry points serve such a set; isocon_hw_pairs and the q-gram bound test entry points
+ *     return ISOCON_E_ALPHABET.
+ * The alignment and consensus entry points need ACGT (the reference builds its parasail matrix on "ACGT",
+ * modules/SW_alignment_module.py:65; what parasail does off that alphabet is not pinned): ISOCON_E_ALPHABET on any other set.
  */
 #ifndef ISOCON_HIP_H
 #define ISOCON_HIP_H
@@ -29,7 +35,7 @@ extern "C" {
 typedef enum {
     ISOCON_OK = 0,
     ISOCON_E_ARG = -1,        /* bad argument */
-    ISOCON_E_ALPHABET = -2,   /* more than four distinct symbols in a set / an alignment entry point on a set that is not over ACGT */
+    ISOCON_E_ALPHABET = -2,   /* an entry point that needs ACGT (alignments, consensus) or 2-bit planes (infix, bound tests) on a set that is not such */
     ISOCON_E_HIP = -3,        /* HIP runtime error (isocon_last_error() has the text) */
     ISOCON_E_CAPACITY = -4,   /* caller buffer too small; required size written back */
     ISOCON_E_NODEVICE = -5,   /* no usable GPU */
@@ -125,6 +131,7 @@ typedef struct {
     uint64_t pairs_wide_to_lanes; /* of pairs_lanes: pairs with a threshold above 31 sent there because of it (ISOCON_DEBUG_VARIANT=nn_narrow=1 only) */
     uint64_t narrow_columns;      /* of cells_columns: columns run by the 32-row form of the table kernel */
     uint64_t pairs_narrow;        /* pairs listed in chunks of the 32-row class */
+    uint64_t pairs_bytes;         /* pairs with a sequence that holds symbols outside the 2-bit map, aligned on the bytes (see "Alphabet") */
 } isocon_nn_stats;
 
 /*

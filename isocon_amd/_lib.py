@@ -34,7 +34,7 @@ class NNStats(ctypes.Structure):
                 ("scan_launches", ctypes.c_uint32), ("pairs_prefiltered", ctypes.c_uint64), ("bound_kernel_ms", ctypes.c_float),
                 ("list_kernel_ms", ctypes.c_float), ("lanes_kernel_ms", ctypes.c_float), ("narrow_kernel_ms", ctypes.c_float),
                 ("pairs_lanes", ctypes.c_uint64), ("bound_tiles", ctypes.c_uint64), ("pairs_wide_to_lanes", ctypes.c_uint64),
-                ("narrow_columns", ctypes.c_uint64), ("pairs_narrow", ctypes.c_uint64)]
+                ("narrow_columns", ctypes.c_uint64), ("pairs_narrow", ctypes.c_uint64), ("pairs_bytes", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

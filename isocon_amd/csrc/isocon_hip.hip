@@ -27,6 +27,7 @@
 #include "hw.hpp"
 #include "hw_tiles.hpp"
 #include "ed_lanes.hpp"
+#include "ed_bytes.hpp"
 
 namespace isocon {
 thread_local std::string g_last_error;
@@ -92,7 +93,7 @@ struct HeldHits { uint64_t store_serial = 0; uint64_t rows = 0; };
 // hipMalloc/hipFree (tens of ms for the multi-GB trace scratch) every time.
 struct ScratchPool {
     struct Slot { void *p = nullptr; size_t cap = 0; };
-    Slot slots[144];
+    Slot slots[152];
     BoundTag bound_tag;
     HeldHits held_hits;
     MsaTag msa_tag;
@@ -127,10 +128,10 @@ enum {
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED, SLOT_MSA_ROWS, SLOT_MSA_OPS, SLOT_MSA_OPTR, SLOT_MSA_LONGEST, SLOT_MSA_WIDTH, SLOT_MSA_CSLOT, SLOT_MSA_LTOT, SLOT_MSA_WIDE, SLOT_MSA_PROW, SLOT_MSA_PCOL, SLOT_MSA_PPTR, SLOT_MSA_PBYTES, SLOT_MSAB_PART, SLOT_MSAB_FIRST, SLOT_MSAB_LM, SLOT_MSAB_SBASE, SLOT_MSAB_NCOLS, SLOT_MSAB_MOFF, SLOT_MSAB_CBASE, SLOT_MSAB_CBP, SLOT_MSAB_CBC,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES, SLOT_HW_PQ, SLOT_HW_KEY, SLOT_HW_HIST, SLOT_HW_CURSOR, SLOT_HW_TBASE, SLOT_HW_CLS,
-    SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD, SLOT_PACK_HIST, SLOT_SCAN_TMP, SLOT_SCAN_SUMS,
+    SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD, SLOT_PACK_HIST, SLOT_PACK_FLAGS, SLOT_EB_A, SLOT_EB_B, SLOT_EB_K, SLOT_EB_OUT, SLOT_EB_ROWS, SLOT_SCAN_TMP, SLOT_SCAN_SUMS,
     SLOT_COUNT
 };
-static_assert(SLOT_COUNT <= 144, "ScratchPool::slots too small");
+static_assert(SLOT_COUNT <= 152, "ScratchPool::slots too small");
 
 // One pool per process (one process drives one GPU): scratch outlives the individual stores, because the Python
 // wrappers create a fresh store per call (the reference's functions are stateless).
@@ -151,6 +152,16 @@ struct isocon_store {
     // reference's "ACGT" matrix (alignments, consensus) refuse such a store (ISOCON_E_ALPHABET).
     char alphabet[4] = {'A', 'C', 'G', 'T'};
     bool acgt = true;
+    // More than four distinct symbols (ACGT + N, mixed case ...): the planes hold the "ACGT" map with code 0 at every other byte, the
+    // bytes themselves stay on the device and exc[i] marks the sequences that hold such a byte ("exceptional").  A pair with an
+    // exceptional sequence is aligned by k_ed_bytes (ed_bytes.hpp) on the bytes; the bit-vector kernels never see it.
+    uint8_t *d_bytes = nullptr;
+    uint64_t *d_boff = nullptr;
+    uint64_t bytes_base = 0;
+    std::vector<uint8_t> exc;
+    std::vector<uint32_t> exc_count;          // such bytes per sequence
+    uint32_t n_exc = 0;
+    bool is_exc(uint32_t i) const { return n_exc != 0 && exc[i] != 0; }
     int32_t *d_lens = nullptr;
     int32_t maxlen = 0;
 };
@@ -367,6 +378,10 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
     }
     const uint32_t nchunks = (uint32_t)((maxlen + 63) / 64 + 1);
     const uint32_t nn = std::max<uint32_t>(n, 1);
+    if ((uint64_t)nchunks * nn >= ((uint64_t)1 << 26)) {          // k_pack_planes: one wavefront per (chunk, sequence), fewer than 2^32 threads per launch
+        g_last_error = "set too large for one store: (longest sequence / 64 + 1) x sequences must stay below 2^26";
+        return ISOCON_E_UNSUPPORTED;
+    }
     std::vector<int32_t> lens(nn, 0);
     for (uint32_t i = 0; i < n; ++i) lens[i] = (int32_t)(offsets[i + 1] - offsets[i]);
     const uint64_t base = n ? offsets[0] : 0, total = n ? offsets[n] - offsets[0] : 0;
@@ -464,12 +479,39 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
             }
             int distinct = 0;
             for (int c = 0; hok && c < 256; ++c) distinct += hist[c] != 0;
-            if (!hok || distinct > 4) {
-                g_last_error = "sequence " + std::to_string((uint32_t)(bad >> 32)) + " position " + std::to_string((uint32_t)bad) + ": symbol outside ACGT" +
-                               (hok ? " (the set uses " + std::to_string(distinct) + " distinct symbols; at most four can be packed)" : "");
+            if (!hok) {
+                g_last_error = "isocon_store_create: symbol histogram failed";
+                (void)hipGetLastError();
                 isocon_store_destroy(st);
-                return ISOCON_E_ALPHABET;
+                return ISOCON_E_HIP;
             }
+            if (distinct > 4) {
+                // The first packing pass left code 0 at every byte outside "ACGT": those planes serve the pairs of ordinary sequences.
+                // The bytes and their offsets move from the scratch pool into the store, with one flag per sequence.
+                DevBuf d_flags(&g_scratch, SLOT_PACK_FLAGS);
+                st->exc.assign(nn, 0);
+                st->exc_count.assign(nn, 0);
+                bool eok = d_flags.alloc((size_t)nn * 4) == ISOCON_OK && hipMemset(d_flags.p, 0, (size_t)nn * 4) == hipSuccess &&
+                           hipMalloc((void **)&st->d_bytes, total ? total : 16) == hipSuccess && hipMalloc((void **)&st->d_boff, (size_t)(nn + 1) * 8) == hipSuccess;
+                if (eok) {
+                    const uint64_t waves = (uint64_t)nchunks * n;
+                    hipLaunchKernelGGL(k_exception_flags, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
+                                       d_flags.as<uint32_t>(), (uint32_t)'A' | ((uint32_t)'C' << 8) | ((uint32_t)'G' << 16) | ((uint32_t)'T' << 24));
+                    eok = hipGetLastError() == hipSuccess && hipMemcpy(st->exc_count.data(), d_flags.p, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                          hipMemcpy(st->d_bytes, d_ascii.p, total, hipMemcpyDeviceToDevice) == hipSuccess &&
+                          hipMemcpy(st->d_boff, d_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice) == hipSuccess;
+                }
+                if (!eok) {
+                    g_last_error = "isocon_store_create: keeping the bytes of a set with more than four symbols failed";
+                    (void)hipGetLastError();
+                    isocon_store_destroy(st);
+                    return ISOCON_E_HIP;
+                }
+                st->bytes_base = base;
+                for (uint32_t i = 0; i < n; ++i) { st->exc[i] = st->exc_count[i] != 0; st->n_exc += st->exc[i]; }
+                st->acgt = false;
+                st->device_bytes += total + (size_t)(nn + 1) * 8;
+            } else {
             PackMap map{{0, 0, 0, 0}};
             bool used[4] = {false, false, false, false};
             const char acgt_sym[4] = {'A', 'C', 'G', 'T'};
@@ -495,9 +537,10 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
             }
             for (int k = 0; k < 4; ++k) st->alphabet[k] = (char)map.sym[k];
             st->acgt = false;
+            }
         }
     }
-    st->device_bytes = pbytes + lbytes;
+    st->device_bytes += pbytes + lbytes;
     st->dev.planes = st->d_planes;
     st->dev.il = nullptr;
     st->dev.lens = st->d_lens;
@@ -546,6 +589,8 @@ void isocon_store_destroy(isocon_store *s)
     if (!s) return;
     if (s->d_planes) (void)hipFree(s->d_planes);
     if (s->d_lens) (void)hipFree(s->d_lens);
+    if (s->d_bytes) (void)hipFree(s->d_bytes);
+    if (s->d_boff) (void)hipFree(s->d_boff);
     delete s;
 }
 
@@ -625,6 +670,31 @@ int run_full(isocon_store *st, const std::vector<uint32_t> &a, const std::vector
     return ISOCON_OK;
 }
 
+// k < 0: unbounded.  One wavefront per pair, a grid of at most 8192 that strides over the list (each needs a row buffer).
+int run_bytes(isocon_store *st, const std::vector<uint32_t> &a, const std::vector<uint32_t> &b, const std::vector<int32_t> &k, std::vector<int32_t> &out, EventTimer &tm)
+{
+    const size_t np = a.size();
+    out.assign(np, -1);
+    if (!np) return ISOCON_OK;
+    if (!st->d_bytes) { g_last_error = "internal: byte-wise distances on a store that kept no bytes"; return ISOCON_E_HIP; }
+    const uint32_t row_stride = (uint32_t)st->maxlen + 130u;
+    size_t waves = std::min<size_t>(np, 8192);
+    while (waves > 256 && waves * row_stride * 4 > ((size_t)2 << 30)) waves /= 2;
+    DevBuf d_a(&st->pool, SLOT_EB_A), d_b(&st->pool, SLOT_EB_B), d_k(&st->pool, SLOT_EB_K), d_out(&st->pool, SLOT_EB_OUT), d_rows(&st->pool, SLOT_EB_ROWS);
+    int rc;
+    if ((rc = d_a.alloc(np * 4)) || (rc = d_b.alloc(np * 4)) || (rc = d_k.alloc(np * 4)) || (rc = d_out.alloc(np * 4)) || (rc = d_rows.alloc(waves * row_stride * 4))) return rc;
+    ISO_HIP_CHECK(copy_h2d(d_a.p, a.data(), np * 4));
+    ISO_HIP_CHECK(copy_h2d(d_b.p, b.data(), np * 4));
+    ISO_HIP_CHECK(copy_h2d(d_k.p, k.data(), np * 4));
+    tm.start();
+    hipLaunchKernelGGL(k_ed_bytes, dim3((unsigned)waves), dim3(64), 0, 0, ByteStore{st->d_bytes, st->d_boff, st->bytes_base, st->d_lens}, d_a.as<uint32_t>(), d_b.as<uint32_t>(),
+                       d_k.as<int32_t>(), (unsigned long long)np, d_rows.as<uint32_t>(), row_stride, d_out.as<int32_t>());
+    ISO_HIP_CHECK(hipGetLastError());
+    tm.stop();
+    ISO_HIP_CHECK(copy_d2h(out.data(), d_out.p, np * 4));
+    return ISOCON_OK;
+}
+
 }  // namespace
 
 namespace isocon {
@@ -649,8 +719,24 @@ int ed_pairs_impl(isocon_store *st, const uint32_t *a, const uint32_t *b, const 
         }
         swap_roles = db < da;
     }
-    std::vector<uint64_t> pending(n_pairs);
-    std::iota(pending.begin(), pending.end(), 0);
+    std::vector<uint64_t> pending;
+    pending.reserve(n_pairs);
+    if (st->n_exc) {
+        // pairs with a sequence that holds symbols outside the planes' map: on the bytes (ed_bytes.hpp), whatever their threshold
+        std::vector<uint64_t> xp;
+        for (uint64_t p = 0; p < n_pairs; ++p) (st->exc[a[p]] || st->exc[b[p]] ? xp : pending).push_back(p);
+        if (!xp.empty()) {
+            std::vector<uint32_t> xa(xp.size()), xb(xp.size());
+            std::vector<int32_t> xk(xp.size()), res;
+            for (size_t i = 0; i < xp.size(); ++i) { xa[i] = a[xp[i]]; xb[i] = b[xp[i]]; xk[i] = k ? k[xp[i]] : -1; }
+            int rc = run_bytes(st, xa, xb, xk, res, tm);
+            if (rc) return rc;
+            for (size_t i = 0; i < xp.size(); ++i) out_ed[xp[i]] = res[i];
+        }
+    } else {
+        pending.resize(n_pairs);
+        std::iota(pending.begin(), pending.end(), 0);
+    }
     static const int stages[4] = {1, 2, 4, 8};
     for (int si = 0; si < 4 && !pending.empty(); ++si) {
         const int W = stages[si];
@@ -819,14 +905,11 @@ extern "C" int isocon_qgram_params(int32_t *out)
     return QM_K;
 }
 
-// q-gram lower bounds of explicit pairs (qgram_mm.hpp): what the main pass of the NN search consults, exposed for tests
-extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound)
+// q-gram lower bounds of explicit pairs (qgram_mm.hpp), computed on the 2-bit planes
+namespace isocon {
+int qgram_bounds_for_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound, float *kernel_ms)
 {
-    if (!s || (n_pairs && (!a || !b || !out_bound))) return ISOCON_E_ARG;
-    if (!n_pairs) return ISOCON_OK;
     const uint32_t n = s->dev.n;
-    for (uint64_t i = 0; i < n_pairs; ++i)
-        if (a[i] >= n || b[i] >= n) { g_last_error = "pair index out of range"; return ISOCON_E_ARG; }
     const uint32_t n_pad = std::max<uint32_t>(QM_TILE, ((n + QM_TILE - 1) / QM_TILE) * QM_TILE);
     DevBuf d_prof(&s->pool, SLOT_NN_QPROF), d_sum(&s->pool, SLOT_NN_QSUM), d_a(&s->pool, SLOT_ED_TS), d_b(&s->pool, SLOT_ED_IDS), d_out(&s->pool, SLOT_ED_OUT);
     int rc;
@@ -836,13 +919,34 @@ extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, cons
     s->pool.bound_tag.valid = false;          // the profile slot is shared with the bound matrix builds
     ISO_HIP_CHECK(copy_h2d(d_a.p, a, n_pairs * 4));
     ISO_HIP_CHECK(copy_h2d(d_b.p, b, n_pairs * 4));
+    EventTimer tm;
+    tm.start();
     hipLaunchKernelGGL(k_qgram_profile4, dim3((n + QP_SEQS - 1) / QP_SEQS), dim3(256), 0, 0, s->dev, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad);
     ISO_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_qgram_lb_pairs, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, 0, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad, d_a.as<uint32_t>(),
-                       d_b.as<uint32_t>(), n_pairs, d_out.as<int32_t>());
-    ISO_HIP_CHECK(hipGetLastError());
+    // (a launch holds fewer than 2^32 threads: 2^24 pairs per launch)
+    for (uint64_t at = 0; at < n_pairs; at += (uint64_t)1 << 24) {
+        const uint64_t cnt = std::min<uint64_t>((uint64_t)1 << 24, n_pairs - at);
+        hipLaunchKernelGGL(k_qgram_lb_pairs, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, 0, d_prof.as<uint8_t>(), d_sum.as<uint32_t>(), n_pad, d_a.as<uint32_t>() + at,
+                           d_b.as<uint32_t>() + at, cnt, d_out.as<int32_t>() + at);
+        ISO_HIP_CHECK(hipGetLastError());
+    }
+    const float ms = tm.stop();
+    if (kernel_ms) *kernel_ms = ms;
     ISO_HIP_CHECK(copy_d2h(out_bound, d_out.p, n_pairs * 4));
     return ISOCON_OK;
+}
+}  // namespace isocon
+
+// ... exposed for tests: what the main pass of the NN search consults
+extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound)
+{
+    if (!s || (n_pairs && (!a || !b || !out_bound))) return ISOCON_E_ARG;
+    if (!n_pairs) return ISOCON_OK;
+    if (s->n_exc) { g_last_error = "q-gram bounds are defined on the 2-bit planes: the set holds more than four distinct symbols"; return ISOCON_E_ALPHABET; }
+    const uint32_t n = s->dev.n;
+    for (uint64_t i = 0; i < n_pairs; ++i)
+        if (a[i] >= n || b[i] >= n) { g_last_error = "pair index out of range"; return ISOCON_E_ARG; }
+    return qgram_bounds_for_pairs(s, a, b, n_pairs, out_bound, nullptr);
 }
 
 #include "nn_host.inc"
