@@ -159,3 +159,57 @@ def test_sharded_graph_with_other_symbols():
                 assert rp1.tolist() == rp2.tolist() and cols1.tolist() == cols2.tolist()
     finally:
         st.close()
+
+
+def test_device_resident_phases_with_other_symbols():
+    """isocon_nn_partial_dev / _hits_dev / _finalize_dev (the path dist.sharded_nn_graph runs on a GPU) over a set with exceptional
+    sequences: three ranks emulated on one device as in tests/test_gpu_nn_graph.py, byte-wise pairs in the main and in the wide phase."""
+    import torch
+    from isocon_amd import _lib, synth
+    from isocon_amd.dist import shard_of
+    from isocon_amd.store import SeqStore
+    rng = random.Random(8)
+    accs, seqs, _ = synth.make_reads(2000, 600, 4, seed=17)
+    seqs = list(dict.fromkeys(seqs))
+    for i in rng.sample(range(len(seqs)), 60):
+        p = rng.randrange(len(seqs[i]))
+        seqs[i] = seqs[i][:p] + "N" + seqs[i][p + 1:]
+    seqs += ["ACGT" * 40 + "TTTTGGGGCCCCAAAA" * 30, "ACGT" * 41 + "NTTTGGGGCCCCAAAA" * 30]          # far from all others: phase 2, one of them exceptional
+    seqs = sorted(dict.fromkeys(seqs), key=len)
+    conv = np.zeros(len(seqs), np.uint8); conv[::9] = 1
+    st = SeqStore(seqs)
+    try:
+        n, world = st.n, 3
+        want = st.nn_graph(is_converged=conv)
+        assert want[3]["pairs_bytes"] > 0
+        dev = torch.device("cuda", 0)
+        reduced = [torch.full((n,), _lib.NN_INF, dtype=torch.int32, device=dev)]
+        for phase in (3, 2):
+            outs = []
+            for r in range(world):
+                b = reduced[-1].clone()
+                qb, qe, qs, qk = shard_of(r, world, n)
+                st.nn_partial_dev(qb, qe, phase, b.data_ptr(), False, is_converged=conv, q_stride=qs, q_block=qk)
+                outs.append(b)
+            reduced.append(torch.stack(outs).min(dim=0).values)
+        final = reduced[-1]
+        blocks = []
+        for r in range(world):
+            held = 0
+            for i, phase in enumerate((3, 2)):
+                b = reduced[i].clone()
+                qb, qe, qs, qk = shard_of(r, world, n)
+                held, _ = st.nn_partial_dev(qb, qe, phase, b.data_ptr(), i > 0, is_converged=conv, q_stride=qs, q_block=qk)
+            blk = torch.empty((held + 1, 3), dtype=torch.int32, device=dev)
+            st.nn_hits_dev(final.data_ptr(), blk.data_ptr(), held + 1)
+            blocks.append(blk)
+        gathered = torch.cat(blocks)
+        got = st.nn_finalize_dev(final.data_ptr(), gathered.data_ptr(), gathered.shape[0])
+        assert all((x == y).all() for x, y in zip(got, want[:3]))
+        # and the graph is the oracle's
+        from isocon_amd import nearest_neighbor_graph as NNG
+        from oracle import oracle as O
+        S = {"r%d" % i: s for i, s in enumerate(seqs[::3])}
+        assert ordered(NNG.compute_nearest_neighbor_graph(S, set(), Params(1))[0]) == ordered(O.compute_nearest_neighbor_graph(S, set(), Params(1))[0])
+    finally:
+        st.close()
