@@ -88,11 +88,17 @@ def test_long_sequences_unbanded():
     assert got.tolist() == exp.tolist()
 
 
-def test_rejects_non_acgt():
+def test_other_symbols_are_symbols_of_their_own():
+    """edlib's semantics (EAM:111): 'N' is just another character (tests/test_gpu_alphabet.py has the parity cases); alignments refuse."""
     from isocon_amd import _lib
     from isocon_amd.store import SeqStore
-    with pytest.raises(_lib.IsoconError):
-        SeqStore(["ACGT", "ACNT"])
+    st = SeqStore(["ACGT", "ACNT", "ACNT" * 30, "ACGT" * 30, "acgtN"])
+    try:
+        assert st.ed_pairs([0, 1, 2, 2, 0], [1, 1, 3, 2, 4], None).tolist() == [1, 0, 30, 0, 5]
+        with pytest.raises(_lib.IsoconError):
+            st.sg_trace([0], [1], -2)
+    finally:
+        st.close()
 
 
 def test_empty_and_tiny():
