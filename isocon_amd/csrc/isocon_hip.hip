@@ -677,6 +677,7 @@ int run_bytes(isocon_store *st, const std::vector<uint32_t> &a, const std::vecto
     out.assign(np, -1);
     if (!np) return ISOCON_OK;
     if (!st->d_bytes) { g_last_error = "internal: byte-wise distances on a store that kept no bytes"; return ISOCON_E_HIP; }
+    if (st->maxlen >= (int32_t)EB_INF - 1) { g_last_error = "byte-wise distances: sequences of 8 388 606 bases and more are not supported"; return ISOCON_E_UNSUPPORTED; }
     const uint32_t row_stride = (uint32_t)st->maxlen + 130u;
     size_t waves = std::min<size_t>(np, 8192);
     while (waves > 256 && waves * row_stride * 4 > ((size_t)2 << 30)) waves /= 2;
