@@ -613,6 +613,17 @@ def other_kernels(store, seqs, lens, last, true_isoforms, ctr):
     stg.hw_pairs(gq, gt, gk, reuse_buffer=True)          # (as end_invariant_functions.get_all_NN calls it; the first call pins the result buffer)
     t0 = time.perf_counter(); gres, g_ms = stg.hw_pairs(gq, gt, gk, return_ms=True, reuse_buffer=True); g_wall = time.perf_counter() - t0
     stg.close()
+    # the byte-wise kernel (sets with more than four distinct symbols, csrc/ed_bytes.hpp): the same pairs with an 'N' put into every first sequence
+    sub = sorted(set(t.tolist()) | set(q.tolist()))
+    pos = {v: i for i, v in enumerate(sub)}
+    tset = set(t.tolist())
+    stb = SeqStore([seqs[v][:len(seqs[v]) // 2] + "N" + seqs[v][len(seqs[v]) // 2 + 1:] if v in tset else seqs[v] for v in sub])
+    bt = np.fromiter((pos[v] for v in t.tolist()), dtype=np.uint32, count=len(t))
+    bq = np.fromiter((pos[v] for v in q.tolist()), dtype=np.uint32, count=len(q))
+    k63 = np.full(len(q), 63, dtype=np.int32)
+    stb.ed_pairs(bt[:64], bq[:64], k63[:64])
+    edb, edb_ms = stb.ed_pairs(bt, bq, k63, return_ms=True)
+    stb.close()
     # the read -> candidate (2-set) search of the pipeline's last steps: all reads against the true isoforms
     cands = [c for c in dict.fromkeys(true_isoforms) if c not in set(seqs)]
     merged = sorted([(s, 0) for s in seqs] + [(c, 1) for c in cands], key=lambda x: len(x[0]))
@@ -641,6 +652,9 @@ def other_kernels(store, seqs, lens, last, true_isoforms, ctr):
                           **_fracs(ctr, "sg_banded", swb_ms, own_time=True)),
         "hw_k25": dict(kernel="infix kernel, 4096 pairs, k = 25", kernel_ms=hw25_ms, **_fracs(ctr, "hw_k25", hw25_ms)),
         "hw_k63": dict(kernel="infix kernel, 4096 pairs, k = 63", kernel_ms=hw63_ms, **_fracs(ctr, "hw_k63", hw63_ms)),
+        "ed_bytes": dict(kernel="k_ed_bytes (one wavefront per pair on the sequences' bytes; 4096 pairs with an 'N' in one sequence, k = 63; VALU-bound)", kernel_ms=edb_ms,
+                         pairs_per_s_kernel=len(q) / (edb_ms / 1e3) if edb_ms > 0 else None, hits=int((edb >= 0).sum()),
+                         within_two_of_the_acgt_distance=bool((np.abs(edb - ed)[(edb >= 0) & (ed <= 61)] <= 2).all())),          # (one 'N' per sequence, both sequences of a pair may carry one)
         "hw_graph": dict(kernel="k_hw_locate + k_hw_finish, candidate-vs-candidate graph (%d candidates, k = 25)" % len(cseqs), pairs=int(len(gq)),
                          hits=int((gres[:, 0] >= 0).sum()), wall_ms=g_wall * 1e3, kernel_ms=g_ms, pairs_per_s_kernel=len(gq) / (g_ms / 1e3) if g_ms > 0 else None,
                          pairs_per_s_wall=len(gq) / g_wall, **_fracs(ctr, "hw_graph", g_ms))}
