@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void k_byte_histogram(const uint8_t *__restric
 }
 
 __global__ __launch_bounds__(256) void k_pack_planes(const uint8_t *__restrict__ ascii, const uint64_t *__restrict__ offsets, uint64_t base, uint32_t n,
-                                                      uint32_t nchunks, uint64_t *__restrict__ planes, unsigned long long *__restrict__ first_bad, PackMap map)
+                                                      uint32_t nchunks, uint64_t *__restrict__ planes, unsigned long long *__restrict__ first_bad, PackMap map,
+                                                      uint32_t fold = 0)
 {
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (uint64_t)nchunks * n) return;
@@ -315,9 +316,10 @@ __global__ __launch_bounds__(256) void k_pack_planes(const uint8_t *__restrict__
     int cd = 0;
     bool bad = false;
     if (pos < len) {
-        const uint8_t ch = ascii[off + pos];
+        uint8_t ch = ascii[off + pos];
+        if (fold && ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);          // fold: lower case takes its upper-case letter's code, any other byte code 0, nothing is reported
         cd = ch == map.sym[0] ? 0 : ch == map.sym[1] ? 1 : ch == map.sym[2] ? 2 : ch == map.sym[3] ? 3 : -1;
-        bad = cd < 0;
+        bad = cd < 0 && !fold;
     }
     const unsigned long long lo = __ballot(!bad && (cd & 1)), hi = __ballot(!bad && (cd & 2)), bm = __ballot(bad);
     if (lane == 0) {
@@ -486,8 +488,11 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
                 return ISOCON_E_HIP;
             }
             if (distinct > 4) {
-                // The first packing pass left code 0 at every byte outside "ACGT": those planes serve the pairs of ordinary sequences.
-                // The bytes and their offsets move from the scratch pool into the store, with one flag per sequence.
+                // Planes: the "ACGT" map with lower case folded onto upper case and code 0 at every other byte.  For the pairs of ordinary
+                // sequences they are what they always are; for a sequence with other bytes they hold its image under a map that MERGES symbol
+                // classes, and merging classes can only turn mismatches into matches: d(image x, image y) <= d(x, y), so every lower bound
+                // computed on the planes (q-gram bounds) holds for the sequences themselves.
+                // The bytes and their offsets move from the scratch pool into the store, with one count per sequence.
                 DevBuf d_flags(&g_scratch, SLOT_PACK_FLAGS);
                 st->exc.assign(nn, 0);
                 st->exc_count.assign(nn, 0);
@@ -495,6 +500,8 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
                            hipMalloc((void **)&st->d_bytes, total ? total : 16) == hipSuccess && hipMalloc((void **)&st->d_boff, (size_t)(nn + 1) * 8) == hipSuccess;
                 if (eok) {
                     const uint64_t waves = (uint64_t)nchunks * n;
+                    hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
+                                       st->d_planes, d_bad.as<unsigned long long>(), PackMap{{'A', 'C', 'G', 'T'}}, 1u);
                     hipLaunchKernelGGL(k_exception_flags, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
                                        d_flags.as<uint32_t>(), (uint32_t)'A' | ((uint32_t)'C' << 8) | ((uint32_t)'G' << 16) | ((uint32_t)'T' << 24));
                     eok = hipGetLastError() == hipSuccess && hipMemcpy(st->exc_count.data(), d_flags.p, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
