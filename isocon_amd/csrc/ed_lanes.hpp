@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void k_ed_lanes(DevStore S, NNParams P, const 
     }
     bool hit_x = false, hit_y = false;
     if (r >= P.min_d) {
-        if (upd_x && r <= m) { const int32_t old = atomicMin(P.best + x, r); hit_x = r <= old; }
-        if (upd_y && r <= n) { const int32_t old = atomicMin(P.best + y, r); hit_y = r <= old; }
+        if (upd_x && r <= m) hit_x = nn_take(P, x, r);
+        if (upd_y && r <= n) hit_y = nn_take(P, y, r);
     }
     nn_append(P, hit_x, (int32_t)x, (int32_t)y, r);
     nn_append(P, hit_y, (int32_t)y, (int32_t)x, r);

@@ -43,9 +43,19 @@ struct NNParams {
     // LDS) with the partners list[chunks[i].begin .. + count) -- survivors of the q-gram bound, collected before the launch
     const struct NNChunk *chunks;
     const uint32_t *list;          // partner | 0x40000000 (the chunk's entry queries it) | 0x80000000 (it queries the chunk's entry)
+    // 1: best[] holds FIXED thresholds -- every pair within its query's threshold is a hit and nothing is tightened (the collecting pass
+    // over a set whose planes are class-merged images of the sequences, nn_host.inc: nn_phase_a_images)
+    int32_t fixed;
 };
 
 struct NNChunk { uint32_t slot, count; unsigned long long begin; };
+
+// The update rule for one end of a pair: distance r against the end's bound; true = the pair is a hit of that end.
+__device__ __forceinline__ bool nn_take(const NNParams &P, uint32_t e, int32_t r)
+{
+    const int32_t old = P.fixed ? load_relaxed_agent(P.best + e) : atomicMin(P.best + e, r);
+    return r <= old;
+}
 
 __device__ __forceinline__ void nn_append(const NNParams &P, bool want, int32_t e, int32_t o, int32_t d)
 {
@@ -102,8 +112,8 @@ __device__ __forceinline__ void nn_process_tile(const DevStore &S, const NNParam
     acc.tiles += 1;
     bool hit_s = false, hit_l = false;
     if (r >= P.min_d) {
-        if (upd_s && r <= m) { const int32_t old = atomicMin(P.best + s, r); hit_s = r <= old; }
-        if (upd_l && r <= n_t) { const int32_t old = atomicMin(P.best + tid, r); hit_l = r <= old; }
+        if (upd_s && r <= m) hit_s = nn_take(P, s, r);
+        if (upd_l && r <= n_t) hit_l = nn_take(P, tid, r);
     }
     nn_append(P, hit_s, (int32_t)s, (int32_t)tid, r);
     nn_append(P, hit_l, (int32_t)tid, (int32_t)s, r);
@@ -201,8 +211,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_lds(DevStore S, NNParam
     nn_flush_acc(P, acc);
 }
 
-// Keeps the hits that can still matter: distance == best[endpoint] at the end of the launch (best only decreases), and
-// the -2 markers.  In place is not possible (unordered appends), so the survivors go to a second list.
+// Keeps the hits that can still matter: distance <= best[endpoint] at the end of the launch -- with bounds that only decrease that is
+// distance == best[endpoint]; with fixed thresholds (NNParams::fixed) every recorded hit -- and the -2 markers.  In place is not possible (unordered appends), so the survivors go to a second list.
 __global__ __launch_bounds__(256) void k_filter_hits(const int32_t *__restrict__ hits, unsigned long long n_hits, const int32_t *__restrict__ best,
                                                       int32_t *__restrict__ out, unsigned long long *out_count)
 {
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void k_filter_hits(const int32_t *__restrict__
         bool keep = false;
         if (i < n_hits) {
             e = hits[i * 3]; o = hits[i * 3 + 1]; d = hits[i * 3 + 2];
-            keep = d == -2 || d == best[e];
+            keep = d == -2 || (d >= 0 && d <= best[e]);
         }
         const unsigned long long mask = __ballot(keep);
         if (!mask) continue;
@@ -434,8 +444,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
             if (__ballot(triv) != 0) {
                 bool hs = false, hl = false;
                 if (triv && ad >= P.min_d) {
-                    if (us && ad <= m) { const int32_t old = atomicMin(P.best + q, ad); hs = ad <= old; }
-                    if (ul && ad <= np) { const int32_t old = atomicMin(P.best + pid, ad); hl = ad <= old; }
+                    if (us && ad <= m) hs = nn_take(P, q, ad);
+                    if (ul && ad <= np) hl = nn_take(P, pid, ad);
                 }
                 nn_append(P, hs, (int32_t)q, (int32_t)pid, ad);
                 nn_append(P, hl, (int32_t)pid, (int32_t)q, ad);
@@ -593,8 +603,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
         if (__ballot(fin && r >= P.min_d) != 0) {
             bool hs = false, hl = false;
             if (fin && r >= P.min_d) {
-                if (upd_s && r <= m) { const int32_t old = atomicMin(P.best + q, r); hs = r <= old; }
-                if (upd_l && r <= n_t) { const int32_t old = atomicMin(P.best + tid, r); hl = r <= old; }
+                if (upd_s && r <= m) hs = nn_take(P, q, r);
+                if (upd_l && r <= n_t) hl = nn_take(P, tid, r);
             }
             nn_append(P, hs, (int32_t)q, (int32_t)tid, r);
             nn_append(P, hl, (int32_t)tid, (int32_t)q, r);

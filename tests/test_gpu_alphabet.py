@@ -213,3 +213,32 @@ def test_device_resident_phases_with_other_symbols():
         assert ordered(NNG.compute_nearest_neighbor_graph(S, set(), Params(1))[0]) == ordered(O.compute_nearest_neighbor_graph(S, set(), Params(1))[0])
     finally:
         st.close()
+
+
+@pytest.mark.parametrize("seed,frac,mode", [(1, 0.1, "N"), (2, 0.02, "N"), (3, 1.0, "mask"), (4, 0.3, "lower")])
+def test_thousands_of_reads_with_other_symbols(seed, frac, mode):
+    """3 000 reads: the survivor lists, both table kernels and the device-side hit filter take part (small sets never reach them).  Reads with
+    a few 'N', a soft-masked copy of the whole set (one motif in lower case wherever it occurs: every read exceptional, image distances mostly
+    equal to the true ones) and random lower-case patches (image distances far below the true ones: most queries need the collecting pass)."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    accs, seqs, _ = synth.make_reads(3000, 700, 4, 1000 + seed)
+    rng = random.Random(seed)
+    seqs = list(dict.fromkeys(seqs))
+    if mode == "N":
+        for i in rng.sample(range(len(seqs)), int(frac * len(seqs))):
+            for _ in range(rng.randrange(1, 4)):
+                p = rng.randrange(len(seqs[i]))
+                seqs[i] = seqs[i][:p] + "N" + seqs[i][p + 1:]
+    elif mode == "mask":
+        seqs = [s.replace("AACA", "aaca") for s in seqs]
+    else:
+        for i in rng.sample(range(len(seqs)), int(frac * len(seqs))):
+            a = rng.randrange(len(seqs[i]) - 30)
+            seqs[i] = seqs[i][:a] + seqs[i][a:a + 12].lower() + seqs[i][a + 12:]
+    S = {"r%d" % i: s for i, s in enumerate(dict.fromkeys(seqs))}
+    g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+    assert NNG.LAST_STATS["pairs_bytes"] > 0
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(8))
+    assert ordered(g_gpu) == ordered(g_cpu)
