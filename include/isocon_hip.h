@@ -15,11 +15,12 @@
  * take ANY bytes, with the same results as a textbook edit distance over those bytes ('N' equals 'N', 'a' differs from 'A'):
  *   - a set over at most four distinct symbols (lower case, RNA ...) is packed in two bits per base under its own symbol map and runs
  *     through the same kernels as ACGT (distances, nearest neighbours, infix alignments);
- *   - a set with MORE than four distinct symbols (ACGT + N, mixed case) keeps its bytes on the device beside the 2-bit planes; a pair
- *     in which a sequence holds a symbol outside ACGT is aligned on the bytes by a separate kernel (one wavefront per pair, exact, much
- *     slower per pair than the bit-vector kernels -- isocon_nn_stats.pairs_bytes counts them), all other pairs are not affected.
- *     isocon_ed_pairs and the nearest-neighbour entry points serve such a set; isocon_hw_pairs and the q-gram bound test entry points
- *     return ISOCON_E_ALPHABET.
+ *   - a set with MORE than four distinct symbols (ACGT + N, mixed case) keeps its bytes on the device beside the 2-bit planes, which then
+ *     hold class-merged IMAGES of the sequences (lower case folded onto upper case, other bytes onto one code: d(images) <= d).  The
+ *     nearest-neighbour search finds its candidates on the images with the ordinary kernels; a candidate pair in which a sequence holds a
+ *     symbol outside ACGT gets its exact distance from a byte-wise kernel (one wavefront per pair, much slower per pair than the bit-vector
+ *     kernels -- isocon_nn_stats.pairs_bytes counts them); pairs of two ACGT sequences are not affected.  isocon_ed_pairs and the
+ *     nearest-neighbour entry points serve such a set; isocon_hw_pairs and the q-gram bound test entry points return ISOCON_E_ALPHABET.
  * The alignment and consensus entry points need ACGT (the reference builds its parasail matrix on "ACGT",
  * modules/SW_alignment_module.py:65; what parasail does off that alphabet is not pinned): ISOCON_E_ALPHABET on any other set.
  */

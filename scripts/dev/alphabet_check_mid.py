@@ -8,7 +8,11 @@ from oracle import oracle as O
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 700
 bad = 0
-for seed, frac, mode in [(1, 0.1, "N"), (2, 0.02, "N"), (3, 1.0, "mask"), (4, 0.3, "lower")]:
+cases = [(1, 0.1, "N"), (2, 0.02, "N"), (3, 1.0, "mask"), (4, 0.3, "lower")]
+if len(sys.argv) > 3:
+    r0 = random.Random(int(sys.argv[3]))
+    cases = [(100 + i, r0.choice([0.01, 0.05, 0.3, 1.0]), r0.choice(["N", "mask", "lower"])) for i in range(int(sys.argv[4]) if len(sys.argv) > 4 else 8)]
+for seed, frac, mode in cases:
     accs, seqs, _ = synth.make_reads(n, L, 4, 1000 + seed)
     rng = random.Random(seed)
     seqs = list(dict.fromkeys(seqs))
