@@ -242,3 +242,25 @@ def test_thousands_of_reads_with_other_symbols(seed, frac, mode):
     assert NNG.LAST_STATS["pairs_bytes"] > 0
     g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(8))
     assert ordered(g_gpu) == ordered(g_cpu)
+
+
+@pytest.mark.parametrize("variant", ["", "nn_tiles=1"])
+def test_other_symbols_through_the_fallback_main_pass_kernels(variant, monkeypatch):
+    """Reads too long for the lane-refill kernel's LDS layout (16-wave tables, scalar-window scan) and the tile-synchronous kernel
+    (ISOCON_DEBUG_VARIANT=nn_tiles: re-run markers resolved on the host): the image passes run through them too."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    if variant:
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", variant)
+    rng = random.Random(3)
+    for (n, L, seed) in ((200, 4600, 11), (30, 11000, 12), (500, 900, 21)):
+        accs, seqs, _ = synth.make_reads(n, L, 3, seed=seed)
+        seqs = list(dict.fromkeys(seqs))
+        for i in rng.sample(range(len(seqs)), len(seqs) // 5):
+            p = rng.randrange(len(seqs[i]))
+            seqs[i] = seqs[i][:p] + rng.choice(["N", "n", seqs[i][p].lower()]) + seqs[i][p + 1:]
+        S = {"r%d" % i: s for i, s in enumerate(dict.fromkeys(seqs))}
+        g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
+        g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
+        assert ordered(g_gpu) == ordered(g_cpu), (variant, n, L)
