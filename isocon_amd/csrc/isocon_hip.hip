@@ -709,8 +709,10 @@ namespace isocon {
 
 // Shared by isocon_ed_pairs and the NN fallback: exact bounded/unbounded distances for an explicit pair list.
 // Stages: 64-row band (k <= 63), 128, 256, 512 rows, then the un-banded kernel.
+// images: distances of the sequences' IMAGES in the planes (a set with more than four symbols: lower bounds of the true distances, see
+// isocon_store) -- the pairs of exceptional sequences are not split off to the byte-wise kernel.
 int ed_pairs_impl(isocon_store *st, const uint32_t *a, const uint32_t *b, const int32_t *k, uint64_t n_pairs,
-                  int32_t *out_ed, float *kernel_ms, uint64_t *full_pairs)
+                  int32_t *out_ed, float *kernel_ms, uint64_t *full_pairs, bool images)
 {
     EventTimer tm;
     const uint32_t n = st->dev.n;
@@ -729,7 +731,7 @@ int ed_pairs_impl(isocon_store *st, const uint32_t *a, const uint32_t *b, const 
     }
     std::vector<uint64_t> pending;
     pending.reserve(n_pairs);
-    if (st->n_exc) {
+    if (st->n_exc && !images) {
         // pairs with a sequence that holds symbols outside the planes' map: on the bytes (ed_bytes.hpp), whatever their threshold
         std::vector<uint64_t> xp;
         for (uint64_t p = 0; p < n_pairs; ++p) (st->exc[a[p]] || st->exc[b[p]] ? xp : pending).push_back(p);
@@ -904,7 +906,7 @@ extern "C" int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_
     if (!s || (n_pairs && (!a || !b || !out_ed))) return ISOCON_E_ARG;
     if (kernel_ms) *kernel_ms = 0.f;
     if (!n_pairs) return ISOCON_OK;
-    return ed_pairs_impl(s, a, b, k, n_pairs, out_ed, kernel_ms, nullptr);
+    return ed_pairs_impl(s, a, b, k, n_pairs, out_ed, kernel_ms, nullptr, false);
 }
 
 extern "C" int isocon_qgram_params(int32_t *out)

@@ -264,3 +264,33 @@ def test_other_symbols_through_the_fallback_main_pass_kernels(variant, monkeypat
         g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
         g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
         assert ordered(g_gpu) == ordered(g_cpu), (variant, n, L)
+
+
+@pytest.mark.parametrize("seed,frac,mode,lr,n", [(1, 0.05, "N", (500, 900), 1500), (2, 0.3, "lower", (500, 900), 1500), (3, 1.0, "mask", (500, 900), 1500),
+                                                 (4, 0.1, "N", (2500, 4500), 500), (5, 0.5, "lower", (5000, 9000), 150)])
+def test_wide_phase_with_other_symbols(seed, frac, mode, lr, n):
+    """ONT-profile reads (nearest neighbours 60 .. 640 edits away: the 128- to 512-row bands and the un-banded stage) with 'N's, random
+    lower-case patches or a soft-masked motif, some entries converged: the image passes of the wide phase against the oracle loop."""
+    from isocon_amd import nearest_neighbor_graph as NNG
+    from isocon_amd import synth
+    from oracle import oracle as O
+    accs, seqs, _ = synth.make_reads(n, 0, 12, 7000 + seed, profile=synth.ONT_PROFILE, families=3, length_range=lr)
+    rng = random.Random(seed)
+    seqs = list(dict.fromkeys(seqs))
+    if mode == "N":
+        for i in rng.sample(range(len(seqs)), int(frac * len(seqs))):
+            for _ in range(rng.randrange(1, 4)):
+                p = rng.randrange(len(seqs[i]))
+                seqs[i] = seqs[i][:p] + "N" + seqs[i][p + 1:]
+    elif mode == "mask":
+        seqs = [s.replace("AACA", "aaca") for s in seqs]
+    else:
+        for i in rng.sample(range(len(seqs)), int(frac * len(seqs))):
+            a = rng.randrange(len(seqs[i]) - 30)
+            seqs[i] = seqs[i][:a] + seqs[i][a:a + 12].lower() + seqs[i][a + 12:]
+    S = {"r%d" % i: s for i, s in enumerate(dict.fromkeys(seqs))}
+    conv = set(rng.sample(sorted(S), 5))
+    g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, conv, Params(1))
+    assert NNG.LAST_STATS["pairs_bytes"] > 0 and NNG.LAST_STATS["fallback_queries"] > 0
+    g_cpu, _ = O.compute_nearest_neighbor_graph(S, conv, Params(8))
+    assert ordered(g_gpu) == ordered(g_cpu)
