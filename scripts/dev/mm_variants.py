@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from isocon_amd import synth
 from isocon_amd.store import SeqStore
 accs, seqs, _ = synth.make_reads(50000, 2500, 10, 30001)
