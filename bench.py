@@ -315,6 +315,7 @@ def load_counters():
 
 
 def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the pool's driver supports dmabuf IPC only (RCCL reads it at init)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
