@@ -3,8 +3,10 @@ profiles/<TAG>_kernel_stats.csv, profiles/<TAG>_pmc_summary.txt, profiles/<TAG>_
 profiles/counters.json (read by bench.py: per-dispatch SQ_INSTS_VALU and HBM bytes of the kernels its line reports)."""
 import csv, glob, json, os, shutil, sys
 
+if __name__ != "__main__" or len(sys.argv) < 2:          # a script that rewrites profiles/counters.json: never by import, never without its tag
+    raise SystemExit("usage: python scripts/summarize_profile.py <TAG>")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1]
 out = os.path.join(ROOT, "gpurun_out")
 prof = os.path.join(ROOT, "profiles")
 
