@@ -113,9 +113,9 @@ __global__ __launch_bounds__(64) void k_ed_bytes(ByteStore B, const uint32_t *__
 
 // per sequence: how many bytes outside the map?  (one wavefront per 64 bases, as k_pack_planes)
 __global__ __launch_bounds__(256) void k_exception_flags(const uint8_t *__restrict__ ascii, const uint64_t *__restrict__ offsets, uint64_t base, uint32_t n,
-                                                        uint32_t nchunks, uint32_t *__restrict__ counts, uint32_t sym4)
+                                                        uint32_t nchunks, uint32_t *__restrict__ counts, uint32_t sym4, uint64_t w0)
 {
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t w = w0 + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (uint64_t)nchunks * n) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t chunk = (uint32_t)(w / n), seq = (uint32_t)(w % n);

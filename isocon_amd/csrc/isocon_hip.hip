@@ -189,6 +189,7 @@ struct PinnedStage {
 };
 static PinnedStage g_stage;
 static constexpr size_t kStageBytes = (size_t)32 << 20;
+static constexpr uint64_t kPackWaves = (uint64_t)1 << 25;          // wavefronts per packing launch (one per 64 bases of a sequence): below 2^32 threads
 static constexpr size_t kStageMin = (size_t)32 << 10;      // smaller copies: the runtime's own staging path is fine
 
 // Host buffers handed out by isocon_host_alloc are pinned: copies to / from them need no staging.
@@ -305,9 +306,9 @@ __global__ __launch_bounds__(256) void k_byte_histogram(const uint8_t *__restric
 
 __global__ __launch_bounds__(256) void k_pack_planes(const uint8_t *__restrict__ ascii, const uint64_t *__restrict__ offsets, uint64_t base, uint32_t n,
                                                       uint32_t nchunks, uint64_t *__restrict__ planes, unsigned long long *__restrict__ first_bad, PackMap map,
-                                                      uint32_t fold = 0)
+                                                      uint32_t fold, uint64_t w0)
 {
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t w = w0 + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);          // (a launch holds fewer than 2^32 threads: w0 = first wavefront of this one)
     if (w >= (uint64_t)nchunks * n) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t chunk = (uint32_t)(w / n), seq = (uint32_t)(w % n);           // consecutive waves: consecutive sequences
@@ -380,10 +381,6 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
     }
     const uint32_t nchunks = (uint32_t)((maxlen + 63) / 64 + 1);
     const uint32_t nn = std::max<uint32_t>(n, 1);
-    if ((uint64_t)nchunks * nn >= ((uint64_t)1 << 26)) {          // k_pack_planes: one wavefront per (chunk, sequence), fewer than 2^32 threads per launch
-        g_last_error = "set too large for one store: (longest sequence / 64 + 1) x sequences must stay below 2^26";
-        return ISOCON_E_UNSUPPORTED;
-    }
     std::vector<int32_t> lens(nn, 0);
     for (uint32_t i = 0; i < n; ++i) lens[i] = (int32_t)(offsets[i + 1] - offsets[i]);
     const uint64_t base = n ? offsets[0] : 0, total = n ? offsets[n] - offsets[0] : 0;
@@ -400,6 +397,8 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
     // the host only checked the offsets.  Scratch (ASCII, offsets, first bad position) comes from the process-wide pool.
     {
         DevBuf d_ascii(&g_scratch, SLOT_PACK_ASCII), d_off(&g_scratch, SLOT_PACK_OFF), d_bad(&g_scratch, SLOT_PACK_BAD);
+        uint64_t pack_waves = kPackWaves;
+        if (const char *e = variant_value("pack_waves")) pack_waves = std::max<uint64_t>(4, strtoull(e, nullptr, 10)) & ~(uint64_t)3;      // tests: many launches on a small set
         const unsigned long long none = ~0ull;
         int rc = ISOCON_OK;
         if ((rc = d_ascii.alloc(total ? total : 16)) || (rc = d_off.alloc((size_t)(nn + 1) * 8)) || (rc = d_bad.alloc(8))) { isocon_store_destroy(st); return rc; }
@@ -455,8 +454,9 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
         if (ok) {
             if (n) {
                 const uint64_t waves = (uint64_t)nchunks * n;
-                hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
-                                   st->d_planes, d_bad.as<unsigned long long>(), PackMap{{'A', 'C', 'G', 'T'}});
+                for (uint64_t w0 = 0; w0 < waves; w0 += pack_waves)
+                    hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((std::min<uint64_t>(pack_waves, waves - w0) + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
+                                       st->d_planes, d_bad.as<unsigned long long>(), PackMap{{'A', 'C', 'G', 'T'}}, 0u, w0);
             } else {
                 ok = hipMemset(st->d_planes, 0, pbytes) == hipSuccess;
             }
@@ -500,10 +500,12 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
                            hipMalloc((void **)&st->d_bytes, total ? total : 16) == hipSuccess && hipMalloc((void **)&st->d_boff, (size_t)(nn + 1) * 8) == hipSuccess;
                 if (eok) {
                     const uint64_t waves = (uint64_t)nchunks * n;
-                    hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
-                                       st->d_planes, d_bad.as<unsigned long long>(), PackMap{{'A', 'C', 'G', 'T'}}, 1u);
-                    hipLaunchKernelGGL(k_exception_flags, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
-                                       d_flags.as<uint32_t>(), (uint32_t)'A' | ((uint32_t)'C' << 8) | ((uint32_t)'G' << 16) | ((uint32_t)'T' << 24));
+                    for (uint64_t w0 = 0; w0 < waves; w0 += pack_waves)
+                    hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((std::min<uint64_t>(pack_waves, waves - w0) + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
+                                       st->d_planes, d_bad.as<unsigned long long>(), PackMap{{'A', 'C', 'G', 'T'}}, 1u, w0);
+                    for (uint64_t w0 = 0; w0 < waves; w0 += pack_waves)
+                        hipLaunchKernelGGL(k_exception_flags, dim3((unsigned)((std::min<uint64_t>(pack_waves, waves - w0) + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n,
+                                           nchunks, d_flags.as<uint32_t>(), (uint32_t)'A' | ((uint32_t)'C' << 8) | ((uint32_t)'G' << 16) | ((uint32_t)'T' << 24), w0);
                     eok = hipGetLastError() == hipSuccess && hipMemcpy(st->exc_count.data(), d_flags.p, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
                           hipMemcpy(st->d_bytes, d_ascii.p, total, hipMemcpyDeviceToDevice) == hipSuccess &&
                           hipMemcpy(st->d_boff, d_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice) == hipSuccess;
@@ -532,8 +534,9 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
             bool rok = hipMemcpy(d_bad.p, &none, 8, hipMemcpyHostToDevice) == hipSuccess;
             if (rok) {
                 const uint64_t waves = (uint64_t)nchunks * n;
-                hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
-                                   st->d_planes, d_bad.as<unsigned long long>(), map);
+                for (uint64_t w0 = 0; w0 < waves; w0 += pack_waves)
+                    hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)((std::min<uint64_t>(pack_waves, waves - w0) + 3) / 4)), dim3(256), 0, 0, d_ascii.as<uint8_t>(), d_off.as<uint64_t>(), base, n, nchunks,
+                                       st->d_planes, d_bad.as<unsigned long long>(), map, 0u, w0);
                 rok = hipGetLastError() == hipSuccess && hipMemcpy(&bad, d_bad.p, 8, hipMemcpyDeviceToHost) == hipSuccess && bad == none;
             }
             if (!rok) {

@@ -177,3 +177,29 @@ def test_sets_over_another_alphabet_of_at_most_four_symbols():
         g_gpu, _ = NNG.compute_nearest_neighbor_graph(S, set(), Params(1))
         g_cpu, _ = O.compute_nearest_neighbor_graph(S, set(), Params(1))
         assert ordered(g_gpu) == ordered(g_cpu), alphabet
+
+
+@pytest.mark.gpu
+def test_packing_in_several_launches(monkeypatch):
+    """A launch holds fewer than 2^32 threads: k_pack_planes (one wavefront per 64 bases of a sequence) covers a large set in several launches.
+    Forced here on a small set (ISOCON_DEBUG_VARIANT=pack_waves): same planes (fingerprint), same distances, also for a set with other symbols."""
+    import random
+    from isocon_amd.store import SeqStore
+    from oracle import oracle as O
+    rng = random.Random(2)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 700))) for _ in range(300)]
+    mixed = [s if i % 7 else s[:len(s) // 2] + "Nn" + s[len(s) // 2:] for i, s in enumerate(seqs)]
+    want = {}
+    for name, ss in (("acgt", seqs), ("mixed", mixed)):
+        st = SeqStore(ss)
+        a = [rng.randrange(len(ss)) for _ in range(100)]
+        b = [rng.randrange(len(ss)) for _ in range(100)]
+        want[name] = (st.fingerprint, a, b, st.ed_pairs(a, b, None).tolist())
+        assert want[name][3] == [O.ed_dp(ss[x], ss[y]) for x, y in zip(a, b)]
+        st.close()
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "pack_waves=1000")
+    for name, ss in (("acgt", seqs), ("mixed", mixed)):
+        st = SeqStore(ss)
+        fp, a, b, d = want[name]
+        assert st.fingerprint == fp and st.ed_pairs(a, b, None).tolist() == d
+        st.close()
