@@ -58,6 +58,9 @@ MFMA_FP4_PEAK_MACS = 5.0e15                 # ~10 PFLOP/s dense FP4 (same guide,
 # tests/golden/make_golden_g17.py; tests/test_oracle_golden.py checks that this constant is that fixture's digest): a step that
 # produces another graph is not a measurement
 EXPECTED_GRAPH_DIGEST_C3 = "65944c838d76a6c9"
+# digest of the alignments of the C3 partition pair list (49 990 pairs) as the oracle computes them on the CPU (tests/golden/g18_c3_sw.npz, written by
+# tests/golden/make_golden_g18.py: orc_sg_trace = SWM:64-86, tie policy 0; tests/test_oracle_golden.py checks that this constant is that fixture's)
+EXPECTED_SW_DIGEST_C3 = "79dafdad72773d7f"
 COUNTERS = os.path.join(ROOT, "profiles", "counters.json")   # written by scripts/summarize_profile.py from rocprofv3 --pmc passes
 
 
@@ -76,6 +79,36 @@ def graph_digest(best, row_ptr, cols):
     import hashlib
     h = hashlib.blake2b(digest_size=8)
     for x, t in ((best, np.int32), (row_ptr, np.int64), (cols, np.uint32)):
+        h.update(np.ascontiguousarray(x, dtype=t).tobytes())
+    return h.hexdigest()
+
+
+_H1, _H2, _H3 = np.uint64(0xD6E8FEB86659FD93), np.uint64(0x9E3779B97F4A7C15), np.uint64(0xC2B2AE3D27D4EB4F)
+
+
+def sw_pair_hashes(ops, ops_ptr):
+    """uint64 per pair: position-dependent hash of the pair's run-length CIGAR ops (len << 4 | code), vectorised so that 50 000 pairs cost
+    milliseconds (what tests/golden/g18_*_sw.npz stores instead of ~15 MB of ops)"""
+    ptr = np.asarray(ops_ptr, dtype=np.int64)
+    x = np.asarray(ops, dtype=np.uint64)[:int(ptr[-1])]
+    pos = (np.arange(len(x), dtype=np.int64) - np.repeat(ptr[:-1], np.diff(ptr))).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(1) + pos * _H1) * _H2
+        x ^= x >> np.uint64(29)
+        x *= _H3
+        x ^= x >> np.uint64(32)
+        cs = np.concatenate([np.zeros(1, np.uint64), np.cumsum(x, dtype=np.uint64)])
+        return cs[ptr[1:]] - cs[ptr[:-1]]
+
+
+def sw_digest(a, b, res, hashes):
+    """identity of a batch of alignments: the pairs in (a, b) order with their result rows (score, end cell, matches, mismatches, indels)
+    and op hashes"""
+    import hashlib
+    a, b = np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)
+    o = np.lexsort((b, a))
+    h = hashlib.blake2b(digest_size=8)
+    for x, t in ((a[o], np.uint32), (b[o], np.uint32), (np.asarray(res)[o], np.int32), (np.asarray(hashes)[o], np.uint64)):
         h.update(np.ascontiguousarray(x, dtype=t).tobytes())
     return h.hexdigest()
 
@@ -521,10 +554,17 @@ def main():
         except Exception as e:  # the headline line must still be printed
             result["other_kernels"] = {"error": repr(e)}
         pair_ed = []
+        sw_leg = {}
         try:
-            result["wrappers"] = wrappers(accs, seqs_all, pair_ed)
+            result["wrappers"] = wrappers(accs, seqs_all, pair_ed, sw_leg)
         except Exception as e:
             result["wrappers"] = {"error": repr(e)}
+        if sw_leg:
+            result["roofline_sw"] = roofline_sw(sw_leg, ctr if is_default else {})
+            if is_default:
+                result["config"]["sw_digest"] = sw_leg["digest"]
+                result["config"]["sw_digest_expected"] = EXPECTED_SW_DIGEST_C3
+                result["config"]["alignments_equal_oracle_fixture"] = sw_leg["digest"] == EXPECTED_SW_DIGEST_C3
         if cpu_pool is not None and pair_ed:
             try:
                 cpu.update(cpu_pair_legs(cpu_pool, cpu["cores"], pair_ed))
@@ -549,6 +589,9 @@ def main():
     if is_default and result["config"]["graph_digest"] != EXPECTED_GRAPH_DIGEST_C3:
         raise SystemExit("bench.py: the graph of the default workload has digest %s, the reference-loop fixture %s: the result is WRONG, the line above is not a measurement"
                          % (result["config"]["graph_digest"], EXPECTED_GRAPH_DIGEST_C3))
+    if is_default and result["config"].get("alignments_equal_oracle_fixture") is False:
+        raise SystemExit("bench.py: the alignments of the default workload's partition pairs have digest %s, the oracle fixture %s: the wrappers leg is WRONG"
+                         % (result["config"]["sw_digest"], EXPECTED_SW_DIGEST_C3))
 
 
 def _fracs(ctr, key, ms, own_time=False):
@@ -662,7 +705,38 @@ def other_kernels(store, seqs, lens, last, true_isoforms, ctr):
     return out
 
 
-def wrappers(accs, seqs_all, pair_ed_out=None):
+def roofline_sw(leg, ctr):
+    """The alignment dispatch of the wrappers leg -- isocon_sg_trace_batch on ALL partition pairs of the workload (C3: 49 990), with the pairs'
+    distances as band hints, as get_partition_alignments / sw_align_sequences call it.  SURVEY 8(d): the trace kernel is the one kernel of the path
+    whose stated bound is HBM (4 bit / cell trace stream); reported: the HBM fraction from the PMC bytes of THAT dispatch of k_sg_band
+    (profiles/counters.json `sg_partition`) over its live event time, its VALU fraction, bytes per pair against the 10.2 kB of the byte model,
+    cell updates / s (full-matrix equivalent, what parasail would compute) and band cells / s (what the kernel computes)."""
+    c = ctr.get("sg_partition", {})
+    fwd_ms, n = leg["stats"]["forward_ms"], leg["pairs"]
+    own_ms = c["dur_ns_sq_pass"] / 1e6 if c.get("dur_ns_sq_pass") else None
+    hbm = float(c["hbm_bytes"]) if c.get("hbm_bytes") else None
+    insts = float(c["SQ_INSTS_VALU"]) if c.get("SQ_INSTS_VALU") else None
+    alg = leg["algorithmic_bytes"]
+    return {"bound": "hbm", "kernel": "isocon::k_sg_band<true, true> (%d partition pairs of the workload in one launch: the certified band's diagonals on the lanes, 4-bit trace per cell)" % n,
+            "pairs": n, "kernel_ms": fwd_ms, "call_kernel_ms": leg["kernel_ms"], "call_wall_ms": leg["wall_ms"],
+            "kernels_ms": {k: leg["stats"][k] for k in ("forward_ms", "walk_ms", "compact_ms", "expand_ms")},
+            "pairs_band": int(leg["stats"]["pairs_band"]), "pairs_strips": int(leg["stats"]["pairs_strips"]), "pairs_redone_in_full": int(leg["stats"]["pairs_redone"]),
+            "achieved": hbm / (fwd_ms / 1e3) / 1e9 if hbm and fwd_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": hbm / (fwd_ms / 1e3) / 1e9 / HBM_PEAK_GBS if hbm and fwd_ms > 0 else None, "traffic": hbm,
+            "traffic_per_pair": hbm / n if hbm else None, "trace_scratch_bytes_per_pair": leg["stats"]["trace_bytes"] / n,
+            "algorithmic_bytes_per_pair": alg / n, "traffic_vs_algorithmic": hbm / alg if hbm else None,
+            "algorithmic_frac": alg / (fwd_ms / 1e3) / 1e9 / HBM_PEAK_GBS if fwd_ms > 0 else None,
+            "valu_frac": insts / (fwd_ms / 1e3) / VALU_PEAK_WAVE_INSTR if insts and fwd_ms > 0 else None,
+            "valu_frac_profiled_pass": insts / (own_ms / 1e3) / VALU_PEAK_WAVE_INSTR if insts and own_ms else None,
+            "cell_updates_per_s": leg["cells_full"] / (leg["kernel_ms"] / 1e3) if leg["kernel_ms"] > 0 else None,
+            "band_cells_per_s": leg["cells_band"] / (fwd_ms / 1e3) if fwd_ms > 0 else None,
+            "pairs_per_s_kernel": n / (leg["kernel_ms"] / 1e3) if leg["kernel_ms"] > 0 else None,
+            "digest": leg["digest"],
+            "note": "algorithmic bytes = SURVEY 8(d): len(q) + len(t) + 2 len(alignment) + 12 per pair; traffic = PMC 2 x FETCH_SIZE + WRITE_SIZE of the dispatch; "
+                    "cell_updates_per_s counts len(q) x len(t) per pair over ALL kernels of the call, band_cells_per_s the 128 cells per anti-diagonal the band kernel computes"}
+
+
+def wrappers(accs, seqs_all, pair_ed_out=None, sw_leg=None):
     """SURVEY 8(d) "Timers": perf_counter() around the PUBLIC functions (string handling, packing, H2D, kernels, D2H and the
     dict rebuild included) -- NNG:237-296, EAM:10-49, SWM:89-164 -- on the workload and on its partition pair list."""
     from isocon_amd import SW_alignment_module as SWM
@@ -705,6 +779,27 @@ def wrappers(accs, seqs_all, pair_ed_out=None):
     t0 = time.perf_counter(); pa = IGC.get_partition_alignments(partition, M, G_star, set(), Q()); t_pa = time.perf_counter() - t0
     seq_to_acc = IGC.get_unique_seq_accessions(S)
     t0 = time.perf_counter(); S_prime, _ = COR.correct_strings(pa, seq_to_acc, {}, 1); t_cor = time.perf_counter() - t0
+    batch = getattr(pa, "batch", None)
+    if sw_leg is not None and batch is not None and batch.alive():
+        # the alignment half of the metric, pinned: digest of (pair, score, end cell, counts, ops) over the whole partition pair list (ids = positions
+        # in the length-sorted unique entries), and the dispatch `roofline_sw` reports: the same pairs through the C ABI once more, alone
+        entries = sorted(dict.fromkeys(seqs_all), key=len)
+        idx = {x: i for i, x in enumerate(entries)}
+        ia = np.fromiter((idx[m] for m, _ in batch.pairs), dtype=np.int64, count=len(batch.pairs))
+        ib = np.fromiter((idx[x] for _, x in batch.pairs), dtype=np.int64, count=len(batch.pairs))
+        sw_leg["digest"] = sw_digest(ia, ib, batch.res, sw_pair_hashes(batch.ops, batch.ops_ptr))
+        from isocon_amd.store import sg_last_stats
+        st, a, b = batch.store, batch.a, batch.b
+        ed = st.ed_pairs(a, b, None)
+        la, lb = st.lens[a].astype(np.int64), st.lens[b].astype(np.int64)
+        rate = ed.astype(np.float64) / np.minimum(la, lb).astype(np.float64)
+        mm = np.where(rate <= 0.01, -1, np.where(rate <= 0.09, -2, -4)).astype(np.int8)
+        st.sg_trace(a, b, mm, ed_upper=ed)
+        t0 = time.perf_counter(); ops, ptr, res, ms = st.sg_trace(a, b, mm, ed_upper=ed, return_ms=True); wall = time.perf_counter() - t0
+        aln_len = res[:, 3].astype(np.int64) + res[:, 4] + res[:, 5]
+        sw_leg.update(pairs=len(a), kernel_ms=float(ms), wall_ms=wall * 1e3, stats=sg_last_stats(), cells_full=float((la * lb).sum()),
+                      cells_band=float(((la + lb) * 128).sum()), algorithmic_bytes=float((la + lb + 2 * aln_len + 12).sum()),
+                      same_as_wrappers=bool((res == batch.res).all() and len(ops) == len(batch.ops) and (ops == batch.ops).all()))
     return {"compute_nearest_neighbor_graph_wall_ms": t_nn * 1e3, "compute_nearest_neighbor_graph_kernel_ms": kern, "nn_edges": n_edges,
             "partition_centres": len(partition), "partition_pairs": n_pairs,
             "edlib_align_sequences_wall_ms": t_ed * 1e3, "edlib_align_sequences_pairs_per_s": n_pairs / t_ed if t_ed > 0 else None,

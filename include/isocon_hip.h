@@ -233,6 +233,16 @@ int isocon_sg_strings_batch(isocon_store *s, const uint32_t *a, const uint32_t *
                             uint64_t aln_cap, uint64_t *n_aln_needed, float *kernel_ms, const int32_t *ed_upper);
 
 /*
+ * Where the kernel time of this thread's most recent isocon_sg_trace_batch / isocon_sg_strings_batch call went (HIP events on the
+ * kernels' stream; a measurement aid for bench.py's `roofline_sw`, the reference has no counterpart: parasail's time is one number per
+ * call, modules/SW_alignment_module.py:66-69).  out[0 .. min(cap, 8)): forward kernels (k_sg_band + k_sg_forward) ms, walk kernels ms,
+ * compaction ms, string expansion ms, pairs aligned with the band's diagonals on the lanes, pairs aligned in strips, pairs whose
+ * banded result could not be certified and was redone in full, bytes of trace scratch the forward kernels wrote.  Returns the number of
+ * values written.
+ */
+int isocon_sg_last_stats(double *out, int32_t cap);
+
+/*
  * Exon-difference filter on CIGAR ops (host-only helper, no GPU): out_flag[p] = 1 iff filter_exon_differences
  * (modules/functions.py:23-50, mask rule :218-236) would drop the pair, i.e. one of the gapped strings has a run of
  * >= min_exon_diff gaps inside the window that excludes min(ignore_ends_len, end-gap) columns at either end.

@@ -88,6 +88,7 @@ SYMBOLS = {
     "isocon_sg_strings_batch": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, ctypes.c_int32, i8p,
                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, u32p, u64p, ctypes.c_uint64,
                                                u64p, i32p, u8p, u8p, u64p, ctypes.c_uint64, u64p, f32p, i32p]),
+    "isocon_sg_last_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.c_int32]),
     "isocon_exon_filter_from_ops": (ctypes.c_int, [u32p, u64p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, u8p]),
     "isocon_msa_correct": (ctypes.c_int, [u8p, ctypes.c_uint32, ctypes.c_uint32, i32p, u8p, ctypes.c_uint64, u64p, i32p,
                                           ctypes.POINTER(ctypes.c_int64), f32p]),

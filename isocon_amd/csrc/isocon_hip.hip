@@ -142,7 +142,11 @@ static uint64_t g_store_serial = 0;
 struct isocon_store {
     uint64_t serial = ++g_store_serial;
     DevStore dev;
-    ScratchPool &pool = g_scratch;
+    // ISOCON_DEBUG_VARIANT=store_private_pool (read when the store is created): the store gets a scratch pool of its own, released with it --
+    // for runs that emulate SEVERAL ranks inside one process (tests/baton_dist.py): a rank's bound matrix, held candidate edges and
+    // counters must not be another rank's.  A real rank is a process, and its stores share the process' pool.
+    std::unique_ptr<ScratchPool> own_pool{variant("store_private_pool") ? new ScratchPool() : nullptr};
+    ScratchPool &pool = own_pool ? *own_pool : g_scratch;
     std::vector<int32_t> lens;   // host copy
     uint64_t device_bytes = 0;
     uint64_t *d_planes = nullptr;
@@ -601,6 +605,7 @@ void isocon_store_destroy(isocon_store *s)
     if (s->d_lens) (void)hipFree(s->d_lens);
     if (s->d_bytes) (void)hipFree(s->d_bytes);
     if (s->d_boff) (void)hipFree(s->d_boff);
+    if (s->own_pool) s->own_pool->release();
     delete s;
 }
 

@@ -360,6 +360,14 @@ class SeqStore(object):
             return out + (ms.value,) if return_ms else out
 
 
+def sg_last_stats():
+    """where the kernel time of this thread's most recent alignment batch went (isocon_sg_last_stats, include/isocon_hip.h)"""
+    out = (ctypes.c_double * 8)()
+    _lib.load().isocon_sg_last_stats(out, 8)
+    keys = ("forward_ms", "walk_ms", "compact_ms", "expand_ms", "pairs_band", "pairs_strips", "pairs_redone", "trace_bytes")
+    return dict(zip(keys, list(out)))
+
+
 def shard_entries(q_begin, q_end, q_stride=1, q_block=1):
     """The entries a shard owns, in slot order (include/isocon_hip.h, isocon_nn_partial): q_begin <= x < q_end with
     (x - q_begin) mod q_stride < q_block."""

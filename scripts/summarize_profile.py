@@ -86,6 +86,11 @@ def classify(rows):
         cls["sg_full"] = sg_full
     if sg_banded:
         cls["sg_banded"] = sg_banded
+    # the alignment dispatch of the wrappers leg: k_sg_band over ALL partition pairs of the workload (the widest k_sg_band launch of the run;
+    # bench.py's own isolated call of it is the last one)
+    bands = [r for r in rows if "k_sg_band" in r[1]]
+    if bands and max(r[2] for r in bands) > 4096 * 64:
+        cls["sg_partition"] = [r for r in bands if r[2] == max(x[2] for x in bands)][-1:]
     if len(calls) >= 3:
         cls["hw_k25"], cls["hw_k63"] = calls[1], calls[2]
     if len(calls) >= 5:

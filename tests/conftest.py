@@ -60,3 +60,26 @@ def g17(which):
         h.update(b"\n")
     assert h.hexdigest() == str(z["inputs_sha1"]), "the synthetic generator no longer produces the set the fixture was made from"
     return seqs, z["best"], z["row_ptr"], z["cols"]
+
+
+def g18(which):
+    """The alignment fixture of a BASELINE configuration (tests/golden/make_golden_g18.py: every pair aligned on the CPU by the oracle's
+    statement of SWM:64-86, tie policy 0): the npz as a dict of arrays.  Ids index the configuration's entries (g17's order)."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g18_%s_sw.npz" % which))
+    return {k: z[k] for k in z.files}
+
+
+def ops_of_alignment(a1, a2):
+    """two gapped strings -> run-length ops (len << 4 | code; 0 '=', 1 'X', 2 'I' = gap in the second, 3 'D' = gap in the first),
+    maximal runs, as include/isocon_hip.h defines them"""
+    import numpy as np
+    x = np.frombuffer(a1.encode("ascii"), dtype=np.uint8)
+    y = np.frombuffer(a2.encode("ascii"), dtype=np.uint8)
+    code = np.where(y == 45, 2, np.where(x == 45, 3, np.where(x == y, 0, 1))).astype(np.uint32)
+    if len(code) == 0:
+        return np.zeros(0, np.uint32)
+    cut = np.flatnonzero(np.diff(code) != 0) + 1
+    starts = np.concatenate([[0], cut])
+    lens = np.diff(np.concatenate([starts, [len(code)]])).astype(np.uint32)
+    return (lens << 4) | code[starts]

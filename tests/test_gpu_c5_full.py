@@ -86,3 +86,57 @@ def test_c5_candidates_at_full_size_keep_their_invariants(c5_reads, tmp_path):
     from isocon_amd.input_output import fasta_parser
     cands = set(s for _, s in fasta_parser.read_fasta(open(cand_file)))
     assert sum(1 for t in set(iso) if t in cands) >= 25                         # of the 50 true isoforms (34 in profiles/r04k_c5_200k_get_candidates.log)
+
+
+def test_c5_sampled_alignments_equal_the_oracle_fixture(c5_reads):
+    """2 000 sampled (read, read of the same isoform) pairs of the 200 000-read set, the 5 kb end included (tests/golden/g18_c5_sw.npz: aligned
+    on the CPU by the oracle, SWM:64-86 tie policy 0): distances, SWM:102-109's buckets (mostly -4 at 6 % errors), score, end cell, counts and
+    ops of every pair -- banded with hints (bands beyond 256 diagonals: the strip kernel), the full-matrix kernel on a sample, and the public
+    sw_align_sequences."""
+    import hashlib
+    import bench
+    from conftest import g18, ops_of_alignment
+    from isocon_amd import SW_alignment_module as SWM
+    from isocon_amd.store import SeqStore
+    fx = g18("c5")
+    accs, seqs_all, iso = c5_reads
+    entries = sorted(dict.fromkeys(seqs_all), key=len)
+    fa, fb = fx["part_a"].astype(np.int64), fx["part_b"].astype(np.int64)
+    sub = sorted(set(fa.tolist()) | set(fb.tolist()))
+    pos = {v: k for k, v in enumerate(sub)}
+    sseqs = [entries[v] for v in sub]
+    h = hashlib.sha1()
+    for s in sseqs:
+        h.update(s.encode()); h.update(b"\n")
+    assert h.hexdigest() == str(fx["inputs_sha1"])
+    assert max(len(s) for s in sseqs) > 4000
+    a = np.array([pos[v] for v in fa.tolist()], dtype=np.uint32)
+    b = np.array([pos[v] for v in fb.tolist()], dtype=np.uint32)
+    st = SeqStore(sseqs)
+    try:
+        ed = st.ed_pairs(a, b, None)
+        assert (ed == fx["part_ed"]).all()
+        rate = ed.astype(np.float64) / np.minimum(st.lens[a], st.lens[b]).astype(np.float64)
+        mm = np.where(rate <= 0.01, -1, np.where(rate <= 0.09, -2, -4)).astype(np.int8)
+        assert (mm == fx["part_mismatch"]).all() and (mm == -4).any()
+        ops, ptr, res = st.sg_trace(a, b, mm, ed_upper=ed)
+        assert (res == fx["part_res"]).all()
+        assert (bench.sw_pair_hashes(ops, ptr) == fx["part_ops_hash"]).all()
+        pick = np.concatenate([np.arange(0, len(a), 8), np.arange(len(a) - 10, len(a))])
+        ops, ptr, res = st.sg_trace(a[pick], b[pick], mm[pick])
+        assert (res == fx["part_res"][pick]).all()
+        assert (bench.sw_pair_hashes(ops, ptr) == fx["part_ops_hash"][pick]).all()
+    finally:
+        st.close()
+    matches = {}
+    for p in range(0, len(a), 4):
+        matches.setdefault(sseqs[int(a[p])], {})[sseqs[int(b[p])]] = int(fx["part_ed"][p])
+    sw = SWM.sw_align_sequences(matches)
+    where = {(int(a[p]), int(b[p])): p for p in range(len(a))}
+    index = {s: i for i, s in enumerate(sseqs)}
+    for s1, inner in sw.items():
+        for s2, (a1, a2, cnt) in inner.items():
+            p = where[(index[s1], index[s2])]
+            o = ops_of_alignment(a1, a2)
+            assert tuple(cnt) == tuple(fx["part_res"][p, 3:6]) and bench.sw_pair_hashes(o, [0, len(o)])[0] == fx["part_ops_hash"][p]
+

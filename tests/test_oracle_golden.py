@@ -118,3 +118,54 @@ def test_g17_whole_graph_fixtures():
             assert cols[row_ptr[i]:row_ptr[i + 1]].tolist() == c.tolist() and (e == best[i]).all()
         if which == "c3":
             assert bench.graph_digest(best, row_ptr, cols) == bench.EXPECTED_GRAPH_DIGEST_C3
+
+
+def test_g18_alignment_fixtures():
+    """tests/golden/g18_*_sw.npz (make_golden_g18.py): the pair lists are the partition of the g17 graph (partition_ids_py, the statement g7 pins
+    to the reference), sampled pairs give the same distance / bucket / result row / ops hash / exon flag when the oracle aligns them again, the
+    native partition routine (host code of the C ABI) cuts the same partition, and the C3 digest is the constant bench.py asserts."""
+    import ctypes
+    import os
+    import sys
+    import numpy as np
+    import bench
+    from conftest import g17, g18
+    from isocon_amd import partitions
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_g18 as MG
+    for which in ("c2", "c3"):
+        fx = g18(which)
+        seqs, best, row_ptr, cols = g17(which)
+        assert MG.sha1_of(seqs) == str(fx["inputs_sha1"])
+        n = len(seqs)
+        a, b = fx["part_a"].astype(np.int64), fx["part_b"].astype(np.int64)
+        assert len(a) + len(fx["centres"]) == n and len(set(b.tolist()) | set(fx["centres"].tolist())) == n
+        assert set(a.tolist()) <= set(fx["centres"].tolist()) and int(fx["weights"].sum()) == n
+        assert bench.sw_digest(a, b, fx["part_res"], fx["part_ops_hash"]) == str(fx["digest"])
+        # the native partition routine on the fixture graph
+        rows = np.repeat(np.arange(n), np.diff(row_ptr))
+        parts = partitions.partition_ids(n, np.ones(n, np.int32), (rows.astype(np.uint32), cols.astype(np.uint32)), seqs)
+        na = np.array([c for c, w, mem in parts for _ in mem.tolist()], dtype=np.int64)
+        nb = np.array([m for c, w, mem in parts for m in mem.tolist()], dtype=np.int64)
+        o = np.lexsort((nb, na))
+        assert (na[o] == a).all() and (nb[o] == b).all()
+        for prefix in ("part_", "edge_") if which == "c2" else ("part_",):
+            pa, pb = fx[prefix + "a"], fx[prefix + "b"]
+            pick = np.random.default_rng(18).choice(len(pa), 24 if which == "c3" else 60, replace=False)
+            ed = O.ed_pairs(seqs, pa[pick], pb[pick], None)
+            assert (ed == fx[prefix + "ed"][pick]).all()
+            for p, d in zip(pick.tolist(), ed.tolist()):
+                s1, s2 = seqs[int(pa[p])], seqs[int(pb[p])]
+                mm = O.mismatch_penalty_for(d, len(s1), len(s2))
+                assert mm == fx[prefix + "mismatch"][p]
+                r = O.sg_trace(s1, s2, 2, mm, 2, 0, 0)
+                assert [r["score"], r["end_query"], r["end_ref"], r["matches"], r["mismatches"], r["indels"]] == fx[prefix + "res"][p].tolist()
+                a1, a2 = O.cigar_to_seq(r["cigar"], s1, s2)
+                from conftest import ops_of_alignment
+                ops = ops_of_alignment(a1, a2)
+                assert len(ops) == fx[prefix + "n_ops"][p]
+                assert bench.sw_pair_hashes(ops, [0, len(ops)])[0] == fx[prefix + "ops_hash"][p]
+                assert MG.exon_flag(a1, a2) == fx[prefix + "exon"][p]
+        if which == "c3":
+            assert str(fx["digest"]) == bench.EXPECTED_SW_DIGEST_C3
