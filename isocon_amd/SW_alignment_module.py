@@ -93,19 +93,20 @@ def ops_to_cigar(ops):
     return "".join("%d%s" % (op >> 4, _OPS[op & 15]) for op in ops)
 
 
-def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0, ed_upper=None):
+def _align_pairs(pairs, mismatch, match_score=2, opening_penalty=2, gap_ext=0, ed_upper=None, want_dict=False):
     """[(s1, s2)], per-pair mismatch penalties -> [(s1_aln, s2_aln, (matches, mismatches, indels))].
     mismatch None: the penalty of every pair from the error-rate bucket of its ed_upper (SWM:102-109).
     ed_upper: the pairs' edit distances where the caller has them (they only narrow the computed part of the matrix;
     the device re-aligns in full whatever it cannot certify, see include/isocon_hip.h)."""
     if not pairs:
-        return []
+        return ([], {}) if want_dict else []
     from . import perf_log
     with perf_log.call("SW_alignment_module.alignments", pairs=len(pairs), open=opening_penalty, ext=gap_ext, hints=ed_upper is not None):
-        return _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed_upper)
+        return _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed_upper, want_dict)
 
 
-def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed_upper):
+def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed_upper, want_dict=False):
+    """want_dict: returns (alignments, {pairs[p][0]: {pairs[p][1]: alignments[p]}} or None when the helper module is missing)"""
     st, a, b, owned = store_for_pairs(pairs)
     try:
         la, lb = st.lens[a], st.lens[b]
@@ -127,7 +128,6 @@ def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed
     finally:
         if owned:
             st.close()
-    counts = list(zip(res[:, 3].tolist(), res[:, 4].tolist(), res[:, 5].tolist()))          # (matches, mismatches, indels) tuples
     from . import _lib
     H = _lib.pyhelp()
     if H is not None:
@@ -136,14 +136,22 @@ def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed
         ba, bb = np.frombuffer(aln_a, dtype=np.uint8), np.frombuffer(aln_b, dtype=np.uint8)
         sa = H.split_ascii(ba.ctypes.data if len(ba) else 0, ptr64.ctypes.data, len(pairs))
         sb = H.split_ascii(bb.ctypes.data if len(bb) else 0, ptr64.ctypes.data, len(pairs))
+        if want_dict and hasattr(H, "alignment_dict") and isinstance(pairs, list):
+            # the result tuples and the dict of dicts that files them under their pairs, in one pass (SWM:146-164)
+            res_c = np.ascontiguousarray(res, dtype=np.int32)
+            out, filed = H.alignment_dict(pairs, sa, sb, res_c.ctypes.data)
+            _OPS_CACHE.set(out, ops, ops_ptr)
+            return out, filed
+        counts = list(zip(res[:, 3].tolist(), res[:, 4].tolist(), res[:, 5].tolist()))          # (matches, mismatches, indels) tuples
         out = list(zip(sa, sb, counts))
     else:
+        counts = list(zip(res[:, 3].tolist(), res[:, 4].tolist(), res[:, 5].tolist()))
         aln_a = str(aln_a, "ascii")
         aln_b = str(aln_b, "ascii")
         ptr = ptr.tolist()
         out = [(aln_a[ptr[p]:ptr[p + 1]], aln_b[ptr[p]:ptr[p + 1]], counts[p]) for p in range(len(pairs))]
     _OPS_CACHE.set(out, ops, ops_ptr)          # (indexed and sliced by whoever asks: ops_of)
-    return out
+    return (out, None) if want_dict else out
 
 
 def ops_of(result_tuple):
@@ -210,6 +218,20 @@ def _batch(keys_pairs_eds):
 
 def sw_align_sequences(matches, nr_cores=1, mismatch_penalty=-1):
     """SWM:89-164.  {s1: {s2: ed}} -> {s1: {s2: (s1_aln, s2_aln, (matches, mismatches, indels))}}."""
+    from . import _lib
+    H = _lib.pyhelp()
+    if H is not None and hasattr(H, "flatten_pairs") and type(matches) is dict and all(type(v) is dict for v in matches.values()):
+        # the pair list and the distances in one pass in C; the result dict is filed in C as well (every alignment tuple is truthy: SWM:158)
+        pairs, eds = H.flatten_pairs(matches)
+        eds = _int_distances(eds) if eds else None
+        if eds is not None:
+            out, filed = _align_pairs(pairs, None, ed_upper=eds, want_dict=True)
+            if filed is not None:
+                return filed
+            exact_matches = {}
+            for (s1, s2), stats in zip(pairs, out):
+                exact_matches.setdefault(s1, {})[s2] = stats
+            return exact_matches
     items = [((s1, s2), (s1, s2), ed) for s1, inner in matches.items() for s2, ed in inner.items()]
     exact_matches = {}
     for (key, _, _), stats in zip(items, _batch(items)):

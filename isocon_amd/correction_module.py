@@ -200,6 +200,20 @@ def _correct_partition_from_ops(batch, m, partition, seq_to_acc):
     return out
 
 
+def _rows_intact(partition, m, batch):
+    from .isocon_get_candidates import LazyAlignment
+    H = _lib.pyhelp()
+    if H is not None and hasattr(H, "lazy_rows_intact"):
+        return H.lazy_rows_intact(partition, m, LazyAlignment, batch, batch.pairs)
+    pairs = batch.pairs
+    for s, v in partition.items():
+        if s is m:
+            continue
+        if type(v) is not LazyAlignment or v._batch is not batch or not (0 <= v._p < len(pairs)) or pairs[v._p][0] is not m or pairs[v._p][1] is not s:
+            return False
+    return True
+
+
 def _correct_all_from_ops(batch, partition_alignments, centres, seq_to_acc):
     """correct_to_consensus for ALL the given partitions (centres: sorted list) in one batched build + correct on the device
     (isocon_msa_build_ops_batch / isocon_msa_correct_built_batch).  Returns ({accession: corrected sequence}, centres whose partition has a
@@ -295,7 +309,9 @@ def correct_strings(partition_alignments, seq_to_acc, ccs_dict, step, nr_cores=1
     batched = []
     for m, partition in sorted(partition_alignments.items()):
         n_members = len(batch.rows_of.get(m, [])) if from_ops else 0
-        if from_ops and len(partition) == 1 + n_members:          # (unchanged since it was built)
+        # unchanged since it was built: as many entries as the batch filed there, and every one of them the batch's own value under its
+        # own key (a caller that replaced or re-keyed an entry gets the string path, which reads the dict)
+        if from_ops and len(partition) == 1 + n_members and _rows_intact(partition, m, batch):
             if n_members >= 1 and partition[m][3] + n_members > 2:          # correction_module.py:263: len(partition) > 1 and N_t > 2
                 batched.append(m)
         else:

@@ -224,6 +224,17 @@ static PyObject *rank_strings(PyObject *self, PyObject *args)
         items[i].idx = (uint32_t)i;
         items[i].key = NULL;
     }
+    /* The sort runs without the GIL on the strings' own buffers: a snapshot of the list with a strong reference to every element keeps
+     * them alive whatever another thread does to the caller's list meanwhile. */
+    PyObject *hold = PyList_GetSlice(seqs, 0, n);
+    if (!hold) { free(items); return NULL; }
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        if (PyList_GET_ITEM(hold, i) != PyList_GET_ITEM(seqs, i) || (const char *)PyUnicode_1BYTE_DATA(PyList_GET_ITEM(hold, i)) != items[i].p) {
+            Py_DECREF(hold); free(items);
+            PyErr_SetString(PyExc_RuntimeError, "rank_strings: the list changed during the call");
+            return NULL;
+        }
+    }
     rank_item *tmp = NULL;
     char *keys = NULL;
     Py_BEGIN_ALLOW_THREADS
@@ -257,6 +268,7 @@ static PyObject *rank_strings(PyObject *self, PyObject *args)
     free(tmp);
     free(keys);
     free(items);
+    Py_DECREF(hold);
     Py_RETURN_NONE;
 }
 
@@ -273,6 +285,11 @@ static PyObject *group_keys_by_value(PyObject *self, PyObject *args)
     Py_ssize_t pos = 0;
     PyObject *key, *value;
     while (PyDict_Next(d, &pos, &key, &value)) {
+        if (!PyUnicode_CheckExact(value)) {          /* (a __hash__ / __eq__ written in Python could change d under PyDict_Next) */
+            Py_DECREF(out);
+            PyErr_SetString(PyExc_TypeError, "group_keys_by_value: every value must be a str");
+            return NULL;
+        }
         PyObject *lst = PyDict_GetItemWithError(out, value);          /* borrowed */
         if (!lst) {
             if (PyErr_Occurred()) { Py_DECREF(out); return NULL; }
@@ -288,7 +305,233 @@ static PyObject *group_keys_by_value(PyObject *self, PyObject *args)
     return out;
 }
 
+/* unique_values_by_length(S: dict[acc, str]) -> (seqs: list[str], accs: list): the unique VALUES of S -- a value keeps the position of its
+ * first appearance and the key of its LAST (what {seq: acc for acc, seq in S.items()} gives, nearest_neighbor_graph.py:243) -- stably sorted
+ * by length (:246), and the keys that go with them.  One pass and a counting sort instead of a dict comprehension, a list of items, a
+ * key-function sort and two list comprehensions over 50 000 entries. */
+static PyObject *unique_values_by_length(PyObject *self, PyObject *args)
+{
+    PyObject *S;
+    if (!PyArg_ParseTuple(args, "O", &S)) return NULL;
+    if (!PyDict_CheckExact(S)) { PyErr_SetString(PyExc_TypeError, "unique_values_by_length: a dict is required"); return NULL; }
+    PyObject *inv = PyDict_New();
+    if (!inv) return NULL;
+    Py_ssize_t pos = 0, maxlen = 0;
+    PyObject *key, *value;
+    while (PyDict_Next(S, &pos, &key, &value)) {
+        if (!PyUnicode_CheckExact(value) || PyUnicode_READY(value) < 0) {
+            Py_DECREF(inv);
+            if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "unique_values_by_length: every value must be a str");
+            return NULL;
+        }
+        if (PyDict_SetItem(inv, value, key) < 0) { Py_DECREF(inv); return NULL; }
+        if (PyUnicode_GET_LENGTH(value) > maxlen) maxlen = PyUnicode_GET_LENGTH(value);
+    }
+    const Py_ssize_t n = PyDict_GET_SIZE(inv);
+    Py_ssize_t *start = (Py_ssize_t *)calloc((size_t)maxlen + 2, sizeof(Py_ssize_t));
+    PyObject *seqs = PyList_New(n), *accs = PyList_New(n);
+    if (!start || !seqs || !accs) { free(start); Py_XDECREF(seqs); Py_XDECREF(accs); Py_DECREF(inv); return PyErr_NoMemory(); }
+    pos = 0;
+    while (PyDict_Next(inv, &pos, &key, &value)) start[PyUnicode_GET_LENGTH(key) + 1] += 1;
+    for (Py_ssize_t l = 0; l <= maxlen; ++l) start[l + 1] += start[l];
+    pos = 0;
+    while (PyDict_Next(inv, &pos, &key, &value)) {          /* insertion order inside a length: stable */
+        const Py_ssize_t at = start[PyUnicode_GET_LENGTH(key)]++;
+        Py_INCREF(key); Py_INCREF(value);
+        PyList_SET_ITEM(seqs, at, key);
+        PyList_SET_ITEM(accs, at, value);
+    }
+    free(start);
+    Py_DECREF(inv);
+    PyObject *out = PyTuple_Pack(2, seqs, accs);
+    Py_DECREF(seqs); Py_DECREF(accs);
+    return out;
+}
+
+/* flatten_pairs(matches: dict) -> (pairs: list[(k1, k2)], values: list): the (outer key, inner key) pairs of a dict of dicts -- or of a dict
+ * of sets / lists / tuples (then values = None) -- in iteration order: the task lists of edlib_align_sequences / sw_align_sequences
+ * (edlib_alignment_module.py:17-24, SW_alignment_module.py:96-118) without 50 000 rounds of the interpreter loop. */
+static PyObject *flatten_pairs(PyObject *self, PyObject *args)
+{
+    PyObject *matches;
+    if (!PyArg_ParseTuple(args, "O", &matches)) return NULL;
+    if (!PyDict_CheckExact(matches)) { PyErr_SetString(PyExc_TypeError, "flatten_pairs: a dict is required"); return NULL; }
+    PyObject *pairs = PyList_New(0), *values = PyList_New(0);
+    if (!pairs || !values) { Py_XDECREF(pairs); Py_XDECREF(values); return NULL; }
+    int have_values = -1;          /* -1 unknown, 1 inner dicts, 0 other iterables */
+    Py_ssize_t pos = 0;
+    PyObject *k1, *inner;
+    while (PyDict_Next(matches, &pos, &k1, &inner)) {
+        if (PyDict_CheckExact(inner)) {
+            if (have_values == 0) goto mixed;
+            have_values = 1;
+            Py_ssize_t p2 = 0;
+            PyObject *k2, *v;
+            while (PyDict_Next(inner, &p2, &k2, &v)) {
+                PyObject *t = PyTuple_Pack(2, k1, k2);
+                if (!t || PyList_Append(pairs, t) < 0 || PyList_Append(values, v) < 0) { Py_XDECREF(t); goto fail; }
+                Py_DECREF(t);
+            }
+        } else {
+            if (have_values == 1) goto mixed;
+            have_values = 0;
+            PyObject *it = PyObject_GetIter(inner);
+            if (!it) goto fail;
+            PyObject *k2;
+            while ((k2 = PyIter_Next(it)) != NULL) {
+                PyObject *t = PyTuple_Pack(2, k1, k2);
+                Py_DECREF(k2);
+                if (!t || PyList_Append(pairs, t) < 0) { Py_XDECREF(t); Py_DECREF(it); goto fail; }
+                Py_DECREF(t);
+            }
+            Py_DECREF(it);
+            if (PyErr_Occurred()) goto fail;
+        }
+    }
+    {
+        PyObject *out = PyTuple_Pack(2, pairs, have_values == 1 ? values : Py_None);
+        Py_DECREF(pairs); Py_DECREF(values);
+        return out;
+    }
+mixed:
+    PyErr_SetString(PyExc_TypeError, "flatten_pairs: inner values are dicts for some keys and not for others");
+fail:
+    Py_DECREF(pairs); Py_DECREF(values);
+    return NULL;
+}
+
+/* alignment_dict(pairs: list[(k1, k2)], aln_a: list[str], aln_b: list[str], res_addr: int (int32[n][6]: .., matches, mismatches, indels)) ->
+ * (out: list of (aln_a[p], aln_b[p], (matches, mismatches, indels)), d: {k1: {k2: out[p]}}): the return value of sw_align_sequences
+ * (SW_alignment_module.py:146-164: every pair's stats filed under its two keys) and the flat list of the same tuple objects. */
+static PyObject *alignment_dict(PyObject *self, PyObject *args)
+{
+    PyObject *pairs, *la, *lb;
+    unsigned long long ra;
+    if (!PyArg_ParseTuple(args, "OOOK", &pairs, &la, &lb, &ra)) return NULL;
+    if (!PyList_Check(pairs) || !PyList_Check(la) || !PyList_Check(lb) || PyList_GET_SIZE(la) != PyList_GET_SIZE(pairs) ||
+        PyList_GET_SIZE(lb) != PyList_GET_SIZE(pairs)) {
+        PyErr_SetString(PyExc_TypeError, "alignment_dict: three lists of one length are required");
+        return NULL;
+    }
+    const int32_t *res = (const int32_t *)(uintptr_t)ra;
+    const Py_ssize_t n = PyList_GET_SIZE(pairs);
+    PyObject *out = PyList_New(n), *d = PyDict_New();
+    if (!out || !d) { Py_XDECREF(out); Py_XDECREF(d); return NULL; }
+    for (Py_ssize_t p = 0; p < n; ++p) {
+        PyObject *pr = PyList_GET_ITEM(pairs, p);
+        if (!PyTuple_Check(pr) || PyTuple_GET_SIZE(pr) < 2) { PyErr_Format(PyExc_TypeError, "pair %zd is not a 2-tuple", p); goto fail; }
+        PyObject *cnt = Py_BuildValue("(iii)", (int)res[p * 6 + 3], (int)res[p * 6 + 4], (int)res[p * 6 + 5]);
+        if (!cnt) goto fail;
+        PyObject *t = PyTuple_Pack(3, PyList_GET_ITEM(la, p), PyList_GET_ITEM(lb, p), cnt);
+        Py_DECREF(cnt);
+        if (!t) goto fail;
+        PyList_SET_ITEM(out, p, t);          /* (steals t; the dict below takes its own reference) */
+        PyObject *k1 = PyTuple_GET_ITEM(pr, 0), *k2 = PyTuple_GET_ITEM(pr, 1);
+        PyObject *row = PyDict_GetItemWithError(d, k1);          /* borrowed */
+        if (!row) {
+            if (PyErr_Occurred()) goto fail;
+            row = PyDict_New();
+            if (!row) goto fail;
+            const int rc = PyDict_SetItem(d, k1, row);
+            Py_DECREF(row);
+            if (rc < 0) goto fail;
+        }
+        if (PyDict_SetItem(row, k2, t) < 0) goto fail;
+    }
+    {
+        PyObject *r = PyTuple_Pack(2, out, d);
+        Py_DECREF(out); Py_DECREF(d);
+        return r;
+    }
+fail:
+    Py_DECREF(out); Py_DECREF(d);
+    return NULL;
+}
+
+/* lazy_rows(cls, batch, pairs: list[(m, s)], keep_addr: int (uint8[n]: 1 = the pair stays), edit_addr: int (int32[n]), out: dict[m, dict],
+ *           rows_of: dict) -> number of values made: out[m][s] = cls(batch, p, edit[p]) and rows_of[m].append(p) for every kept pair p, in
+ * pair order -- the loop that files 50 000 alignments under their centres in get_partition_alignments (isocon_get_candidates.py:66-76). */
+static PyObject *lazy_rows(PyObject *self, PyObject *args)
+{
+    PyObject *cls, *batch, *pairs, *out, *rows_of;
+    unsigned long long ka, ea;
+    if (!PyArg_ParseTuple(args, "OOOKKOO", &cls, &batch, &pairs, &ka, &ea, &out, &rows_of)) return NULL;
+    if (!PyList_Check(pairs) || !PyDict_Check(out) || !PyDict_Check(rows_of)) { PyErr_SetString(PyExc_TypeError, "lazy_rows: list, dict, dict"); return NULL; }
+    const uint8_t *keep = (const uint8_t *)(uintptr_t)ka;
+    const int32_t *edit = (const int32_t *)(uintptr_t)ea;
+    const Py_ssize_t n = PyList_GET_SIZE(pairs);
+    Py_ssize_t made = 0;
+    for (Py_ssize_t p = 0; p < n; ++p) {
+        if (!keep[p]) continue;
+        PyObject *pr = PyList_GET_ITEM(pairs, p);
+        if (!PyTuple_Check(pr) || PyTuple_GET_SIZE(pr) < 2) { PyErr_Format(PyExc_TypeError, "pair %zd is not a 2-tuple", p); return NULL; }
+        PyObject *m = PyTuple_GET_ITEM(pr, 0), *s = PyTuple_GET_ITEM(pr, 1);
+        PyObject *row = PyDict_GetItemWithError(out, m);          /* borrowed */
+        if (!row) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_KeyError, "lazy_rows: a centre without a row"); return NULL; }
+        PyObject *pi = PyLong_FromSsize_t(p), *ei = PyLong_FromLong((long)edit[p]);
+        PyObject *v = (pi && ei) ? PyObject_CallFunctionObjArgs(cls, batch, pi, ei, NULL) : NULL;
+        Py_XDECREF(ei);
+        if (!v) { Py_XDECREF(pi); return NULL; }
+        int rc = PyDict_SetItem(row, s, v);
+        Py_DECREF(v);
+        if (rc < 0) { Py_DECREF(pi); return NULL; }
+        PyObject *lst = PyDict_GetItemWithError(rows_of, m);          /* borrowed */
+        if (!lst) {
+            if (PyErr_Occurred()) { Py_DECREF(pi); return NULL; }
+            lst = PyList_New(0);
+            if (!lst) { Py_DECREF(pi); return NULL; }
+            rc = PyDict_SetItem(rows_of, m, lst);
+            Py_DECREF(lst);
+            if (rc < 0) { Py_DECREF(pi); return NULL; }
+        }
+        rc = PyList_Append(lst, pi);
+        Py_DECREF(pi);
+        if (rc < 0) return NULL;
+        ++made;
+    }
+    return PyLong_FromSsize_t(made);
+}
+
+/* lazy_rows_intact(partition: dict, centre, cls, batch, pairs: list) -> bool: every value of `partition` except the centre's own is an
+ * instance of exactly `cls` whose `_batch` is `batch` and whose `_p` names the pair (centre, that key) of `pairs` -- i.e. the dict still
+ * holds what lazy_rows filed there and nothing else, so the correction may read members and alignments from the batch's arrays instead
+ * of from the dict (correction_module.correct_strings). */
+static PyObject *lazy_rows_intact(PyObject *self, PyObject *args)
+{
+    PyObject *partition, *centre, *cls, *batch, *pairs;
+    if (!PyArg_ParseTuple(args, "OOOOO", &partition, &centre, &cls, &batch, &pairs)) return NULL;
+    if (!PyDict_Check(partition) || !PyList_Check(pairs)) { PyErr_SetString(PyExc_TypeError, "lazy_rows_intact: a dict and a list are required"); return NULL; }
+    static PyObject *s_batch = NULL, *s_p = NULL;
+    if (!s_batch) { s_batch = PyUnicode_InternFromString("_batch"); s_p = PyUnicode_InternFromString("_p"); }
+    if (!s_batch || !s_p) return NULL;
+    const Py_ssize_t n = PyList_GET_SIZE(pairs);
+    Py_ssize_t pos = 0;
+    PyObject *key, *value;
+    while (PyDict_Next(partition, &pos, &key, &value)) {
+        if (key == centre) continue;
+        if ((PyObject *)Py_TYPE(value) != cls) Py_RETURN_FALSE;
+        PyObject *b = PyObject_GetAttr(value, s_batch);
+        if (!b) return NULL;
+        Py_DECREF(b);
+        if (b != batch) Py_RETURN_FALSE;
+        PyObject *pi = PyObject_GetAttr(value, s_p);
+        if (!pi) return NULL;
+        const Py_ssize_t p = PyLong_AsSsize_t(pi);
+        Py_DECREF(pi);
+        if (p == -1 && PyErr_Occurred()) return NULL;
+        if (p < 0 || p >= n) Py_RETURN_FALSE;
+        PyObject *pr = PyList_GET_ITEM(pairs, p);
+        if (!PyTuple_Check(pr) || PyTuple_GET_SIZE(pr) < 2 || PyTuple_GET_ITEM(pr, 0) != centre || PyTuple_GET_ITEM(pr, 1) != key) Py_RETURN_FALSE;
+    }
+    Py_RETURN_TRUE;
+}
+
 static PyMethodDef methods[] = {
+    {"lazy_rows_intact", lazy_rows_intact, METH_VARARGS, "the values of a partition are still the lazily expanded alignments filed there"},
+    {"unique_values_by_length", unique_values_by_length, METH_VARARGS, "unique values of a dict, stably sorted by length, with their last keys"},
+    {"flatten_pairs", flatten_pairs, METH_VARARGS, "(outer key, inner key) pairs of a dict of dicts / sets, and the inner values"},
+    {"alignment_dict", alignment_dict, METH_VARARGS, "alignment tuples and the dict of dicts that files them under their pairs"},
+    {"lazy_rows", lazy_rows, METH_VARARGS, "files lazily expanded alignment values under their centres"},
     {"group_keys_by_value", group_keys_by_value, METH_VARARGS, "{value: [keys]} of a dict, in insertion order"},
     {"rank_strings", rank_strings, METH_VARARGS, "rank of every string of a list in the sorted order of the list"},
     {"pair_ids", pair_ids, METH_VARARGS, "ids of the members of a list of pairs"},

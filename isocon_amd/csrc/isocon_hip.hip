@@ -967,7 +967,13 @@ extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, cons
     return qgram_bounds_for_pairs(s, a, b, n_pairs, out_bound, nullptr);
 }
 
-#include "nn_host.inc"
+#include "nn_context.inc"
+#include "nn_bounds.inc"
+#include "nn_lists.inc"
+#include "nn_main.inc"
+#include "nn_wide.inc"
+#include "nn_images.inc"
+#include "nn_entry.inc"
 #include "sg_host.inc"
 #include "msa_host.inc"
 #include "hw_host.inc"

@@ -295,9 +295,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     static_assert(!HALF || W == 1, "the 32-row band is the narrow form of the 64-row kernel");
     constexpr int ROWS = HALF ? 32 : 64 * W;
     constexpr int UNROLL_COLS = W >= 5 ? 1 : 8;      // 5 words and more: a real loop (VGPRs, instruction cache)
+    // the next block's text is requested while this block computes -- except for the 512-row band, whose 16 waves per table leave 128 registers
+    // a lane: five of them held a block ahead pushed the kernel into scratch (44 B); there the text is requested when the block is done
+    constexpr bool PREFETCH_TEXT = W < 8;
+    constexpr int RING = W < 8 ? NN_RING : 128;      // (a power of two there: the slot arithmetic needs no reciprocal held in a register)
     extern __shared__ uint32_t tw[];
     __shared__ uint32_t s_next;
-    __shared__ uint32_t s_ring[NWAVES][NN_RING][2];
+    __shared__ uint32_t s_ring[NWAVES][RING][2];
     typedef __attribute__((address_space(3))) const uint32_t lds_u32;
     const int32_t wave = threadIdx.x >> 6;
     const int32_t lane = threadIdx.x & 63;
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
     for (;;) {
         const uint64_t freemask = __ballot(!run);
         const uint32_t nfree = (uint32_t)__popcll(freemask);
-        while (!exhausted && qcount < nfree && qcount + 64 <= (uint32_t)NN_RING) {
+        while (!exhausted && qcount < nfree && qcount + 64 <= (uint32_t)RING) {
             uint32_t c0 = 0;
             if (lane == 0) c0 = atomicAdd(&s_next, 64u);
             c0 = (uint32_t)uniform_i32((int32_t)c0);
@@ -453,22 +457,22 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
             }
             const uint64_t am = __ballot(accept);
             if (accept) {
-                const uint32_t slot = (qhead + qcount + (uint32_t)__popcll(am & lt_mask)) % (uint32_t)NN_RING;
+                const uint32_t slot = (qhead + qcount + (uint32_t)__popcll(am & lt_mask)) % (uint32_t)RING;
                 int32_t a0 = lane_emin(d, k);
                 if (a0 < -(ROWS - 1)) a0 = -(ROWS - 1);
                 ring[slot][0] = pid | (us ? 0x40000000u : 0u) | (ul ? 0x80000000u : 0u);
                 ring[slot][1] = (uint32_t)np | ((uint32_t)k << 14) | ((uint32_t)(-a0) << 23);      // 14 + 9 + 9 bits
             }
             qcount += (uint32_t)__popcll(am);
-            n_pairs += (uint32_t)__popcll(am);
-            n_batches += 1;
+            n_pairs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_pairs + (uint32_t)__popcll(am)));          // (wave-uniform counters: kept in scalar registers)
+            if (W < 8) n_batches += 1;          // (the 512-row form has no register to spare for a diagnostic counter)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
         if (nfree && qcount) {
             const uint32_t rank = (uint32_t)__popcll(freemask & lt_mask);
             if (!run && rank < qcount) {
-                const uint32_t slot = (qhead + rank) % (uint32_t)NN_RING;
+                const uint32_t slot = (qhead + rank) % (uint32_t)RING;
                 const uint32_t e0w = ring[slot][0], e1w = ring[slot][1];
                 tid = e0w & 0x3fffffffu;
                 upd_s = (e0w >> 30) & 1u;
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                 run = true;
             }
             const uint32_t taken = nfree < qcount ? nfree : qcount;
-            qhead = (qhead + taken) % (uint32_t)NN_RING;
+            qhead = (qhead + taken) % (uint32_t)RING;
             qcount -= taken;
         }
         const uint64_t runmask = __ballot(run);
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
         }
         uint32_t w0 = __builtin_amdgcn_alignbit(cur[1], cur[0], nsh), w1 = __builtin_amdgcn_alignbit(cur[2], cur[1], nsh),
                  w2 = __builtin_amdgcn_alignbit(cur[3], cur[2], nsh), w3 = __builtin_amdgcn_alignbit(cur[4], cur[3], nsh);
-        if (run && col + 32 < n_t) load5(tp + 4, cur);
+        if (PREFETCH_TEXT && run && col + 32 < n_t) load5(tp + 4, cur);
         if (HALF) {
             uint32_t zreg = 0;
             if (__ballot(run && col + 32 > n_t) == 0) {
@@ -588,8 +592,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
                 a_blk += 32u;
             }
         }
-        n_blocks += 1;
-        n_live += (uint32_t)__popcll(runmask);
+        n_blocks = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_blocks + 1u));
+        if (W < 8) n_live += (uint32_t)__popcll(runmask);
         col += 32;
         const bool fin = run && col >= n_t;
         int32_t dv;
@@ -612,9 +616,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_nn_scan_refill(DevStore S, NNPa
         blk += 128u;
         tp += 4;
         if (!run) blk = idle_blk;
+        if (!PREFETCH_TEXT && run) load5(tp, cur);
     }
     WaveAcc acc;
-    acc.pairs = n_pairs; acc.tiles = n_batches; acc.cols = (unsigned long long)n_blocks * 2048ull; acc.live = (unsigned long long)n_live * 32ull;
+    acc.pairs = n_pairs; acc.tiles = W < 8 ? n_batches : 1u; acc.cols = (unsigned long long)n_blocks * 2048ull;
+    acc.live = (unsigned long long)n_live * 32ull;          // (W = 8 does not count its live lanes: 0)
     nn_flush_acc(P, acc);
     if (lane == 0 && n_filtered) atomicAdd(P.stats + (size_t)NN_COUNTER_SLOTS * 4, (unsigned long long)n_filtered);
 }

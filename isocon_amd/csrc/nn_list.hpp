@@ -25,7 +25,10 @@
 namespace isocon {
 
 static constexpr uint32_t NN_LIST_MIN = 256;       // owners with fewer pairs (and what is left of a list below this): one pair per lane
-static constexpr uint32_t NN_LIST_CHUNK = 2048;    // a wave hands over a chunk as soon as it has staged this many pairs of its entry
+#ifndef ISOCON_NN_LIST_CHUNK          // (experiments build the library with another value: scripts/dev/build_variant.sh)
+#define ISOCON_NN_LIST_CHUNK 2048
+#endif
+static constexpr uint32_t NN_LIST_CHUNK = ISOCON_NN_LIST_CHUNK;    // a wave hands over a chunk as soon as it has staged this many pairs of its entry
 static constexpr int NN_STAGE = NN_LIST_CHUNK + 64;
 
 // counters of the list builder, each on a cache line of its own (they are hot: tens of thousands of atomics per launch)

@@ -130,6 +130,15 @@ __global__ __launch_bounds__(256) void k_qgram_profile4(DevStore S, uint8_t *__r
     if (threadIdx.x < cnt) psum[i0 + threadIdx.x] = s_sum[threadIdx.x];
 }
 
+// -DISOCON_QM_TIMELINE (scripts/dev/build_variant.sh; never in the product build): every workgroup of k_qgram_mm records s_memtime at its
+// phase boundaries -- start, ring primed, K loop done, E1, E2, E3 -- and the host prints where a tile's time goes (nn_bounds.inc).
+#ifdef ISOCON_QM_TIMELINE
+__device__ unsigned long long g_qm_timeline[16384 * 8];
+#define QM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384u) g_qm_timeline[blockIdx.x * 8u + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QM_STAMP(k) do { } while (0)
+#endif
+
 typedef int qm_v8i __attribute__((ext_vector_type(8)));
 typedef float qm_v16f __attribute__((ext_vector_type(16)));
 
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave & 1, wq = wave >> 1;
+    QM_STAMP(0);
     const int r = lane & 31, h = lane >> 5;
 
     uint8_t *meta = qm_lds + (size_t)QM_STAGES * QM_STAGE_BYTES;
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     asm volatile("" ::: "memory");
     read_frags(0, 0);
     read_frags(0, 1);
+    QM_STAMP(1);
     // The two waves of a SIMD (w and w + 4) run this loop in lockstep; a wave that is issuing an LDS-DMA request issues no MFMA, so the
     // second half of the workgroup places its requests BEFORE the MFMA groups, the first half behind them: one partner requests while
     // the other feeds the matrix pipe.
@@ -342,6 +353,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
         if (t > 1) read_frags(kb + 1, 1);
     }
     __syncthreads();          // every wave is done with the ring: it becomes the byte tile out[q][p]
+    QM_STAMP(2);
 
     // ---- E1: accumulators -> bound bytes.  C layout: column (B side, q) = lane & 31, row (A side, p) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     uint32_t *out32 = reinterpret_cast<uint32_t *>(qm_lds);
@@ -370,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
         }
     }
     __syncthreads();
+    QM_STAMP(3);
 
     // ---- E2: rows.  16 threads per row (16 columns each), 32 rows per round
     {
@@ -422,6 +435,10 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
             }
         }
     }
+#ifdef ISOCON_QM_TIMELINE
+    __syncthreads();
+    QM_STAMP(4);
+#endif
     // ---- E3: columns.  Thread = one column x half of the rows: the transposed matrix (row p of lbT = the slots whose window holds p,
     //      lbT[offT[p] + (slot - sloT[p])], address congruent to the slot mod 16), the columns' hub scores and smallest admissible bounds
     if (lbT != nullptr || colmin != nullptr) {
@@ -460,6 +477,15 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
             if (score != nullptr && m_cnt[tid] != 0 && p < n) atomicAdd(score + p, m_cnt[tid]);
         }
     }
+#ifdef ISOCON_QM_TIMELINE
+    __syncthreads();
+    QM_STAMP(5);
+    if (threadIdx.x == 0 && blockIdx.x < 16384u) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_qm_timeline[blockIdx.x * 8u + 6] = hw;
+    }
+#endif
 }
 
 // Row layout of the transposed matrix (nn_host.inc, build_bounds): for entry p the launch slots whose window holds p -- the slots s with

@@ -85,24 +85,20 @@ def protocol_steps(rank, world, n, phase2_steps=None):
     return steps
 
 
-def _device_path_agreed(store, n, dist, device):
-    """The device-resident protocol is used only if EVERY rank can and the collectives run on the GPU: decided once per store and
-    group with one all_reduce(MIN) of a capability flag (a rank deciding from its local state alone could pair a CUDA tensor with a
-    CPU tensor in the same collective)."""
+def _agree(store, n, dist, device):
+    """ONE all_reduce(MIN) per search of (fingerprint, -fingerprint, capability): every rank learns from the reduced values alone whether
+    all ranks packed the very same sequences in the very same order (min == max) and whether EVERY rank can run the device-resident
+    protocol.  Done on every call: a decision cached per store would let a rank whose store was rebuilt enter a collective that the
+    others skip, and a rank deciding from its local state could pair a CUDA tensor with a CPU tensor in one collective.
+    Returns (same set, device path)."""
     import torch
-    world = dist.get_world_size()
-    cached = getattr(store, "_dist_device_path", None)
-    if cached is not None and cached[0] == world and cached[1] == device.type:
-        return cached[2]
     can = (device.type == "cuda" and hasattr(store, "nn_partial_dev") and n > 0 and len(_lib.hip_runtimes_loaded()) == 1 and torch.cuda.is_available())
-    t = torch.tensor([1 if can else 0], dtype=torch.int32, device=device)
+    fp = getattr(store, "fingerprint", None)
+    fp = 0 if fp is None else int(fp)
+    t = torch.tensor([fp, -fp, 1 if can else 0], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    agreed = bool(int(t.item()))
-    try:
-        store._dist_device_path = (world, device.type, agreed)
-    except AttributeError:
-        pass
-    return agreed
+    lo, neg_hi, agreed = (int(x) for x in t.tolist())
+    return lo == -neg_hi, bool(agreed)
 
 
 def _all_gather_rows(dist, rows, device):
@@ -124,7 +120,7 @@ def _all_gather_rows(dist, rows, device):
 
 def same_everywhere(value, dist=None, device=None):
     """True iff the int64 `value` (a store fingerprint, a hash of a pair list ...) is the same on every rank; every rank gets
-    the same answer (one all_reduce(MIN) of (value, -value))."""
+    the same answer from ONE all_reduce(MIN) of (value, -value): the reduced pair is (min, -max)."""
     import torch
     if dist is None:
         import torch.distributed as dist  # noqa: PLC0415
@@ -132,10 +128,9 @@ def same_everywhere(value, dist=None, device=None):
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     value = int(value)
     t = torch.tensor([value, -value], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    ok = torch.tensor([1 if (int(t[0].item()) == value and int(t[1].item()) == -value) else 0], dtype=torch.int64, device=device)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    return bool(int(ok.item()))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)          # (min, -max): equal on every rank iff min == max, which every rank sees
+    lo, neg_hi = (int(x) for x in t.tolist())
+    return lo == -neg_hi
 
 
 def _digest(*arrays):
@@ -267,18 +262,12 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     n = store.n
     tl = time.perf_counter()
-    fp = getattr(store, "fingerprint", None)
-    if fp is not None and getattr(store, "_fingerprint_agreed", None) != (world, fp):
-        # every rank must have packed the very same sequences in the very same order (checked once per store)
-        if not same_everywhere(fp, dist, device):
-            raise RuntimeError("sharded_nn_graph: the ranks hold different sequence sets / orders (fingerprint mismatch); "
-                               "build the store from a deterministic order (not from set())")
-        try:
-            store._fingerprint_agreed = (world, fp)
-        except AttributeError:
-            pass
+    same, device_path = _agree(store, n, dist, device)
+    if not same:
+        raise RuntimeError("sharded_nn_graph: the ranks hold different sequence sets / orders (fingerprint mismatch); "
+                           "build the store from a deterministic order (not from set())")
     tl = lap("fingerprint", tl)
-    if _device_path_agreed(store, n, dist, device):
+    if device_path:
         out = _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap)
         return out if return_stats else out[:3]
     hits_all, stats_all = [], []

@@ -19,7 +19,10 @@ def get_unique_seq_accessions(S):
     from . import _lib
     H = _lib.pyhelp()
     if H is not None and hasattr(H, "group_keys_by_value") and type(S) is dict:
-        return H.group_keys_by_value(S)          # (the same loop in C: 50 000 reads per correction step)
+        try:
+            return H.group_keys_by_value(S)          # (the same loop in C: 50 000 reads per correction step)
+        except TypeError:                            # (values that are not exact str: the plain loop)
+            pass
     seq_to_acc = {}
     for acc, seq in S.items():
         seq_to_acc.setdefault(seq, []).append(acc)
@@ -95,12 +98,19 @@ def _partition_alignments_from_ops(graph_partition, M, G_star, exon_filtered, pa
     from . import _lib
     from .SW_alignment_module import TIE_POLICY
     from .store import store_for_pairs
-    pairs = [(m, s) for m, members in graph_partition.items() for s in members]
+    H = _lib.pyhelp()
+    pairs = None
+    if H is not None and hasattr(H, "flatten_pairs") and type(graph_partition) is dict:
+        try:
+            pairs = H.flatten_pairs(graph_partition)[0]          # [(centre, member)] in the dict's / the sets' iteration order, in C
+        except TypeError:
+            pairs = None
+    if pairs is None:
+        pairs = [(m, s) for m, members in graph_partition.items() for s in members]
     out = PartitionAlignments()
     if pairs:
-        st, a, b, owned = store_for_pairs(pairs)
-        if owned:          # (not the remembered store: nothing to keep resident -- the plain path)
-            st.close()
+        st, a, b, owned = store_for_pairs(pairs, only_remembered=True)
+        if st is None:          # (not the remembered store: nothing to keep resident -- the plain path, and nothing was packed to find out)
             return None
         if bool((st.lens[a] == 0).any() or (st.lens[b] == 0).any()):
             raise ValueError("empty sequence in an alignment pair")
@@ -124,10 +134,15 @@ def _partition_alignments_from_ops(graph_partition, M, G_star, exon_filtered, pa
     for m in M:
         out[m] = {m: (0, m, m, G_star.nodes[m]["degree"])}
     if pairs:
-        for p in np.flatnonzero(keep).tolist():
-            m, s = pairs[p]
-            out[m][s] = LazyAlignment(batch, p, edit[p])
-            batch.rows_of.setdefault(m, []).append(p)
+        if H is not None and hasattr(H, "lazy_rows") and all(m in out for m in graph_partition):
+            keep_c = np.ascontiguousarray(keep, dtype=np.uint8)
+            edit_c = np.ascontiguousarray(res[:, 4] + res[:, 5], dtype=np.int32)
+            H.lazy_rows(LazyAlignment, batch, pairs, keep_c.ctypes.data, edit_c.ctypes.data, out, batch.rows_of)
+        else:
+            for p in np.flatnonzero(keep).tolist():
+                m, s = pairs[p]
+                out[m][s] = LazyAlignment(batch, p, edit[p])
+                batch.rows_of.setdefault(m, []).append(p)
     return out
 
 

@@ -116,13 +116,15 @@ def nn_1set_arrays(seqs, conv, depth):
     return best, row_ptr, cols
 
 
-def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
-    seqs = [s for s, _ in seq_to_acc_list_sorted]
-    accs = [a for _, a in seq_to_acc_list_sorted]
+def _nn_1set_lists(seqs, accs, has_converged, depth):
     conv = np.fromiter((1 if s in has_converged else 0 for s in seqs), dtype=np.uint8, count=len(seqs)) if has_converged else np.zeros(len(seqs), dtype=np.uint8)
     best, row_ptr, cols = nn_1set_arrays(seqs, conv, depth)
     # every entry gets a key; converged ones an empty dict (NNG:120-123)
     return _rows_to_dict(accs, np.ones(len(accs), dtype=bool), best, row_ptr, cols)
+
+
+def _nn_1set(seq_to_acc_list_sorted, has_converged, depth):
+    return _nn_1set_lists([s for s, _ in seq_to_acc_list_sorted], [a for _, a in seq_to_acc_list_sorted], has_converged, depth)
 
 
 _SLICED = {"key": None, "graph": None}      # the whole graph of the most recent sliced call
@@ -160,6 +162,20 @@ def get_exact_nearest_neighbor_graph(seq_to_acc_list_sorted, has_converged, para
 
 def compute_nearest_neighbor_graph(S, has_converged, params):
     """NNG:237-296 -> (nearest_neighbor_graph, isolated)."""
+    from . import _lib
+    H = _lib.pyhelp()
+    if H is not None and hasattr(H, "unique_values_by_length") and type(S) is dict:
+        try:
+            # unique sequences (first position, last accession: NNG:243) stably sorted by length (NNG:246), in one pass in C
+            seqs, accs = H.unique_values_by_length(S)
+        except TypeError:
+            seqs = None
+        if seqs is not None:
+            nearest_neighbor_graph = _nn_1set_lists(seqs, accs, has_converged, params.neighbor_search_depth)
+            if len(nearest_neighbor_graph) == len(seqs):       # every unique sequence has a row (NNG:120-123): nothing is isolated
+                return nearest_neighbor_graph, set()
+            seen = set(S[acc1] for acc1 in nearest_neighbor_graph)
+            return nearest_neighbor_graph, set(seqs).difference(seen)
     seq_to_acc = {seq: acc for (acc, seq) in S.items()}
     items = list(seq_to_acc.items())
     # stable sort by length (NNG:246) through numpy: the same order as sorted(..., key=len) at a fraction of the calls

@@ -493,9 +493,10 @@ def forget():
     _RECENT["index"] = None
 
 
-def store_for_pairs(pairs):
+def store_for_pairs(pairs, only_remembered=False):
     """[(x, y), ...] -> (store, a ids, b ids, owned).  Reuses the remembered store when it holds every sequence of the
-    pair list; otherwise packs a private one (owned = True: the caller closes it)."""
+    pair list; otherwise packs a private one (owned = True: the caller closes it) -- or, with only_remembered, packs nothing and
+    returns (None, None, None, False): a caller that can only use the remembered store finds out before anything is uploaded."""
     index = _RECENT["index"]
     n = len(pairs)
     a = np.empty(n, dtype=np.uint32)
@@ -514,6 +515,8 @@ def store_for_pairs(pairs):
         except KeyError:
             a = np.empty(n, dtype=np.uint32)
             b = np.empty(n, dtype=np.uint32)
+    if only_remembered:
+        return None, None, None, False
     index, seqs = {}, []
     for p, (x, y) in enumerate(pairs):
         ia = index.get(x)

@@ -144,7 +144,7 @@ def check_rank_strings(H):
 
 
 def check_group_keys_by_value(H):
-    for d in ({}, {"a": "X"}, {"a": "X", "b": "Y", "c": "X", "d": "Z", "e": "Y"}, {i: i % 7 for i in range(1000)}):
+    for d in ({}, {"a": "X"}, {"a": "X", "b": "Y", "c": "X", "d": "Z", "e": "Y"}, {i: "v%d" % (i % 7) for i in range(1000)}):
         want = {}
         for k, v in d.items():
             want.setdefault(v, []).append(k)
@@ -154,10 +154,104 @@ def check_group_keys_by_value(H):
         H.group_keys_by_value([("a", "X")])
     with pytest.raises(TypeError):
         H.group_keys_by_value({"a": ["unhashable"]})
+    with pytest.raises(TypeError):          # values must be exact str: their hash / eq cannot run code that changes the dict under the loop
+        H.group_keys_by_value({"a": 1})
+
+
+def check_unique_values_by_length(H):
+    rng = np.random.Generator(np.random.PCG64(9))
+    for n in (0, 1, 5, 3000):
+        vals = ["ACGT"[int(rng.integers(0, 4))] * int(rng.integers(0, 40)) + "G" * int(rng.integers(0, 3)) for _ in range(n)]
+        S = {"acc%d" % i: v for i, v in enumerate(vals)}
+        inv = {seq: acc for acc, seq in S.items()}                         # NNG:243
+        want = sorted(inv.items(), key=lambda x: len(x[0]))                # NNG:246 (stable)
+        seqs, accs = H.unique_values_by_length(S)
+        assert seqs == [s for s, _ in want] and accs == [a for _, a in want]
+    with pytest.raises(TypeError):
+        H.unique_values_by_length({"a": 5})
+    with pytest.raises(TypeError):
+        H.unique_values_by_length([("a", "ACGT")])
+
+
+def check_flatten_pairs(H):
+    m = {"x": {"p": 1, "q": 2}, "y": {}, "z": {"r": 3}}
+    assert H.flatten_pairs(m) == ([("x", "p"), ("x", "q"), ("z", "r")], [1, 2, 3])
+    sets = {"x": {"p", "q", "r"}, "y": set(), "z": ["k", "k"], "w": ("t",)}
+    pairs, vals = H.flatten_pairs(sets)
+    assert vals is None and pairs == [(k, v) for k, inner in sets.items() for v in inner]
+    assert H.flatten_pairs({}) == ([], None)
+    big = {"c%d" % i: {"m%d_%d" % (i, j): i * j for j in range(i % 13)} for i in range(500)}
+    assert H.flatten_pairs(big) == ([(a, b) for a, inner in big.items() for b in inner], [v for inner in big.values() for v in inner.values()])
+    with pytest.raises(TypeError):
+        H.flatten_pairs({"x": {"p": 1}, "y": {"q"}})
+    with pytest.raises(TypeError):
+        H.flatten_pairs({"x": 5})
+    with pytest.raises(TypeError):
+        H.flatten_pairs([("x", "p")])
+
+
+def check_alignment_dict(H):
+    pairs = [("x", "p"), ("x", "q"), ("y", "p")]
+    la, lb = ["A-C", "GG", ""], ["AAC", "G-", ""]
+    res = np.arange(18, dtype=np.int32).reshape(3, 6)
+    out, d = H.alignment_dict(pairs, la, lb, res.ctypes.data)
+    assert out == [("A-C", "AAC", (3, 4, 5)), ("GG", "G-", (9, 10, 11)), ("", "", (15, 16, 17))]
+    assert d == {"x": {"p": out[0], "q": out[1]}, "y": {"p": out[2]}} and list(d) == ["x", "y"] and list(d["x"]) == ["p", "q"]
+    assert d["x"]["q"] is out[1]                     # the very tuple objects (the ops cache finds an alignment by identity)
+    assert H.alignment_dict([], [], [], res.ctypes.data) == ([], {})
+    with pytest.raises(TypeError):
+        H.alignment_dict(pairs, la[:2], lb, res.ctypes.data)
+    with pytest.raises(TypeError):
+        H.alignment_dict([("x",)], ["A"], ["A"], res.ctypes.data)
+
+
+def check_lazy_rows(H):
+    class V(object):
+        __slots__ = ("_batch", "_p", "_edit")
+
+        def __init__(self, batch, p, edit):
+            self._batch, self._p, self._edit = batch, p, edit
+
+    batch = object()
+    pairs = [("c1", "a"), ("c1", "b"), ("c2", "a"), ("c2", "z"), ("c1", "c")]
+    keep = np.array([1, 0, 1, 1, 1], dtype=np.uint8)
+    edit = np.array([5, 6, 70000, 8, 0], dtype=np.int32)
+    out = {"c1": {"c1": 0}, "c2": {"c2": 0}}
+    rows_of = {}
+    assert H.lazy_rows(V, batch, pairs, keep.ctypes.data, edit.ctypes.data, out, rows_of) == 4
+    assert rows_of == {"c1": [0, 4], "c2": [2, 3]}
+    assert list(out["c1"]) == ["c1", "a", "c"] and list(out["c2"]) == ["c2", "a", "z"]
+    v = out["c2"]["a"]
+    assert type(v) is V and v._batch is batch and v._p == 2 and v._edit == 70000
+    for c in ("c1", "c2"):
+        assert H.lazy_rows_intact(out[c], c, V, batch, pairs) is True
+    assert H.lazy_rows_intact(out["c1"], "c1", V, object(), pairs) is False          # another batch
+    out["c1"]["b"] = out["c1"].pop("a")                                                # re-keyed
+    assert H.lazy_rows_intact(out["c1"], "c1", V, batch, pairs) is False
+    out["c2"]["z"] = (8, "A", "A", 1)                                                  # replaced by a plain tuple
+    assert H.lazy_rows_intact(out["c2"], "c2", V, batch, pairs) is False
+    with pytest.raises(KeyError):
+        H.lazy_rows(V, batch, [("nope", "a")], keep.ctypes.data, edit.ctypes.data, {}, {})
 
 
 def test_group_keys_by_value():
     check_group_keys_by_value(_helper())
+
+
+def test_unique_values_by_length():
+    check_unique_values_by_length(_helper())
+
+
+def test_flatten_pairs():
+    check_flatten_pairs(_helper())
+
+
+def test_alignment_dict():
+    check_alignment_dict(_helper())
+
+
+def test_lazy_rows():
+    check_lazy_rows(_helper())
 
 
 def test_rank_strings():
@@ -204,6 +298,7 @@ def test_under_address_and_undefined_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
                ISOCON_PYHELP_UNDER_TEST=so)
     code = ("import sys; sys.path.insert(0, %r); import test_pyhelp as T; H = T._helper(); "
-            "T.check_group_keys_by_value(H); T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_csr_to_dict(H); T.check_pair_ids(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
+            "T.check_group_keys_by_value(H); T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_csr_to_dict(H); T.check_pair_ids(H); "
+            "T.check_unique_values_by_length(H); T.check_flatten_pairs(H); T.check_alignment_dict(H); T.check_lazy_rows(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
