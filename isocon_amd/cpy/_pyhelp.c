@@ -420,8 +420,13 @@ static PyObject *alignment_dict(PyObject *self, PyObject *args)
     for (Py_ssize_t p = 0; p < n; ++p) {
         PyObject *pr = PyList_GET_ITEM(pairs, p);
         if (!PyTuple_Check(pr) || PyTuple_GET_SIZE(pr) < 2) { PyErr_Format(PyExc_TypeError, "pair %zd is not a 2-tuple", p); goto fail; }
-        PyObject *cnt = Py_BuildValue("(iii)", (int)res[p * 6 + 3], (int)res[p * 6 + 4], (int)res[p * 6 + 5]);
+        PyObject *cnt = PyTuple_New(3);          /* (matches, mismatches, indels) */
         if (!cnt) goto fail;
+        for (int k = 0; k < 3; ++k) {
+            PyObject *v = PyLong_FromLong((long)res[p * 6 + 3 + k]);
+            if (!v) { Py_DECREF(cnt); goto fail; }
+            PyTuple_SET_ITEM(cnt, k, v);
+        }
         PyObject *t = PyTuple_Pack(3, PyList_GET_ITEM(la, p), PyList_GET_ITEM(lb, p), cnt);
         Py_DECREF(cnt);
         if (!t) goto fail;

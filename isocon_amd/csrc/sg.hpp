@@ -44,11 +44,12 @@ struct SgPair {            // per pair of the batch
     uint64_t bound_off;    // first int2 of this pair's pass-boundary row (capacity n)
     int32_t dhi;
     int32_t steps;         // steps per pass (window columns + 63), the same for every pass of the pair
-    int32_t mode;          // 0: strips of 512 query rows (k_sg_forward); 1: the band's diagonals on the lanes (k_sg_band)
+    int32_t mode;          // 0: strips of 512 query rows (k_sg_forward); 1 / 2: the band's diagonals on the lanes, 4 / 2 per lane (k_sg_band<.., 4 / 2>)
     int32_t pad_;
 };
 
-static constexpr int SG_BAND_DIAGS = 256;      // k_sg_band: 64 lanes x 4 diagonals
+static constexpr int SG_BAND_DIAGS = 256;      // k_sg_band<.., 4>: 64 lanes x 4 diagonals
+static constexpr int SG_BAND_DIAGS_NARROW = 128;      // k_sg_band<.., 2>: 64 lanes x 2 diagonals (half the cells per step, half the trace)
 
 // Column window of one pass (64*R query rows starting at prow0) for the band [dlo, dhi]: every cell of the band lies
 // inside, the window starts on a multiple of 64 (text chunks) at least one column left of the band.  Cells of the
@@ -297,14 +298,18 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
 // Match bits: per slot a 64-cell mask ~(q ^ t) of its diagonal, refilled every 128 steps (per-lane unaligned plane fetches).
 // Trace: the two nibbles of a step form a byte, four steps a dword: ((a >> 2) * 64 + lane) * 4 bytes -- one 256-B line per
 // four steps, (m + n) * 64 bytes per pair instead of ~ m * (512 + band) / 2.
-template <bool POL0, bool EXT0>
+template <bool POL0, bool EXT0, int DPL = 4>
 __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__restrict__ pairs, SgParams prm,
                                                    uint8_t *__restrict__ trace, int32_t *__restrict__ endinfo)
 {
     const uint32_t pidx = blockIdx.x;
     const int lane = threadIdx.x;
     const SgPair pr = pairs[pidx];
-    if (uniform_i32(pr.mode) != 1) return;
+    static_assert(DPL == 4 || DPL == 2, "diagonals per lane: 4 (bands of up to 256 diagonals) or 2 (up to 128: half the cells and half the trace)");
+    constexpr int DIAGS = 64 * DPL;                 // diagonals of the band
+    constexpr int SPW = 32 / (2 * DPL);             // steps per trace dword: DPL / 2 nibbles per step
+    constexpr int SPW_LOG = DPL == 4 ? 2 : 3;
+    if (uniform_i32(pr.mode) != (DPL == 4 ? 1 : 2)) return;
     const uint32_t ia = (uint32_t)uniform_i32((int32_t)pr.a), ib = (uint32_t)uniform_i32((int32_t)pr.b);
     const int32_t m = uniform_i32(S.lens[ia]), n = uniform_i32(S.lens[ib]);
     const int32_t match = prm.match, mism = uniform_i32(pr.mismatch), open = prm.open, ext = prm.ext;
@@ -323,17 +328,17 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
     const int32_t nchunks = (int32_t)S.nchunks;
     uint32_t *tw_base = reinterpret_cast<uint32_t *>(trace + pr.trace_off);
     const int32_t dlo = uniform_i32(pr.dlo);
-    const int32_t d0 = dlo + 4 * lane;
-    int32_t H[4], E[4], F[4];
-    uint32_t Mlo[4], Mhi[4], Mcur[4];
+    const int32_t d0 = dlo + DPL * lane;
+    int32_t H[DPL], E[DPL], F[DPL];
+    uint32_t Mlo[DPL], Mhi[DPL], Mcur[DPL];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { H[s] = 0; E[s] = SG_NEG; F[s] = SG_NEG; Mlo[s] = Mhi[s] = Mcur[s] = 0; }
+    for (int s = 0; s < DPL; ++s) { H[s] = 0; E[s] = SG_NEG; F[s] = SG_NEG; Mlo[s] = Mhi[s] = Mcur[s] = 0; }
     int32_t rowbest = SG_NEG, rowj_first = -1, rowj_last = -1;      // last query row, over this lane's columns (ascending)
     int32_t colbest = SG_NEG, coli_first = -1, coli_last = -1;      // last ref column, over this lane's rows (ascending)
     const int32_t a_end = m + n - 2;
-    const int32_t row_from = 2 * (m - 1) + dlo, col_from = 2 * (n - 1) - dlo - (SG_BAND_DIAGS - 1);
+    const int32_t row_from = 2 * (m - 1) + dlo, col_from = 2 * (n - 1) - dlo - (DIAGS - 1);
     // steps at which EVERY lane's two cells lie inside the matrix and off its last row / column: no range checks there
-    const int32_t dtop = dlo + SG_BAND_DIAGS - 1;
+    const int32_t dtop = dlo + DIAGS - 1;
     const int32_t in_from = (dtop > -dlo ? dtop : -dlo) + 1;
     const int32_t in_to = (2 * (m - 1) + dlo < 2 * (n - 1) - dtop ? 2 * (m - 1) + dlo : 2 * (n - 1) - dtop) - 1;      // inclusive
     uint32_t tw = 0;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
         constexpr int PAR = decltype(par_tag)::value;
         if ((a & 127) == 0) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < DPL; ++s) {
                 const int32_t d = d0 + s;
                 const int32_t ifirst = (a + ((a - d) & 1) - d) >> 1;            // row of the slot's first cell at or after step a
                 const uint64_t ql = plane_bits64(planes, nseq, nchunks, ia, 0, ifirst), qh = plane_bits64(planes, nseq, nchunks, ia, 1, ifirst);
@@ -401,39 +406,51 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
         }
         if ((a & 63) == 0) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) Mcur[s] = (a & 64) ? Mhi[s] : Mlo[s];
+            for (int s = 0; s < DPL; ++s) Mcur[s] = (a & 64) ? Mhi[s] : Mlo[s];
         }
         const int32_t kbit = (a & 63) >> 1;
-        uint32_t f0, e0, g0, x0, f1, e1, g1, x1;
+        uint32_t f0, e0, g0, x0, f1 = 0, e1 = 0, g1 = 0, x1 = 0;
         const bool interior = a >= in_from && a <= in_to;      // wave-uniform: both cells of every lane are plain matrix cells
         if (PAR == 0) {
             const int32_t edge = (interior || a + dlo != 0) ? SG_NEG : 0;      // left of the band: -inf, or the boundary column of cell (i, 0)
-            const int32_t Hl = __builtin_amdgcn_update_dpp(edge, H[3], 0x138, 0xf, 0xf, false);      // wave_shr:1: lane l takes lane l - 1
-            const int32_t El = __builtin_amdgcn_update_dpp(SG_NEG, E[3], 0x138, 0xf, 0xf, false);
-            const int32_t h1 = H[1], e1s = E[1], f1s = F[1], h3 = H[3], f3 = F[3];
-            if (interior) {
-                core(H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
-                core(H[2], E[2], F[2], h3, f3, h1, e1s, Mcur[2], kbit, f1, e1, g1, x1);
-            } else {
-                cell(a, d0, H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
-                cell(a, d0 + 2, H[2], E[2], F[2], h3, f3, h1, e1s, Mcur[2], kbit, f1, e1, g1, x1);
+            const int32_t Hl = __builtin_amdgcn_update_dpp(edge, H[DPL - 1], 0x138, 0xf, 0xf, false);      // wave_shr:1: lane l takes lane l - 1
+            const int32_t El = __builtin_amdgcn_update_dpp(SG_NEG, E[DPL - 1], 0x138, 0xf, 0xf, false);
+            if constexpr (DPL == 4) {
+                const int32_t h1 = H[1], e1s = E[1], f1s = F[1], h3 = H[3], f3 = F[3];
+                if (interior) {
+                    core(H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
+                    core(H[2], E[2], F[2], h3, f3, h1, e1s, Mcur[2], kbit, f1, e1, g1, x1);
+                } else {
+                    cell(a, d0, H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
+                    cell(a, d0 + 2, H[2], E[2], F[2], h3, f3, h1, e1s, Mcur[2], kbit, f1, e1, g1, x1);
+                }
+            } else {          // two diagonals per lane: slot 0 (up = the lane's slot 1, left = lane - 1's slot 1)
+                const int32_t h1 = H[1], f1s = F[1];
+                if (interior) core(H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
+                else cell(a, d0, H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
             }
         } else {
-            const int32_t edge = (interior || a - dlo - (SG_BAND_DIAGS - 1) != 0) ? SG_NEG : 0;   // above the band: -inf, or the boundary row of cell (0, j)
+            const int32_t edge = (interior || a - dlo - (DIAGS - 1) != 0) ? SG_NEG : 0;   // above the band: -inf, or the boundary row of cell (0, j)
             const int32_t Hu = __builtin_amdgcn_update_dpp(edge, H[0], 0x130, 0xf, 0xf, false);      // wave_shl:1: lane l takes lane l + 1
             const int32_t Fu = __builtin_amdgcn_update_dpp(SG_NEG, F[0], 0x130, 0xf, 0xf, false);
-            const int32_t h0 = H[0], e0s = E[0], h2 = H[2], e2s = E[2], f2s = F[2];
-            if (interior) {
-                core(H[1], E[1], F[1], h2, f2s, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
-                core(H[3], E[3], F[3], Hu, Fu, h2, e2s, Mcur[3], kbit, f1, e1, g1, x1);
-            } else {
-                cell(a, d0 + 1, H[1], E[1], F[1], h2, f2s, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
-                cell(a, d0 + 3, H[3], E[3], F[3], Hu, Fu, h2, e2s, Mcur[3], kbit, f1, e1, g1, x1);
+            if constexpr (DPL == 4) {
+                const int32_t h0 = H[0], e0s = E[0], h2 = H[2], e2s = E[2], f2s = F[2];
+                if (interior) {
+                    core(H[1], E[1], F[1], h2, f2s, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
+                    core(H[3], E[3], F[3], Hu, Fu, h2, e2s, Mcur[3], kbit, f1, e1, g1, x1);
+                } else {
+                    cell(a, d0 + 1, H[1], E[1], F[1], h2, f2s, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
+                    cell(a, d0 + 3, H[3], E[3], F[3], Hu, Fu, h2, e2s, Mcur[3], kbit, f1, e1, g1, x1);
+                }
+            } else {          // slot 1 (up = lane + 1's slot 0, left = the lane's slot 0)
+                const int32_t h0 = H[0], e0s = E[0];
+                if (interior) core(H[1], E[1], F[1], Hu, Fu, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
+                else cell(a, d0 + 1, H[1], E[1], F[1], Hu, Fu, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
             }
         }
         push(f0, e0, g0, x0);
-        push(f1, e1, g1, x1);
-        if ((a & 3) == 3 && a >= 0) tw_base[(size_t)(a >> 2) * 64 + lane] = tw;
+        if constexpr (DPL == 4) push(f1, e1, g1, x1);
+        if ((a & (SPW - 1)) == SPW - 1 && a >= 0) tw_base[(size_t)(a >> SPW_LOG) * 64 + lane] = tw;
     };
     // the first step of a pair is the "even" kind: start one anti-diagonal early if dlo is odd (no cell lives there; its
     // byte is shifted out of the trace word before the first store), and the pair's last half may lie beyond a_end
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
         step(a + 1, std::integral_constant<int, 1>());
     }
     const int32_t a_done = a - 1;                 // last step taken (a_end or a_end + 1)
-    if (((a_done + 1) & 3) != 0) tw_base[(size_t)(a_done >> 2) * 64 + lane] = tw << (8 * (4 - ((a_done + 1) & 3)));
+    if (((a_done + 1) & (SPW - 1)) != 0) tw_base[(size_t)(a_done >> SPW_LOG) * 64 + lane] = tw << (2 * DPL * (SPW - ((a_done + 1) & (SPW - 1))));
     // reduce the candidates over lanes: maximum; smallest (first) / largest (last) column resp. row on ties
     int32_t rb = rowbest, rf = rowj_first, rl = rowj_last, cb = colbest, cf = coli_first, cl = coli_last;
 #pragma unroll
@@ -492,7 +509,7 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
     const uint32_t p = blockIdx.x * 64u + threadIdx.x;
     if (p >= n_pairs) return;
     const SgPair pr = pairs[p];
-    if (pr.mode == 1) return;                // k_sg_band's trace layout: k_sg_walk_band
+    if (pr.mode != 0) return;                // k_sg_band's trace layouts: k_sg_walk_band<4 | 2>
     const int32_t m = S.lens[pr.a], n = S.lens[pr.b];
     const int32_t R = Rs[p];
     const uint8_t *tb = trace + pr.trace_off;
@@ -555,7 +572,11 @@ __global__ __launch_bounds__(64) void k_sg_walk_band(DevStore S, const SgPair *_
     const uint32_t p = blockIdx.x * 64u + threadIdx.x;
     if (p >= n_pairs) return;
     const SgPair pr = pairs[p];
-    if (pr.mode != 1) return;
+    if (pr.mode != 1 && pr.mode != 2) return;
+    // k_sg_band<.., DPL>'s layout, DPL = 4 (mode 1) or 2 (mode 2) diagonals per lane: DPL / 2 nibbles per step, 4 or 8 steps per dword.  One
+    // launch walks both classes (a launch per class cost the latency of a thread's ~5 000 dependent steps twice)
+    const bool four = pr.mode == 1;
+    const int32_t DIAGS = four ? 256 : 128, SPW_LOG = four ? 2 : 3, DPL_LOG = four ? 2 : 1;
     const int32_t m = S.lens[pr.a], n = S.lens[pr.b];
     const uint32_t *tb = reinterpret_cast<const uint32_t *>(trace + pr.trace_off);
     const int32_t score = endinfo[(size_t)p * 4], eq = endinfo[(size_t)p * 4 + 1], er = endinfo[(size_t)p * 4 + 2];
@@ -586,8 +607,8 @@ __global__ __launch_bounds__(64) void k_sg_walk_band(DevStore S, const SgPair *_
     const int32_t dlo = pr.dlo;
     while (i >= 0 && j >= 0) {
         const int32_t sl = (j - i) - dlo;
-        if ((uint32_t)sl >= (uint32_t)SG_BAND_DIAGS) { left_window = true; break; }
-        const int32_t a = i + j, q = a >> 2, lc = sl >> 2;
+        if ((uint32_t)sl >= (uint32_t)DIAGS) { left_window = true; break; }
+        const int32_t a = i + j, q = a >> SPW_LOG, lc = sl >> DPL_LOG;
         if (lc != c_lane || q > c_top || q < c_top - 31) {
             const uint32_t *col = tb + lc;
             c_lane = lc; c_top = q;
@@ -598,7 +619,7 @@ __global__ __launch_bounds__(64) void k_sg_walk_band(DevStore S, const SgPair *_
             for (int x = 0; x < 32; ++x) my[x] = w[x];
         }
         const uint32_t word = my[c_top - q];
-        const uint32_t tr = (word >> (8 * (3 - (a & 3)) + ((sl & 2) ? 0 : 4))) & 15u;
+        const uint32_t tr = (word >> (four ? 8 * (3 - (a & 3)) + ((sl & 2) ? 0 : 4) : 4 * (7 - (a & 7)))) & 15u;
         const uint32_t gap = (tr >> 1) & 1u, xbit = tr & 1u, fopen = (tr >> 3) & 1u, eopen = (tr >> 2) & 1u;
         const bool w0 = where == 0, w1 = where == 1;
         const bool prod = w0 ? gap == 0 : true;                                   // this step emits one alignment column

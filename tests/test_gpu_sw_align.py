@@ -217,3 +217,45 @@ def test_diagonal_band_kernel_equals_strip_kernel(monkeypatch):
         assert (r1 == r2).all() and (p1 == p2).all() and (o1 == o2).all(), (policy, open_, ext)
         assert (r1 == r3).all() and (p1 == p3).all() and (o1 == o3).all(), (policy, open_, ext)
     st.close()
+
+
+def test_two_band_classes_give_the_same_alignments(monkeypatch):
+    """Certified bands of at most 128 diagonals run with TWO diagonals per lane (k_sg_band<.., 2>: half the cells per step, half the trace),
+    wider ones up to 256 with four; ISOCON_DEBUG_VARIANT=sw_band256 sends every pair through the four-per-lane form.  Pairs on both sides of
+    the class boundary (bands of ~40 .. ~250 diagonals, length differences of both signs, ends cut), every tie policy class, both gap
+    models: the two runs and the full matrix give identical ops and results, and both classes were in the default run."""
+    from isocon_amd import synth
+    from isocon_amd.store import SeqStore, sg_last_stats
+    rng = np.random.Generator(np.random.PCG64(19))
+    seqs, a, b = [], [], []
+    for it in range(96):
+        L = int(rng.integers(300, 2600))
+        base = synth._rand_seq(rng, L)
+        rate = [0.002, 0.004, 0.008, 0.012, 0.02, 0.03][it % 6]
+        x = synth.mutate(rng, base, dict(synth.CCS_PROFILE, rate=rate))
+        y = synth.mutate(rng, base, dict(synth.ONT_PROFILE, rate=rate))
+        if it % 4 == 0:
+            y = y[int(rng.integers(0, 20)):len(y) - int(rng.integers(0, 20))]
+        if it % 7 == 0:
+            x = x[int(rng.integers(0, 25)):]
+        seqs += [x.tobytes().decode(), y.tobytes().decode()]
+        if it % 2:
+            a.append(2 * it); b.append(2 * it + 1)
+        else:
+            a.append(2 * it + 1); b.append(2 * it)
+    st = SeqStore(seqs)
+    ed = st.ed_pairs(a, b, None)
+    mm = np.array([[-1, -2, -4][i % 3] for i in range(len(a))], dtype=np.int8)
+    for policy, open_, ext in ((0, 2, 0), (3, 2, 0), (12, 2, 0), (21, 2, 0), (0, 3, 1)):
+        monkeypatch.delenv("ISOCON_DEBUG_VARIANT", raising=False)
+        o1, p1, r1 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy, ed_upper=ed)
+        stats = sg_last_stats()
+        assert 0 < stats["pairs_band_narrow"] < stats["pairs_band"], stats          # both classes
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "sw_band256")
+        o2, p2, r2 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy, ed_upper=ed)
+        assert sg_last_stats()["pairs_band_narrow"] == 0 and sg_last_stats()["trace_bytes"] > stats["trace_bytes"]
+        monkeypatch.delenv("ISOCON_DEBUG_VARIANT", raising=False)
+        o3, p3, r3 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy)
+        assert (r1 == r2).all() and (p1 == p2).all() and (o1 == o2).all(), (policy, open_, ext)
+        assert (r1 == r3).all() and (p1 == p3).all() and (o1 == o3).all(), (policy, open_, ext)
+    st.close()
