@@ -501,7 +501,7 @@ def main():
                        "frac": ach_n / VALU_PEAK_WAVE_INSTR if ach_n else None}
     alg_bytes = pairs_eval * (2.0 * mean_len + 8.0)
     align_ms = tables_ms + pm["lanes_kernel_ms"]
-    roofline = {"bound": "valu", "kernel": "isocon::k_nn_scan_refill<8, 1, false> (64-row table kernel of the main pass, one step)",
+    roofline = {"bound": "valu", "kernel": "isocon::k_nn_scan_refill<4, 1, false> (64-row table kernel of the main pass, one step; 4 waves per table)",
                 "achieved": achieved, "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instr/s",
                 "frac": achieved / VALU_PEAK_WAVE_INSTR if achieved else None, "traffic": traffic,
                 "kernel_ms": k_ms, "valu_insts_per_wave_column": ipc, "wave_columns_this_run": wave_cols, "valu_insts_this_run": insts,
@@ -510,13 +510,13 @@ def main():
                 # Not every vector instruction issues in 2 cycles: measured on this part (scripts/ubench/valu_issue.hip, profiles/r03h_ubench_valu_issue.txt)
                 # v_and / v_add_u32 / v_lshrrev_b32 / v_bitop3_b32 issue at the full rate, every other instruction of the band step
                 # (v_bfe, v_mad_u32_u24, v_alignbit, v_lshl_add_u64, v_lshrrev_b64) at 1.72x that cost.  The unrolled column of the table kernel
-                # is 14 full-rate + 5 half-rate instructions (ISA of k_nn_scan_refill<8, 1>): frac above counts instructions, this one issue slots.
+                # is 14 full-rate + 5 half-rate instructions (ISA of k_nn_scan_refill<4 | 8, 1>): frac above counts instructions, this one issue slots.
                 "issue_slots": {"half_rate_share_of_column": HALF_RATE_SHARE, "half_rate_cost": HALF_RATE_COST,
                                 "frac": (achieved / VALU_PEAK_WAVE_INSTR) * (1.0 + HALF_RATE_SHARE * (HALF_RATE_COST - 1.0)) if achieved else None,
                                 "stream_rate_of_nominal_peak": STREAM_RATE_OF_NOMINAL,
                                 "frac_of_stream_rate": (achieved / VALU_PEAK_WAVE_INSTR) * (1.0 + HALF_RATE_SHARE * (HALF_RATE_COST - 1.0)) / STREAM_RATE_OF_NOMINAL if achieved else None},
                 "step_kernels_ms": {"bounds (profiles + k_qgram_mm)": pm["bound_kernel_ms"], "seeds (k_ed_lanes)": pm["seed_kernel_ms"],
-                                    "survivor lists (k_nn_survivors)": pm["list_kernel_ms"], "tables, 64-row class (k_nn_scan_refill<8, 1, false>)": k_ms,
+                                    "survivor lists (k_nn_survivors)": pm["list_kernel_ms"], "tables, 64-row class (k_nn_scan_refill<4, 1, false>)": k_ms,
                                     "tables, 32-row class (k_nn_scan_refill<8, 1, true>)": pm["narrow_kernel_ms"],
                                     "pair per lane (k_ed_lanes)": pm["lanes_kernel_ms"], "all kernels": pm["kernel_ms"]},
                 "bound_pass": bound_pass, "narrow_pass": narrow_pass,

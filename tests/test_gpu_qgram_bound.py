@@ -123,7 +123,7 @@ def test_graph_with_the_filter_is_the_graph_without_it_and_the_filter_is_used():
         # ... the survivor lists switched off (the kernel's own admission), every pair through a table / one pair per lane, and lists
         # that do not fit (fallback to the kernel's own admission)
         for env in ("nn_old_seed", "nn_waves=8", "nn_order=0", "nn_order=1", "nn_no_list", "nn_list_min=1", "nn_list_min=1000000", "nn_list_cap=1000",
-                    "nn_list_waves=4", "nn_host_finalize", "nn_narrow=1", "nn_narrow=0", "nn_narrow=1,nn_list_waves=4", "nn_narrow=0,nn_list_waves=4",
+                    "nn_list_waves=4", "nn_list_waves=8", "nn_host_finalize", "nn_narrow=1", "nn_narrow=0", "nn_narrow=1,nn_list_waves=4", "nn_narrow=0,nn_list_waves=4",
                     "nn_seed_classes=1", "nn_seed_classes=2"):
             os.environ["ISOCON_DEBUG_VARIANT"] = env          # (the one switch behind which the A/B variants sit: DESIGN.md section 8)
             try:
