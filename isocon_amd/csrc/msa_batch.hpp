@@ -126,24 +126,46 @@ __global__ __launch_bounds__(256) void k_msab_patch(uint8_t *__restrict__ M_all,
     for (uint32_t k = b + (uint32_t)lane; k < e; k += 64u) dst[k - b] = bytes[k];
 }
 
-// column statistics: workgroup b handles the 256 columns cb_col0[b] .. of partition cb_part[b] (host-built table of column blocks)
-__global__ __launch_bounds__(256) void k_msab_col_stats(const uint8_t *__restrict__ M_all, MsaBatch B, const uint32_t *__restrict__ cb_part, const uint32_t *__restrict__ cb_col0,
-                                                         const int32_t *__restrict__ degree, int32_t *__restrict__ counts_all, uint8_t *__restrict__ maj_all,
-                                                         uint8_t *__restrict__ flags_all, unsigned long long *__restrict__ class_tot_all)
+// Column statistics in two launches (round 5; one thread per column walking ALL rows of its partition -- 11 000 at C3 -- took 6.2 ms with 110
+// workgroups on the chip):
+//   k_msab_col_counts  workgroup b = the 256 columns cbr[3b + 1] .. of partition cbr[3b], rows cbr[3b + 2] .. + MSAB_ROWS_PER_WG (host-built table):
+//                      per-column symbol counts of that row chunk, weighted by the rows' degrees, added to counts (zeroed by the host)
+//   k_msab_col_finish  workgroup b = the 256 columns cb_col0[b] .. of partition cb_part[b]: majority, tie flag, the partition's error-class totals
+static constexpr uint32_t MSAB_ROWS_PER_WG = 256;
+
+__global__ __launch_bounds__(256) void k_msab_col_counts(const uint8_t *__restrict__ M_all, MsaBatch B, const uint32_t *__restrict__ cbr, const int32_t *__restrict__ degree,
+                                                          int32_t *__restrict__ counts_all)
+{
+    const uint32_t p = cbr[3 * blockIdx.x], col = cbr[3 * blockIdx.x + 1] + threadIdx.x, row0 = cbr[3 * blockIdx.x + 2];
+    const uint32_t ncols = B.ncols[p], r0 = B.first_row[p], nr = B.first_row[p + 1] - r0;
+    if (col >= ncols) return;
+    const uint32_t row1 = row0 + MSAB_ROWS_PER_WG < nr ? row0 + MSAB_ROWS_PER_WG : nr;
+    const uint8_t *M = M_all + B.m_off[p];
+    int32_t c[5] = {0, 0, 0, 0, 0};
+#pragma unroll 8
+    for (uint32_t r = row0; r < row1; ++r) {
+        const int sidx = msa_sym(M[(size_t)r * ncols + col]);
+        const int32_t d = degree[r0 + r];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) c[k] += sidx == k ? d : 0;
+    }
+    int32_t *counts = counts_all + (size_t)5 * B.col_base[p];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) if (c[k]) atomicAdd(counts + (size_t)k * ncols + col, c[k]);
+}
+
+__global__ __launch_bounds__(256) void k_msab_col_finish(MsaBatch B, const uint32_t *__restrict__ cb_part, const uint32_t *__restrict__ cb_col0,
+                                                          const int32_t *__restrict__ counts_all, uint8_t *__restrict__ maj_all,
+                                                          uint8_t *__restrict__ flags_all, unsigned long long *__restrict__ class_tot_all)
 {
     const uint32_t p = cb_part[blockIdx.x], col = cb_col0[blockIdx.x] + threadIdx.x;
-    const uint32_t ncols = B.ncols[p], r0 = B.first_row[p], nr = B.first_row[p + 1] - r0;
-    const uint8_t *M = M_all + B.m_off[p];
-    int32_t *counts = counts_all + (size_t)5 * B.col_base[p];
+    const uint32_t ncols = B.ncols[p];
+    const int32_t *counts = counts_all + (size_t)5 * B.col_base[p];
     long long ci = 0, cd = 0, cs = 0;
     if (col < ncols) {
-        int32_t c[5] = {0, 0, 0, 0, 0};
-        for (uint32_t r = 0; r < nr; ++r) {
-            const int sidx = msa_sym(M[(size_t)r * ncols + col]);
-            const int32_t d = degree[r0 + r];
+        int32_t c[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) c[k] += sidx == k ? d : 0;
-        }
+        for (int k = 0; k < 5; ++k) c[k] = counts[(size_t)k * ncols + col];
         int best = 0, ties = 1;
 #pragma unroll
         for (int k = 1; k < 5; ++k) {
@@ -152,7 +174,7 @@ __global__ __launch_bounds__(256) void k_msab_col_stats(const uint8_t *__restric
         }
         int32_t tot = 0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { counts[(size_t)k * ncols + col] = c[k]; tot += c[k]; }
+        for (int k = 0; k < 5; ++k) tot += c[k];
         maj_all[B.col_base[p] + col] = (uint8_t)best;
         flags_all[B.col_base[p] + col] = ties == 1 ? 1 : 0;
         if (ties == 1) {

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
         if (narrow_class || merged) fill_n = 0;
         if (!narrow_class) fill = 0;
     };
-    constexpr int U = 8;                         // batches of 64 partners per iteration: their loads are independent
+#ifndef ISOCON_SURV_U
+#define ISOCON_SURV_U 8
+#endif
+    constexpr int U = ISOCON_SURV_U;             // batches of 64 partners per iteration: their loads are independent
     for (int side = 0; side < 2; ++side) {
         const uint32_t len = side == 0 ? up_len : dn_len;
         const uint8_t *row = side == 0 ? B.lb + up_off : B.lbT + dn_off;

@@ -292,7 +292,9 @@ class SeqStore(object):
         n_cols = np.zeros(n_parts, dtype=np.uint32)
         col_slot = np.zeros(int(slot_base[-1]), dtype=np.uint32)
         longest = np.zeros(int(slot_base[-1]), dtype=np.uint32)
-        cap = 1 << 17
+        # room for the wide-slot records: a too-small buffer means building everything again (two 3.7 ms fill launches per correction step at
+        # C3 with the old fixed 2^17); what the previous call of this store needed is the best guess for the next one
+        cap = max(1 << 17, 8 * len(row_ids), int(1.25 * getattr(self, "_msa_wide_seen", 0)) + 16)
         n_wide = ctypes.c_uint64(0)
         while True:
             wide = np.empty((cap, 8), dtype=np.uint32)
@@ -303,6 +305,7 @@ class SeqStore(object):
                 cap = int(n_wide.value) + 16
                 continue
             _lib.check(rc, "isocon_msa_build_ops_batch")
+            self._msa_wide_seen = int(n_wide.value)
             return n_cols, slot_base, col_slot, longest, wide[:int(n_wide.value)]
 
     def msa_correct_built_batch(self, n_parts, n_rows, degree, packed_cap, patch_row=None, patch_col=None, patch_ptr=None, patch_bytes=None):
