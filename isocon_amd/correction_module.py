@@ -120,35 +120,42 @@ def _wide_slot_patches(members, wide, col_slot, longest):
     inv = np.empty(len(order), dtype=np.int64)
     inv[order] = np.cumsum(new) - 1
     u_slot, u_len = slot[first], ln[first]
-    # the distinct insertion strings
-    strings = []
-    for i, f in enumerate(first.tolist()):
-        n_b = int(u_len[i])
-        if n_b > 32:
+    # the distinct insertion strings: the 2-bit codes of all of them decoded in one numpy pass, cut out of one str
+    n_u = len(first)
+    u_codes = codes[first]
+    chars = _CODE[((u_codes[:, None] >> (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :]) & np.uint64(3)).astype(np.intp)]
+    flat = chars.tobytes().decode()
+    first_l, u_len_l = first.tolist(), u_len.tolist()
+    strings = [flat[32 * i:32 * i + n_b] if n_b <= 32 else None for i, n_b in enumerate(u_len_l)]
+    for i, n_b in enumerate(u_len_l):
+        if n_b > 32:          # (rare: an insertion longer than the coded bases is read from the member itself)
+            f = first_l[i]
             r, sp = int(wide[f, 0]), int(wide[f, 2])
-            strings.append(members[r - 1][sp:sp + n_b])
-        else:
-            c = int(codes[f])
-            strings.append(_CODE[[(c >> (2 * j)) & 3 for j in range(n_b)]].tobytes().decode())
-    # per slot: the padded longest insertion (functions.py:722-731), then every distinct insertion inside it
-    by_slot = {}
-    for i, t in enumerate(u_slot.tolist()):
-        by_slot.setdefault(t, []).append(i)
+            strings[i] = members[r - 1][sp:sp + n_b]
+    # per slot: the padded longest insertion (functions.py:722-731), then every distinct insertion inside it.  `first` is ordered by slot, so
+    # a slot's distinct insertions are a run of it
     width = longest.astype(np.int64) + 2
     sol_len = width[u_slot]
-    sol_off = np.zeros(len(first) + 1, dtype=np.int64)
+    sol_off = np.zeros(n_u + 1, dtype=np.int64)
     np.cumsum(sol_len, out=sol_off[1:])
     sol_bytes = np.empty(int(sol_off[-1]), dtype=np.uint8)
-    for t, members_of_slot in by_slot.items():
-        lg = int(longest[t])
-        mx = "-" + min(strings[i] for i in members_of_slot if len(strings[i]) == lg) + "-"
-        for i in members_of_slot:
-            sol = _PLACEMENT_CACHE.get((mx, strings[i]))
+    cuts = [0] + (np.flatnonzero(np.diff(u_slot)) + 1).tolist() + [n_u]
+    sol_off_l = sol_off.tolist()
+    longest_l = longest.tolist()
+    u_slot_l = u_slot.tolist()
+    cache = _PLACEMENT_CACHE
+    for g in range(len(cuts) - 1):
+        lo, hi = cuts[g], cuts[g + 1]
+        lg = longest_l[u_slot_l[lo]]
+        mx = "-" + min(strings[i] for i in range(lo, hi) if u_len_l[i] == lg) + "-"
+        for i in range(lo, hi):
+            key = (mx, strings[i])
+            sol = cache.get(key)
             if sol is None:
-                if len(_PLACEMENT_CACHE) > 200000:
-                    _PLACEMENT_CACHE.clear()
-                sol = _PLACEMENT_CACHE[(mx, strings[i])] = np.frombuffer("".join(get_best_solution(mx, strings[i])).encode(), dtype=np.uint8)
-            sol_bytes[int(sol_off[i]):int(sol_off[i + 1])] = sol
+                if len(cache) > 200000:
+                    cache.clear()
+                sol = cache[key] = np.frombuffer("".join(get_best_solution(mx, strings[i])).encode(), dtype=np.uint8)
+            sol_bytes[sol_off_l[i]:sol_off_l[i + 1]] = sol
     # one patch per record: the bytes of its distinct insertion's placement, at its slot's first column
     p_len = sol_len[inv]
     p_ptr = np.zeros(len(wide) + 1, dtype=np.int64)
@@ -220,12 +227,16 @@ def _correct_all_from_ops(batch, partition_alignments, centres, seq_to_acc):
     row with more correctable positions than the batched kernel keeps: those go through the single-partition path)."""
     st = batch.store
     first_row, idx_parts, keys, deg_parts = [0], [], [], []
+    members_all = getattr(batch, "_members", None)
+    if members_all is None:          # the member (second) sequence of every pair, once per batch
+        members_all = batch._members = [pr[1] for pr in batch.pairs]
+    member_of = members_all.__getitem__
     for m in centres:
         rows = batch.rows_of[m]
         idx_parts.append(np.asarray(rows, dtype=np.int64))
         first_row.append(first_row[-1] + 1 + len(rows))
         keys.append(m)
-        keys.extend(batch.pairs[p][1] for p in rows)
+        keys.extend(map(member_of, rows))
         d = np.ones(1 + len(rows), dtype=np.int32)
         d[0] = partition_alignments[m][m][3]
         deg_parts.append(d)
