@@ -717,7 +717,8 @@ def roofline_sw(leg, ctr):
     hbm = float(c["hbm_bytes"]) if c.get("hbm_bytes") else None
     insts = float(c["SQ_INSTS_VALU"]) if c.get("SQ_INSTS_VALU") else None
     alg = leg["algorithmic_bytes"]
-    return {"bound": "hbm", "kernel": "isocon::k_sg_band<true, true, 4 | 2> (%d partition pairs of the workload: the certified band's diagonals on the lanes, four per lane for bands of up to 256 diagonals, "
+    return {"bound": "hbm", "what_binds_it": "VALU issue (valu_frac); SURVEY 8(d) states HBM as the bound of the trace kernel, so frac is the HBM fraction",
+            "kernel": "isocon::k_sg_band<true, true, 4 | 2> (%d partition pairs of the workload: the certified band's diagonals on the lanes, four per lane for bands of up to 256 diagonals, "
                       "two for up to 128; 4-bit trace per cell; the two launches of the call, one per class)" % n,
             "pairs": n, "kernel_ms": fwd_ms, "call_kernel_ms": leg["kernel_ms"], "call_wall_ms": leg["wall_ms"],
             "kernels_ms": {k: leg["stats"][k] for k in ("forward_ms", "walk_ms", "compact_ms", "expand_ms")},
