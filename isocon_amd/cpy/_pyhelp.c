@@ -375,6 +375,11 @@ static PyObject *flatten_pairs(PyObject *self, PyObject *args)
         } else {
             if (have_values == 1) goto mixed;
             have_values = 0;
+            /* only containers whose iteration runs no Python code (it could change `matches` under PyDict_Next); anything else: the caller's loop */
+            if (!PyAnySet_CheckExact(inner) && !PyList_CheckExact(inner) && !PyTuple_CheckExact(inner)) {
+                PyErr_SetString(PyExc_TypeError, "flatten_pairs: inner values must be dict, set, frozenset, list or tuple");
+                goto fail;
+            }
             PyObject *it = PyObject_GetIter(inner);
             if (!it) goto fail;
             PyObject *k2;

@@ -186,6 +186,8 @@ def check_flatten_pairs(H):
         H.flatten_pairs({"x": {"p": 1}, "y": {"q"}})
     with pytest.raises(TypeError):
         H.flatten_pairs({"x": 5})
+    with pytest.raises(TypeError):          # a generator: its iteration runs Python code
+        H.flatten_pairs({"x": (c for c in "ab")})
     with pytest.raises(TypeError):
         H.flatten_pairs([("x", "p")])
 
