@@ -72,7 +72,7 @@ def _report(name, world, res, group, single_kernel_ms):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [8, 2])
+@pytest.mark.parametrize("world", [8, 4, 2])
 def test_c3_in_block_cyclic_shards_equals_the_reference_loop_fixture(world):
     import bench
     from isocon_amd.dist import shard_of
@@ -81,6 +81,7 @@ def test_c3_in_block_cyclic_shards_equals_the_reference_loop_fixture(world):
     n = len(seqs)
     assert shard_of(world - 1, world, n) == ((world - 1) * 256, n, world * 256, 256)          # blocks of one bound-tile row, dealt round-robin
     st = SeqStore(seqs)
+    st.nn_graph()                                   # (warm-up: scratch pool, first-launch costs)
     single = st.nn_graph()
     st.close()
     assert bench.graph_digest(*single[:3]) == bench.EXPECTED_GRAPH_DIGEST_C3
