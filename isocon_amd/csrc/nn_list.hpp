@@ -30,6 +30,10 @@ static constexpr uint32_t NN_LIST_MIN = 256;       // owners with fewer pairs (a
 #endif
 static constexpr uint32_t NN_LIST_CHUNK = ISOCON_NN_LIST_CHUNK;    // a wave hands over a chunk as soon as it has staged this many pairs of its entry
 static constexpr int NN_STAGE = NN_LIST_CHUNK + 64;
+#ifndef ISOCON_SURV_WAVES            // waves (= entries) per workgroup of the list builder.  One: 8.4 KB of LDS per workgroup, so residency is bound by
+#define ISOCON_SURV_WAVES 1          // registers (24 waves per CU) instead of LDS (16 with four): 1.06 -> 0.98 ms at C3 (profiles/r05t_chunk_sweep.txt)
+#endif
+static constexpr int NN_SURV_WAVES = ISOCON_SURV_WAVES;
 
 // counters of the list builder, each on a cache line of its own (they are hot: tens of thousands of atomics per launch)
 struct NNPlanTotals {
@@ -81,16 +85,16 @@ __global__ __launch_bounds__(256) void k_nn_entry_meta(DevStore S, NNParams P, c
 // surviving pair is kept by exactly one of its two ends.  Kept pairs are staged in LDS; NN_LIST_CHUNK staged pairs become a chunk
 // of `list` (one k_nn_scan_refill workgroup with x's table), what is left at the end becomes a last chunk if it has NN_LIST_MIN
 // pairs, else flat pairs for the one-pair-per-lane kernel.
-__global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint32_t *__restrict__ meta, QMap Q, uint32_t nq,
+__global__ __launch_bounds__(64 * NN_SURV_WAVES) void k_nn_survivors(DevStore S, NNParams P, NNBoundRows B, const uint32_t *__restrict__ meta, QMap Q, uint32_t nq,
                                                        uint32_t *__restrict__ list, unsigned long long list_cap, NNChunk *__restrict__ chunks, unsigned long long chunks_cap,
                                                        uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min,
                                                        int32_t class_mode)
 {
-    __shared__ uint32_t stage[4][NN_STAGE];
-    __shared__ uint32_t s_small[4], s_filtered[4], s_kept[4];
+    __shared__ uint32_t stage[NN_SURV_WAVES][NN_STAGE];
+    __shared__ uint32_t s_small[NN_SURV_WAVES], s_filtered[NN_SURV_WAVES], s_kept[NN_SURV_WAVES];
     __shared__ unsigned long long s_base;
     const int wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t x = blockIdx.x * (uint32_t)NN_SURV_WAVES + (uint32_t)wave;
     const int lane = threadIdx.x & 63;
     const uint32_t mx = x < S.n ? meta[x] : 0u;
     const bool x_isq = (mx & (1u << 22)) != 0, x_ist = (mx & (1u << 21)) != 0;
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(256) void k_nn_survivors(DevStore S, NNParams P, NN
     if (lane == 0) { s_small[wave] = rest; s_filtered[wave] = filtered; s_kept[wave] = kept; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t tot = s_small[0] + s_small[1] + s_small[2] + s_small[3];
-        const uint32_t fsum = s_filtered[0] + s_filtered[1] + s_filtered[2] + s_filtered[3], ksum = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+        uint32_t tot = 0, fsum = 0, ksum = 0;
+        for (int w = 0; w < NN_SURV_WAVES; ++w) { tot += s_small[w]; fsum += s_filtered[w]; ksum += s_kept[w]; }
         unsigned long long base = 0;
         if (tot) {
             base = atomicAdd(&totals->n_small, (unsigned long long)tot);
