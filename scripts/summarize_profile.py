@@ -50,6 +50,8 @@ def classify(rows):
     for x, r in enumerate(rows):
         if "k_sg_band" in r[1] and r[2] == 4096 * 64:
             sg_banded = [r]
+            if x + 1 < len(rows) and "k_sg_band" in rows[x + 1][1] and rows[x + 1][2] == 4096 * 64:          # the other band class of the same call
+                sg_banded.append(rows[x + 1])
             if x and "k_sg_forward" in rows[x - 1][1] and rows[x - 1][2] == 4096 * 64 and rows[x - 1] not in sg_full:
                 sg_banded.insert(0, rows[x - 1])
             break
