@@ -85,32 +85,57 @@ __global__ __launch_bounds__(256) void k_msab_fill(DevStore S, MsaBatch B, const
         for (uint32_t t = (uint32_t)lane; t < Lm; t += 64u) row[col_slot[t] + width[t]] = msa_base_char(S, id, t);
         return;
     }
+    // The row's ops, 64 at a time: every lane loads one (coalesced), a wave scan gives each op its slot and member position, and the ops are then
+    // taken one by one from the lanes' registers -- no chain of dependent global loads (op k + 1 could not be requested before op k had arrived).
     uint32_t t = 0, sp = 0;
-    for (unsigned long long k = ops_ptr[r]; k < ops_ptr[r + 1]; ++k) {
-        const uint32_t op = ops[k], len = op >> 4, code = op & 15u;
-        if (t + (code == 3u ? 0u : len) > Lm) return;
-        if (code == 3u) {
-            if (longest[t] <= 1u) { if (lane == 0) row[col_slot[t]] = msa_base_char(S, id, sp); }
-            else if (lane == 0) {
-                const unsigned long long at = atomicAdd(wide_count, 1ull);
-                if (at < wide_cap) {
+    const unsigned long long k_end = ops_ptr[r + 1];
+    for (unsigned long long kb = ops_ptr[r]; kb < k_end; kb += 64ull) {
+        const uint32_t n_here = (uint32_t)(k_end - kb < 64ull ? k_end - kb : 64ull);
+        const uint32_t op_l = (uint32_t)lane < n_here ? ops[kb + (unsigned long long)lane] : 0u;
+        const uint32_t len_l = op_l >> 4, code_l = op_l & 15u;
+        uint32_t it = code_l == 3u ? 0u : len_l, is = code_l == 2u ? 0u : len_l;          // inclusive scans of the advances in slot / member position
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ot = (uint32_t)__shfl_up((int)it, d, 64), os = (uint32_t)__shfl_up((int)is, d, 64);
+            if (lane >= d) { it += ot; is += os; }
+        }
+        const uint32_t t_l = t + it - (code_l == 3u ? 0u : len_l), sp_l = sp + is - (code_l == 2u ? 0u : len_l);
+        // Insertions at wide slots are only LISTED (their place inside the padded longest insertion is decided on the host): every lane files
+        // its own op's record, ONE atomic per batch reserves the records (one atomic per record -- 6 10^5 on one address at C3 -- was what the
+        // kernel's 3.7 ms were: same-address atomics serialise in L2).
+        {
+            const bool wide_l = (uint32_t)lane < n_here && code_l == 3u && t_l <= Lm && longest[t_l] > 1u;
+            const unsigned long long wm = __ballot(wide_l);
+            if (wm != 0ull) {
+                unsigned long long at0 = 0;
+                if (lane == 0) at0 = atomicAdd(wide_count, (unsigned long long)__popcll(wm));
+                at0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(at0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)at0);
+                const unsigned long long at = at0 + (unsigned long long)__popcll(wm & (((unsigned long long)1 << lane) - 1ull));
+                if (wide_l && at < wide_cap) {
                     unsigned long long codes = 0;
-                    for (uint32_t j = 0; j < len && j < 32u; ++j) {
-                        const size_t w = ((size_t)((sp + j) >> 6) * S.n + id) * 2;
-                        const uint32_t sh = (sp + j) & 63u;
-                        codes |= (((S.planes[w] >> sh) & 1ull) | (((S.planes[w + 1] >> sh) & 1ull) << 1)) << (2u * j);
+                    for (uint32_t jj = 0; jj < len_l && jj < 32u; ++jj) {
+                        const size_t w = ((size_t)((sp_l + jj) >> 6) * S.n + id) * 2;
+                        const uint32_t sh = (sp_l + jj) & 63u;
+                        codes |= (((S.planes[w] >> sh) & 1ull) | (((S.planes[w + 1] >> sh) & 1ull) << 1)) << (2u * jj);
                     }
                     uint32_t *e = wide + 8 * at;
-                    e[0] = r; e[1] = t; e[2] = sp; e[3] = len; e[4] = (uint32_t)codes; e[5] = (uint32_t)(codes >> 32); e[6] = p; e[7] = 0u;
+                    e[0] = r; e[1] = t_l; e[2] = sp_l; e[3] = len_l; e[4] = (uint32_t)codes; e[5] = (uint32_t)(codes >> 32); e[6] = p; e[7] = 0u;
                 }
             }
-            sp += len;
-        } else {
-            for (uint32_t i = (uint32_t)lane; i < len; i += 64u)
-                row[col_slot[t + i] + width[t + i]] = code == 2u ? (uint8_t)'-' : msa_base_char(S, id, sp + i);
-            t += len;
-            if (code != 2u) sp += len;
         }
+        for (uint32_t j = 0; j < n_here; ++j) {
+            const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)op_l, (int)j), len = op >> 4, code = op & 15u;
+            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)t_l, (int)j), spj = (uint32_t)__builtin_amdgcn_readlane((int)sp_l, (int)j);
+            if (tj + (code == 3u ? 0u : len) > Lm) return;
+            if (code == 3u) {
+                if (longest[tj] <= 1u && lane == 0) row[col_slot[tj]] = msa_base_char(S, id, spj);          // (wide slots: listed above)
+            } else {
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64u)
+                    row[col_slot[tj + i] + width[tj + i]] = code == 2u ? (uint8_t)'-' : msa_base_char(S, id, spj + i);
+            }
+        }
+        t += (uint32_t)__shfl((int)it, 63, 64);
+        sp += (uint32_t)__shfl((int)is, 63, 64);
     }
 }
 
@@ -193,14 +218,19 @@ __global__ __launch_bounds__(256) void k_msab_col_finish(MsaBatch B, const uint3
     }
 }
 
-// one wave per row (the list of correctable positions in LDS; a row with more than MSA_MAX_CAND gets n_cand = -1: the host corrects that
+// Candidate positions per row the batched kernel keeps in LDS.  With the single-partition kernel's 2 048 a workgroup of four rows took 96 KB:
+// ONE workgroup per CU, one wave per SIMD, 4.2 ms for the 50 000 rows of C3 (25-60 candidates each).  1 024: 48 KB, three workgroups per CU;
+// a row with more (reads of > 8 kb at ONT error rates) sends its partition through the single-partition entry points, as before.
+static constexpr int MSAB_MAX_CAND = 1024;
+
+// one wave per row (the list of correctable positions in LDS; a row with more than MSAB_MAX_CAND gets n_cand = -1: the host corrects that
 // row's partition through the single-partition entry points)
 __global__ __launch_bounds__(256) void k_msab_row_correct(const uint8_t *__restrict__ M_all, uint8_t *__restrict__ out_all, MsaBatch B, const int32_t *__restrict__ degree,
                                                            const int32_t *__restrict__ counts_all, const uint8_t *__restrict__ maj_all, const uint8_t *__restrict__ flags_all,
                                                            const unsigned long long *__restrict__ class_tot_all, int32_t *__restrict__ n_cand)
 {
-    __shared__ double s_freq[4][MSA_MAX_CAND];
-    __shared__ uint32_t s_col[4][MSA_MAX_CAND];
+    __shared__ double s_freq[4][MSAB_MAX_CAND];
+    __shared__ uint32_t s_col[4][MSAB_MAX_CAND];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r = blockIdx.x * 4 + wave;
     if (r >= B.n_rows) return;
@@ -232,14 +262,14 @@ __global__ __launch_bounds__(256) void k_msab_row_correct(const uint8_t *__restr
         const unsigned long long mask = __ballot(cand);
         if (mask) {
             const uint32_t at = n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            if (cand && at < (uint32_t)MSA_MAX_CAND) {
+            if (cand && at < (uint32_t)MSAB_MAX_CAND) {
                 const int mj = maj[col];
                 const double own = (double)counts[(size_t)msa_sym(v) * ncols + col];
                 fq[at] = own / (mj == 4 ? d_ins : (v == '-' ? d_del : d_sub));
                 cl[at] = col;
             }
             n += (uint32_t)__popcll(mask);
-            if (n > (uint32_t)MSA_MAX_CAND) overflow = true;
+            if (n > (uint32_t)MSAB_MAX_CAND) overflow = true;
         }
     }
     if (overflow) { if (lane == 0) n_cand[r] = -1; return; }
