@@ -362,7 +362,16 @@ ISO_HD void band_step(BandLane<W> &L, const uint64_t (&NL)[W], const uint64_t (&
     uint64_t EQ[W];
 #pragma unroll
     for (int i = 0; i < W; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (NL ^ sl) & (NH ^ sh) per 32-bit half as xor + one 3-input boolean a & (b ^ c) (table 0x60): 2 instead of 3 instructions
+        const uint32_t tl = (uint32_t)NL[i] ^ slo, th = (uint32_t)(NL[i] >> 32) ^ slo;
+        const uint32_t el = __builtin_amdgcn_bitop3_b32(tl, (uint32_t)NH[i], shi, 0x60);
+        const uint32_t eh = __builtin_amdgcn_bitop3_b32(th, (uint32_t)(NH[i] >> 32), shi, 0x60);
+        EQ[i] = ((uint64_t)eh << 32) | el;
+        (void)sl; (void)sh;
+#else
         EQ[i] = (NL[i] ^ sl) & (NH[i] ^ sh);
+#endif
         if (MASKED) EQ[i] &= VM[i];
     }
     band_step_eq<W>(L, EQ);

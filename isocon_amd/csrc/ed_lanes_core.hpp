@@ -72,15 +72,27 @@ ISO_HD int32_t lane_pair_distance(XL x_lo, XH x_hi, YL y_lo, YH y_hi, int32_t m,
         const bool full = c0 + 32 <= n;
         if (o >= 0 && !any(run && !full)) {
             // no virtual rows in any window of the block, 32 columns for every running lane
+            // (the top-row bit of every column is shifted into zreg and counted once per block, as in the table kernel: band_step_eq64z)
+            uint32_t zreg = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
             for (int jj = 0; jj < 32; ++jj) {
-                uint64_t NL[1], NH[1], VM[1] = {0};
-                NL[0] = ((uint64_t)funnel32(L2, L1, jj) << 32) | funnel32(L1, L0, jj);
-                NH[0] = ((uint64_t)funnel32(H2, H1, jj) << 32) | funnel32(H1, H0, jj);
-                band_step<1, false>(L, NL, NH, VM, splat_bit(wl, jj), splat_bit(wh, jj));
+                const uint32_t sl = splat_bit(wl, jj), sh = splat_bit(wh, jj);
+                const uint32_t nl0 = funnel32(L1, L0, jj), nl1 = funnel32(L2, L1, jj), nh0 = funnel32(H1, H0, jj), nh1 = funnel32(H2, H1, jj);
+#if defined(__HIP_DEVICE_COMPILE__)
+                const uint32_t e0 = __builtin_amdgcn_bitop3_b32(nl0 ^ sl, nh0, sh, 0x60);          // (nl ^ sl) & (nh ^ sh)
+                const uint32_t e1 = __builtin_amdgcn_bitop3_b32(nl1 ^ sl, nh1, sh, 0x60);
+#else
+                const uint32_t e0 = (nl0 ^ sl) & (nh0 ^ sh), e1 = (nl1 ^ sl) & (nh1 ^ sh);
+#endif
+                band_step_eq64z(L.VP[0], L.VN[0], zreg, ((uint64_t)e1 << 32) | e0);
             }
+#if defined(__HIP_DEVICE_COMPILE__)
+            L.ztop += (uint32_t)__popc(zreg);
+#else
+            L.ztop += (uint32_t)__builtin_popcount(zreg);
+#endif
         } else {
             const uint32_t V0 = lane_valid32(o, m), V1 = lane_valid32(o + 32, m), V2 = lane_valid32(o + 64, m);
 #if defined(__HIP_DEVICE_COMPILE__)
