@@ -719,10 +719,12 @@ def roofline_sw(leg, ctr):
     alg = leg["algorithmic_bytes"]
     return {"bound": "hbm", "what_binds_it": "VALU issue (valu_frac); SURVEY 8(d) states HBM as the bound of the trace kernel, so frac is the HBM fraction",
             "kernel": "isocon::k_sg_band<true, true, 4 | 2> (%d partition pairs of the workload: the certified band's diagonals on the lanes, four per lane for bands of up to 256 diagonals, "
-                      "two for up to 128; 4-bit trace per cell; the two launches of the call, one per class)" % n,
+                      "two for up to 128 -- and for wider bounds whose middle 128 diagonals certify themselves; 4-bit trace per cell; the launches of the call, one per class "
+                      "and one for the pairs that run again)" % n,
             "pairs": n, "kernel_ms": fwd_ms, "call_kernel_ms": leg["kernel_ms"], "call_wall_ms": leg["wall_ms"],
             "kernels_ms": {k: leg["stats"][k] for k in ("forward_ms", "walk_ms", "compact_ms", "expand_ms")},
             "pairs_band": int(leg["stats"]["pairs_band"]), "pairs_band_two_diagonals_per_lane": int(leg["stats"].get("pairs_band_narrow", 0)),
+            "pairs_tried_on_128_diagonals_first": int(leg["stats"].get("pairs_tried_narrow", 0)), "pairs_run_again_on_256": int(leg["stats"].get("pairs_retried_wider", 0)),
             "pairs_strips": int(leg["stats"]["pairs_strips"]), "pairs_redone_in_full": int(leg["stats"]["pairs_redone"]),
             "achieved": hbm / (fwd_ms / 1e3) / 1e9 if hbm and fwd_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": hbm / (fwd_ms / 1e3) / 1e9 / HBM_PEAK_GBS if hbm and fwd_ms > 0 else None, "traffic": hbm,
@@ -807,9 +809,12 @@ def wrappers(accs, seqs_all, pair_ed_out=None, sw_leg=None):
         aD = np.abs(la - lb)
         Qp = np.maximum(-mm.astype(np.int64), 2)
         X = np.maximum(((2 + Qp) * ed.astype(np.int64) + 1) // 2 - aD + 1, 1)
-        narrow = (aD + 2 * X + 1) <= 128
+        diags = aD + 2 * X + 1
+        # (a bound of 129 .. 256 diagonals runs on 128 first when that keeps >= 85 % of X; the few that do not certify themselves run again on 256)
+        tried = (diags > 128) & (diags <= 256) & ((127 - aD) // 2 >= 1) & (((127 - aD) // 2) * 100 >= 85 * X)
+        narrow = (diags <= 128) | tried
         sw_leg.update(pairs=len(a), kernel_ms=float(ms), wall_ms=wall * 1e3, stats=sg_last_stats(), cells_full=float((la * lb).sum()),
-                      cells_band=float(((la + lb) * np.where(narrow, 64, 128)).sum()), algorithmic_bytes=float((la + lb + 2 * aln_len + 12).sum()),
+                      cells_band=float(((la + lb) * np.where(narrow, 64, 128)).sum()), tried_model=int(tried.sum()), algorithmic_bytes=float((la + lb + 2 * aln_len + 12).sum()),
                       same_as_wrappers=bool((res == batch.res).all() and len(ops) == len(batch.ops) and (ops == batch.ops).all()))
     return {"compute_nearest_neighbor_graph_wall_ms": t_nn * 1e3, "compute_nearest_neighbor_graph_kernel_ms": kern, "nn_edges": n_edges,
             "partition_centres": len(partition), "partition_pairs": n_pairs,

@@ -235,10 +235,12 @@ int isocon_sg_strings_batch(isocon_store *s, const uint32_t *a, const uint32_t *
 /*
  * Where the kernel time of this thread's most recent isocon_sg_trace_batch / isocon_sg_strings_batch call went (HIP events on the
  * kernels' stream; a measurement aid for bench.py's `roofline_sw`, the reference has no counterpart: parasail's time is one number per
- * call, modules/SW_alignment_module.py:66-69).  out[0 .. min(cap, 9)): forward kernels (k_sg_band + k_sg_forward) ms, walk kernels ms,
+ * call, modules/SW_alignment_module.py:66-69).  out[0 .. min(cap, 11)): forward kernels (k_sg_band + k_sg_forward) ms, walk kernels ms,
  * compaction ms, string expansion ms, pairs aligned with the band's diagonals on the lanes, pairs aligned in strips, pairs whose
  * banded result could not be certified and was redone in full, bytes of trace scratch the forward kernels wrote, pairs of the fifth
- * value whose band fits 128 diagonals (two per lane instead of four).  Returns the number of values written.
+ * value that ran on 128 diagonals (two per lane instead of four), those of them whose bound asks for more than 128 diagonals (run
+ * narrower first: the certificate decides), and those of these that failed it and ran again in the band of their bound.  Returns the
+ * number of values written.
  */
 int isocon_sg_last_stats(double *out, int32_t cap);
 

@@ -45,7 +45,8 @@ struct SgPair {            // per pair of the batch
     int32_t dhi;
     int32_t steps;         // steps per pass (window columns + 63), the same for every pass of the pair
     int32_t mode;          // 0: strips of 512 query rows (k_sg_forward); 1 / 2: the band's diagonals on the lanes, 4 / 2 per lane (k_sg_band<.., 4 / 2>)
-    int32_t pad_;
+    int32_t retry_x;       // > 0: the pair runs in a band NARROWER than its bound asks for (a cheaper class), and this is the half-width X the
+                           // bound asks for: k_sg_band runs the pair again in that band if the narrow result does not certify itself
 };
 
 static constexpr int SG_BAND_DIAGS = 256;      // k_sg_band<.., 4>: 64 lanes x 4 diagonals
@@ -298,18 +299,16 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
 // Match bits: per slot a 64-cell mask ~(q ^ t) of its diagonal, refilled every 128 steps (per-lane unaligned plane fetches).
 // Trace: the two nibbles of a step form a byte, four steps a dword: ((a >> 2) * 64 + lane) * 4 bytes -- one 256-B line per
 // four steps, (m + n) * 64 bytes per pair instead of ~ m * (512 + band) / 2.
-template <bool POL0, bool EXT0, int DPL = 4>
-__global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__restrict__ pairs, SgParams prm,
-                                                   uint8_t *__restrict__ trace, int32_t *__restrict__ endinfo)
+// (the body of k_sg_band: one pair, the band [dlo, dlo + 64 DPL); returns the score of the end cell, wave-uniform)
+template <bool POL0, bool EXT0, int DPL>
+__device__ __forceinline__ int32_t sg_band_run(const DevStore &S, const SgPair &pr, const int32_t dlo, const SgParams &prm, uint8_t *__restrict__ trace,
+                                               int32_t *__restrict__ endinfo, const uint32_t pidx)
 {
-    const uint32_t pidx = blockIdx.x;
     const int lane = threadIdx.x;
-    const SgPair pr = pairs[pidx];
     static_assert(DPL == 4 || DPL == 2, "diagonals per lane: 4 (bands of up to 256 diagonals) or 2 (up to 128: half the cells and half the trace)");
     constexpr int DIAGS = 64 * DPL;                 // diagonals of the band
     constexpr int SPW = 32 / (2 * DPL);             // steps per trace dword: DPL / 2 nibbles per step
     constexpr int SPW_LOG = DPL == 4 ? 2 : 3;
-    if (uniform_i32(pr.mode) != (DPL == 4 ? 1 : 2)) return;
     const uint32_t ia = (uint32_t)uniform_i32((int32_t)pr.a), ib = (uint32_t)uniform_i32((int32_t)pr.b);
     const int32_t m = uniform_i32(S.lens[ia]), n = uniform_i32(S.lens[ib]);
     const int32_t match = prm.match, mism = uniform_i32(pr.mismatch), open = prm.open, ext = prm.ext;
@@ -327,7 +326,6 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
     const uint32_t nseq = S.n;
     const int32_t nchunks = (int32_t)S.nchunks;
     uint32_t *tw_base = reinterpret_cast<uint32_t *>(trace + pr.trace_off);
-    const int32_t dlo = uniform_i32(pr.dlo);
     const int32_t d0 = dlo + DPL * lane;
     int32_t H[DPL], E[DPL], F[DPL];
     uint32_t Mlo[DPL], Mhi[DPL], Mcur[DPL];
@@ -385,11 +383,15 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
         tw = __builtin_amdgcn_alignbit(tw, t_x, 31);
     };
 
-    // One step = one anti-diagonal.  PAR = 0: slots 0 and 2, PAR = 1: slots 1 and 3 -- compile-time, and the loop below runs an
+    // One step = one anti-diagonal.  PAR = 0: slots 0 and 2, PAR = 1: slots 1 and 3 -- compile-time, and the loops below run an
     // even and an odd step per iteration, so that no register shuffling is left at the control-flow joins (a loop over
     // single steps with a run-time parity cost ~25 v_mov per step).
-    auto step = [&](int32_t a, auto par_tag) {
-        constexpr int PAR = decltype(par_tag)::value;
+    // INTERIOR (compile-time): every lane's cells of the step are plain matrix cells off the last row / column -- the loop over
+    // those steps (all but ~ DIAGS at either end of a pair) holds no range checks, no second code path to join with (the join cost
+    // 6 v_mov per step), and its DPP shifts take their own previous result as the value of the lane without a neighbour (-inf,
+    // set once before the loop), so that no register has to be re-initialised before each of them.
+    int32_t hl_keep = SG_NEG, el_keep = SG_NEG, hu_keep = SG_NEG, fu_keep = SG_NEG;
+    auto refill = [&](int32_t a) {
         if ((a & 127) == 0) {
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
@@ -405,19 +407,30 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
             }
         }
         if ((a & 63) == 0) {
+            asm volatile("");                      // keep this a (wave-uniform) branch: as selects it costs 2 DPL/2 v_cndmask on every step
 #pragma unroll
             for (int s = 0; s < DPL; ++s) Mcur[s] = (a & 64) ? Mhi[s] : Mlo[s];
         }
+    };
+    auto step = [&](int32_t a, auto par_tag, auto interior_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+        refill(a);
         const int32_t kbit = (a & 63) >> 1;
         uint32_t f0, e0, g0, x0, f1 = 0, e1 = 0, g1 = 0, x1 = 0;
-        const bool interior = a >= in_from && a <= in_to;      // wave-uniform: both cells of every lane are plain matrix cells
         if (PAR == 0) {
-            const int32_t edge = (interior || a + dlo != 0) ? SG_NEG : 0;      // left of the band: -inf, or the boundary column of cell (i, 0)
-            const int32_t Hl = __builtin_amdgcn_update_dpp(edge, H[DPL - 1], 0x138, 0xf, 0xf, false);      // wave_shr:1: lane l takes lane l - 1
-            const int32_t El = __builtin_amdgcn_update_dpp(SG_NEG, E[DPL - 1], 0x138, 0xf, 0xf, false);
+            int32_t Hl, El;
+            if constexpr (INTERIOR) {
+                Hl = hl_keep = __builtin_amdgcn_update_dpp(hl_keep, H[DPL - 1], 0x138, 0xf, 0xf, false);      // wave_shr:1: lane l takes lane l - 1
+                El = el_keep = __builtin_amdgcn_update_dpp(el_keep, E[DPL - 1], 0x138, 0xf, 0xf, false);
+            } else {
+                const int32_t edge = a + dlo != 0 ? SG_NEG : 0;      // left of the band: -inf, or the boundary column of cell (i, 0)
+                Hl = __builtin_amdgcn_update_dpp(edge, H[DPL - 1], 0x138, 0xf, 0xf, false);
+                El = __builtin_amdgcn_update_dpp(SG_NEG, E[DPL - 1], 0x138, 0xf, 0xf, false);
+            }
             if constexpr (DPL == 4) {
                 const int32_t h1 = H[1], e1s = E[1], f1s = F[1], h3 = H[3], f3 = F[3];
-                if (interior) {
+                if constexpr (INTERIOR) {
                     core(H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
                     core(H[2], E[2], F[2], h3, f3, h1, e1s, Mcur[2], kbit, f1, e1, g1, x1);
                 } else {
@@ -426,16 +439,22 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
                 }
             } else {          // two diagonals per lane: slot 0 (up = the lane's slot 1, left = lane - 1's slot 1)
                 const int32_t h1 = H[1], f1s = F[1];
-                if (interior) core(H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
+                if constexpr (INTERIOR) core(H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
                 else cell(a, d0, H[0], E[0], F[0], h1, f1s, Hl, El, Mcur[0], kbit, f0, e0, g0, x0);
             }
         } else {
-            const int32_t edge = (interior || a - dlo - (DIAGS - 1) != 0) ? SG_NEG : 0;   // above the band: -inf, or the boundary row of cell (0, j)
-            const int32_t Hu = __builtin_amdgcn_update_dpp(edge, H[0], 0x130, 0xf, 0xf, false);      // wave_shl:1: lane l takes lane l + 1
-            const int32_t Fu = __builtin_amdgcn_update_dpp(SG_NEG, F[0], 0x130, 0xf, 0xf, false);
+            int32_t Hu, Fu;
+            if constexpr (INTERIOR) {
+                Hu = hu_keep = __builtin_amdgcn_update_dpp(hu_keep, H[0], 0x130, 0xf, 0xf, false);      // wave_shl:1: lane l takes lane l + 1
+                Fu = fu_keep = __builtin_amdgcn_update_dpp(fu_keep, F[0], 0x130, 0xf, 0xf, false);
+            } else {
+                const int32_t edge = a - dlo - (DIAGS - 1) != 0 ? SG_NEG : 0;   // above the band: -inf, or the boundary row of cell (0, j)
+                Hu = __builtin_amdgcn_update_dpp(edge, H[0], 0x130, 0xf, 0xf, false);
+                Fu = __builtin_amdgcn_update_dpp(SG_NEG, F[0], 0x130, 0xf, 0xf, false);
+            }
             if constexpr (DPL == 4) {
                 const int32_t h0 = H[0], e0s = E[0], h2 = H[2], e2s = E[2], f2s = F[2];
-                if (interior) {
+                if constexpr (INTERIOR) {
                     core(H[1], E[1], F[1], h2, f2s, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
                     core(H[3], E[3], F[3], Hu, Fu, h2, e2s, Mcur[3], kbit, f1, e1, g1, x1);
                 } else {
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
                 }
             } else {          // slot 1 (up = lane + 1's slot 0, left = the lane's slot 0)
                 const int32_t h0 = H[0], e0s = E[0];
-                if (interior) core(H[1], E[1], F[1], Hu, Fu, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
+                if constexpr (INTERIOR) core(H[1], E[1], F[1], Hu, Fu, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
                 else cell(a, d0 + 1, H[1], E[1], F[1], Hu, Fu, h0, e0s, Mcur[1], kbit, f0, e0, g0, x0);
             }
         }
@@ -456,10 +475,22 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
     // byte is shifted out of the trace word before the first store), and the pair's last half may lie beyond a_end
     const int32_t a_start = -(dlo & 1);
     int32_t a = a_start;
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
 #pragma unroll 1
-    for (; a <= a_end; a += 2) {
-        step(a, std::integral_constant<int, 0>());
-        step(a + 1, std::integral_constant<int, 1>());
+    for (; a <= a_end && a < in_from; a += 2) {            // the band enters the matrix
+        step(a, T0(), std::false_type());
+        step(a + 1, T1(), std::false_type());
+    }
+#pragma unroll 1
+    for (const int32_t in_end = in_to < a_end ? in_to : a_end; a + 1 <= in_end; a += 2) {
+        step(a, T0(), std::true_type());
+        step(a + 1, T1(), std::true_type());
+    }
+#pragma unroll 1
+    for (; a <= a_end; a += 2) {                           // the band leaves it
+        step(a, T0(), std::false_type());
+        step(a + 1, T1(), std::false_type());
     }
     const int32_t a_done = a - 1;                 // last step taken (a_end or a_end + 1)
     if (((a_done + 1) & (SPW - 1)) != 0) tw_base[(size_t)(a_done >> SPW_LOG) * 64 + lane] = tw << (2 * DPL * (SPW - ((a_done + 1) & (SPW - 1))));
@@ -480,9 +511,10 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
             if (pl > cl) cl = pl;
         }
     }
+    int32_t score = 0;
     if (lane == 0) {
         const bool last = (policy & SG_POL_LAST_MAX) != 0, col_first = (policy & SG_POL_COL_FIRST) != 0;
-        int32_t score, eq, er;
+        int32_t eq, er;
         const int32_t rj = last ? rl : rf, ci = last ? cl : cf;
         if (!col_first) {
             score = rb; eq = m - 1; er = rj;
@@ -494,6 +526,40 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, const SgPair *__r
         endinfo[(size_t)pidx * 4 + 0] = score;
         endinfo[(size_t)pidx * 4 + 1] = eq;
         endinfo[(size_t)pidx * 4 + 2] = er;
+    }
+    return __builtin_amdgcn_readfirstlane(score);
+}
+
+// One wave per pair of the kernel's class (SgPair::mode).  A pair with retry_x > 0 runs in a band NARROWER than its bound asks for
+// (sg_host.inc: the 128 diagonals around its corridor, where the bound asks for up to 256): the result stands if it certifies itself --
+// score > match * (min(m, n) - X - 1) for the half-width X that was run, so nothing outside that band can score as much -- otherwise
+// the same wave runs the pair again in the band of its bound (four diagonals per lane; the trace region was sized for that), the
+// pair's record says so for the walk kernel, and *n_again counts it.
+template <bool POL0, bool EXT0, int DPL = 4>
+__global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, SgPair *__restrict__ pairs, SgParams prm,
+                                                   uint8_t *__restrict__ trace, int32_t *__restrict__ endinfo, uint32_t *__restrict__ n_again)
+{
+    const uint32_t pidx = blockIdx.x;
+    const SgPair pr = pairs[pidx];
+    if (uniform_i32(pr.mode) != (DPL == 4 ? 1 : 2)) return;
+    const int32_t dlo = uniform_i32(pr.dlo);
+    const int32_t score = sg_band_run<POL0, EXT0, DPL>(S, pr, dlo, prm, trace, endinfo, pidx);
+    if constexpr (DPL == 2) {
+        const int32_t xs = uniform_i32(pr.retry_x);
+        if (xs > 0) {
+            const int32_t m = uniform_i32(S.lens[pr.a]), n = uniform_i32(S.lens[pr.b]), D = n - m, mn = m < n ? m : n;
+            const int32_t corridor_lo = D < 0 ? D : 0, corridor_hi = D > 0 ? D : 0;
+            const int32_t x_run = corridor_lo - dlo;
+            if (!((long long)score > (long long)prm.match * (mn - x_run - 1))) {
+                sg_band_run<POL0, EXT0, 4>(S, pr, corridor_lo - xs, prm, trace, endinfo, pidx);
+                if (threadIdx.x == 0) {
+                    pairs[pidx].dlo = corridor_lo - xs;
+                    pairs[pidx].dhi = corridor_hi + xs;
+                    pairs[pidx].mode = 1;
+                    atomicAdd(n_again, 1u);
+                }
+            }
+        }
     }
 }
 

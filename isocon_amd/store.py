@@ -365,9 +365,10 @@ class SeqStore(object):
 
 def sg_last_stats():
     """where the kernel time of this thread's most recent alignment batch went (isocon_sg_last_stats, include/isocon_hip.h)"""
-    out = (ctypes.c_double * 9)()
-    _lib.load().isocon_sg_last_stats(out, 9)
-    keys = ("forward_ms", "walk_ms", "compact_ms", "expand_ms", "pairs_band", "pairs_strips", "pairs_redone", "trace_bytes", "pairs_band_narrow")
+    out = (ctypes.c_double * 11)()
+    _lib.load().isocon_sg_last_stats(out, 11)
+    keys = ("forward_ms", "walk_ms", "compact_ms", "expand_ms", "pairs_band", "pairs_strips", "pairs_redone", "trace_bytes", "pairs_band_narrow",
+            "pairs_tried_narrow", "pairs_retried_wider")
     return dict(zip(keys, list(out)))
 
 

@@ -50,8 +50,11 @@ def classify(rows):
     for x, r in enumerate(rows):
         if "k_sg_band" in r[1] and r[2] == 4096 * 64:
             sg_banded = [r]
-            if x + 1 < len(rows) and "k_sg_band" in rows[x + 1][1] and rows[x + 1][2] == 4096 * 64:          # the other band class of the same call
-                sg_banded.append(rows[x + 1])
+            for y in range(x + 1, len(rows)):          # the other band class of the same call, the launch for the pairs that run again
+                if "k_sg_band" in rows[y][1] and rows[y][2] == 4096 * 64:
+                    sg_banded.append(rows[y])
+                elif "k_sg_recheck" not in rows[y][1] and "fillBuffer" not in rows[y][1]:
+                    break
             if x and "k_sg_forward" in rows[x - 1][1] and rows[x - 1][2] == 4096 * 64 and rows[x - 1] not in sg_full:
                 sg_banded.insert(0, rows[x - 1])
             break
@@ -93,12 +96,18 @@ def classify(rows):
     bands = [r for r in rows if "k_sg_band" in r[1]]
     if bands and max(r[2] for r in bands) > 4096 * 64:
         # the call launches one k_sg_band per band class (<.., 4>: up to 256 diagonals, <.., 2>: up to 128) over the same grid: the last
-        # dispatch of each
-        widest = [r for r in bands if r[2] == max(x[2] for x in bands)]
-        last = {}
-        for r in widest:
-            last[r[1]] = r
-        cls["sg_partition"] = sorted(last.values(), key=lambda r: r[0])
+        # dispatch of each class, plus the launch for the pairs that run again (narrow tries that did not certify themselves): the trailing
+        # run of such launches, (a fill kernel for the counter between them)
+        wide_grid = max(x[2] for x in bands)
+        picked = []
+        for r in reversed(rows):
+            if "k_sg_band" in r[1] and r[2] == wide_grid:
+                picked.append(r)
+            elif picked and ("k_sg_recheck" in r[1] or "fillBuffer" in r[1]):
+                continue
+            elif picked:
+                break
+        cls["sg_partition"] = picked[::-1]
     if len(calls) >= 3:
         cls["hw_k25"], cls["hw_k63"] = calls[1], calls[2]
     if len(calls) >= 5:

@@ -259,3 +259,58 @@ def test_two_band_classes_give_the_same_alignments(monkeypatch):
         assert (r1 == r2).all() and (p1 == p2).all() and (o1 == o2).all(), (policy, open_, ext)
         assert (r1 == r3).all() and (p1 == p3).all() and (o1 == o3).all(), (policy, open_, ext)
     st.close()
+
+
+def test_narrow_tries_certify_themselves_or_run_again(monkeypatch):
+    """A pair whose bound asks for 129 .. 256 diagonals runs on 128 first when that keeps >= 85 % of the half-width (two diagonals per lane
+    cost half of four); k_sg_recheck evaluates the certificate for the band that was run and sends the failures through the band of their
+    bound within the same batch.  Pairs at ~1.2-1.5 % errors with three error mixes -- insertions / deletions only (the narrow band certifies),
+    substitutions only (the bound is tight: every try fails) and the CCS mix -- under the default threshold, under a threshold that tries
+    every such pair (ISOCON_DEBUG_VARIANT=sw_narrow_try_pct=1), without tries, and without hints (full matrix): identical ops, results and
+    gapped strings; the counters show tries that passed and tries that ran again."""
+    from isocon_amd import synth
+    from isocon_amd.store import SeqStore, sg_last_stats
+    rng = np.random.Generator(np.random.PCG64(23))
+    seqs, a, b = [], [], []
+    mixes = (dict(ins=0.5, dele=0.5, sub=0.0), dict(ins=0.0, dele=0.0, sub=1.0), dict(ins=0.6875, dele=0.25, sub=0.0625))
+    for it in range(90):
+        L = int(rng.integers(2000, 2800))
+        base = synth._rand_seq(rng, L)
+        rate = [0.006, 0.007, 0.0075][it % 3]          # per read; the pair sees twice that
+        mix = mixes[(it // 3) % 3]
+        x = synth.mutate(rng, base, dict(mix, rate=rate))
+        y = synth.mutate(rng, base, dict(mix, rate=rate))
+        if it % 6 == 0:
+            y = y[int(rng.integers(0, 12)):len(y) - int(rng.integers(0, 12))]
+        seqs += [x.tobytes().decode(), y.tobytes().decode()]
+        a.append(2 * it + (it & 1)); b.append(2 * it + 1 - (it & 1))
+    st = SeqStore(seqs)
+    ed = st.ed_pairs(a, b, None)
+    mm = np.array([[-2, -1, -4][i % 3] for i in range(len(a))], dtype=np.int8)
+    seen_pass = seen_again = 0
+    for policy, open_, ext in ((0, 2, 0), (12, 2, 0), (21, 2, 0), (0, 3, 1)):
+        monkeypatch.delenv("ISOCON_DEBUG_VARIANT", raising=False)
+        o0, p0, r0 = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy)          # no hints: the full matrix
+        runs = {}
+        for name, var in (("default", None), ("all", "sw_narrow_try_pct=1"), ("none", "sw_no_narrow_try")):
+            if var is None:
+                monkeypatch.delenv("ISOCON_DEBUG_VARIANT", raising=False)
+            else:
+                monkeypatch.setenv("ISOCON_DEBUG_VARIANT", var)
+            o, p, r = st.sg_trace(a, b, mm, open_=open_, ext=ext, tie_policy=policy, ed_upper=ed)
+            runs[name] = sg_last_stats()
+            assert runs[name]["pairs_redone"] == 0, (name, runs[name])
+            assert (r == r0).all() and (p == p0).all() and (o == o0).all(), (name, policy, open_, ext)
+            sa, sb, sp, sr = st.sg_strings(a, b, mm, open_=open_, ext=ext, tie_policy=policy, ed_upper=ed)[:4]
+            monkeypatch.delenv("ISOCON_DEBUG_VARIANT", raising=False)
+            ra, rb, rp, rr = st.sg_strings(a, b, mm, open_=open_, ext=ext, tie_policy=policy)[:4]
+            assert (sr == rr).all() and (sp == rp).all() and bytes(sa) == bytes(ra) and bytes(sb) == bytes(rb), (name, policy)
+        assert runs["none"]["pairs_tried_narrow"] == 0 and runs["none"]["pairs_retried_wider"] == 0
+        assert runs["all"]["pairs_tried_narrow"] >= runs["default"]["pairs_tried_narrow"] > 0, runs
+        assert runs["all"]["pairs_retried_wider"] > 0, runs          # the substitution-only pairs
+        assert runs["all"]["pairs_retried_wider"] < runs["all"]["pairs_tried_narrow"], runs          # the indel-only pairs
+        assert runs["default"]["pairs_band_narrow"] > runs["none"]["pairs_band_narrow"], runs
+        seen_pass += runs["default"]["pairs_tried_narrow"] - runs["default"]["pairs_retried_wider"]
+        seen_again += runs["all"]["pairs_retried_wider"]
+    assert seen_pass > 0 and seen_again > 0
+    st.close()
