@@ -50,6 +50,7 @@ struct SgPair {            // per pair of the batch
 };
 
 static constexpr int SG_BAND_DIAGS = 256;      // k_sg_band<.., 4>: 64 lanes x 4 diagonals
+static constexpr int SG_TILE_DWORDS = 16, SG_TILE_LOG = 4;      // k_sg_band's trace: tiles of 16 dwords per lane (one 64-byte line)
 static constexpr int SG_BAND_DIAGS_NARROW = 128;      // k_sg_band<.., 2>: 64 lanes x 2 diagonals (half the cells per step, half the trace)
 
 // Column window of one pass (64*R query rows starting at prow0) for the band [dlo, dhi]: every cell of the band lies
@@ -297,12 +298,15 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
 // slot that has not reached the matrix yet holds H = 0, E = F = -inf, which IS the free boundary row / column its
 // neighbours read; beyond the two outermost diagonals lies -inf (0 where that cell is the boundary row / column).
 // Match bits: per slot a 64-cell mask ~(q ^ t) of its diagonal, refilled every 128 steps (per-lane unaligned plane fetches).
-// Trace: the two nibbles of a step form a byte, four steps a dword: ((a >> 2) * 64 + lane) * 4 bytes -- one 256-B line per
-// four steps, (m + n) * 64 bytes per pair instead of ~ m * (512 + band) / 2.
+// Trace: the two nibbles of a step form a byte, four steps a dword (two diagonals per lane: one nibble per step, eight steps a dword):
+// (m + n) * 64 bytes per pair instead of ~ m * (512 + band) / 2.  Dword q = a >> 2 (>> 3) of lane l lies at ((q >> 4) * 64 + l) * 16 + (q & 15):
+// tiles of 16 dwords per lane, so that the 64 (128) steps a path spends on a lane's diagonals are ONE 64-byte line for the walk
+// (step-major -- dword q of all lanes in one 256-byte line -- the walk fetched a line per dword: 4-5 GB at C3, the whole of its time).
+// The wave stages a tile in LDS (dword q of all lanes: one conflict-free ds_write) and writes it out as 64 bytes per lane.
 // (the body of k_sg_band: one pair, the band [dlo, dlo + 64 DPL); returns the score of the end cell, wave-uniform)
 template <bool POL0, bool EXT0, int DPL>
 __device__ __forceinline__ int32_t sg_band_run(const DevStore &S, const SgPair &pr, const int32_t dlo, const SgParams &prm, uint8_t *__restrict__ trace,
-                                               int32_t *__restrict__ endinfo, const uint32_t pidx)
+                                               int32_t *__restrict__ endinfo, const uint32_t pidx, uint32_t *__restrict__ stage)
 {
     const int lane = threadIdx.x;
     static_assert(DPL == 4 || DPL == 2, "diagonals per lane: 4 (bands of up to 256 diagonals) or 2 (up to 128: half the cells and half the trace)");
@@ -326,6 +330,17 @@ __device__ __forceinline__ int32_t sg_band_run(const DevStore &S, const SgPair &
     const uint32_t nseq = S.n;
     const int32_t nchunks = (int32_t)S.nchunks;
     uint32_t *tw_base = reinterpret_cast<uint32_t *>(trace + pr.trace_off);
+    // trace dword q of the lane: into the staged tile; the tile leaves when its 16th dword is in (and at the end of the pair)
+    auto flush_tile = [&](int32_t tile) {
+        uint4 *dst = reinterpret_cast<uint4 *>(tw_base + ((size_t)tile * 64 + lane) * SG_TILE_DWORDS);
+#pragma unroll
+        for (int c = 0; c < SG_TILE_DWORDS / 4; ++c)
+            dst[c] = make_uint4(stage[(4 * c) * 64 + lane], stage[(4 * c + 1) * 64 + lane], stage[(4 * c + 2) * 64 + lane], stage[(4 * c + 3) * 64 + lane]);
+    };
+    auto put_dword = [&](int32_t q, uint32_t w) {
+        stage[(q & (SG_TILE_DWORDS - 1)) * 64 + lane] = w;
+        if ((q & (SG_TILE_DWORDS - 1)) == SG_TILE_DWORDS - 1) flush_tile(q >> SG_TILE_LOG);
+    };
     const int32_t d0 = dlo + DPL * lane;
     int32_t H[DPL], E[DPL], F[DPL];
     uint32_t Mlo[DPL], Mhi[DPL], Mcur[DPL];
@@ -469,7 +484,7 @@ __device__ __forceinline__ int32_t sg_band_run(const DevStore &S, const SgPair &
         }
         push(f0, e0, g0, x0);
         if constexpr (DPL == 4) push(f1, e1, g1, x1);
-        if ((a & (SPW - 1)) == SPW - 1 && a >= 0) tw_base[(size_t)(a >> SPW_LOG) * 64 + lane] = tw;
+        if ((a & (SPW - 1)) == SPW - 1 && a >= 0) put_dword(a >> SPW_LOG, tw);
     };
     // the first step of a pair is the "even" kind: start one anti-diagonal early if dlo is odd (no cell lives there; its
     // byte is shifted out of the trace word before the first store), and the pair's last half may lie beyond a_end
@@ -493,7 +508,12 @@ __device__ __forceinline__ int32_t sg_band_run(const DevStore &S, const SgPair &
         step(a + 1, T1(), std::false_type());
     }
     const int32_t a_done = a - 1;                 // last step taken (a_end or a_end + 1)
-    if (((a_done + 1) & (SPW - 1)) != 0) tw_base[(size_t)(a_done >> SPW_LOG) * 64 + lane] = tw << (2 * DPL * (SPW - ((a_done + 1) & (SPW - 1))));
+    {
+        const int32_t q_done = a_done >> SPW_LOG;
+        const bool partial = ((a_done + 1) & (SPW - 1)) != 0;          // the last dword is not full: not stored yet
+        if (partial) stage[(q_done & (SG_TILE_DWORDS - 1)) * 64 + lane] = tw << (2 * DPL * (SPW - ((a_done + 1) & (SPW - 1))));
+        if (partial || (q_done & (SG_TILE_DWORDS - 1)) != SG_TILE_DWORDS - 1) flush_tile(q_done >> SG_TILE_LOG);          // (else it left with its 16th dword)
+    }
     // reduce the candidates over lanes: maximum; smallest (first) / largest (last) column resp. row on ties
     int32_t rb = rowbest, rf = rowj_first, rl = rowj_last, cb = colbest, cf = coli_first, cl = coli_last;
 #pragma unroll
@@ -539,11 +559,12 @@ template <bool POL0, bool EXT0, int DPL = 4>
 __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, SgPair *__restrict__ pairs, SgParams prm,
                                                    uint8_t *__restrict__ trace, int32_t *__restrict__ endinfo, uint32_t *__restrict__ n_again)
 {
+    __shared__ uint32_t stage[SG_TILE_DWORDS * 64];
     const uint32_t pidx = blockIdx.x;
     const SgPair pr = pairs[pidx];
     if (uniform_i32(pr.mode) != (DPL == 4 ? 1 : 2)) return;
     const int32_t dlo = uniform_i32(pr.dlo);
-    const int32_t score = sg_band_run<POL0, EXT0, DPL>(S, pr, dlo, prm, trace, endinfo, pidx);
+    const int32_t score = sg_band_run<POL0, EXT0, DPL>(S, pr, dlo, prm, trace, endinfo, pidx, stage);
     if constexpr (DPL == 2) {
         const int32_t xs = uniform_i32(pr.retry_x);
         if (xs > 0) {
@@ -551,7 +572,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_band(DevStore S, SgPair *__restric
             const int32_t corridor_lo = D < 0 ? D : 0, corridor_hi = D > 0 ? D : 0;
             const int32_t x_run = corridor_lo - dlo;
             if (!((long long)score > (long long)prm.match * (mn - x_run - 1))) {
-                sg_band_run<POL0, EXT0, 4>(S, pr, corridor_lo - xs, prm, trace, endinfo, pidx);
+                sg_band_run<POL0, EXT0, 4>(S, pr, corridor_lo - xs, prm, trace, endinfo, pidx, stage);
                 if (threadIdx.x == 0) {
                     pairs[pidx].dlo = corridor_lo - xs;
                     pairs[pidx].dhi = corridor_hi + xs;
@@ -630,7 +651,7 @@ __global__ __launch_bounds__(64) void k_sg_walk(DevStore S, const SgPair *__rest
 
 // The same walk over k_sg_band's trace (byte of step a = i + j in dword a / 4 of the lane that owns the diagonal): one thread
 // per pair, the state machine written with selects (64 pairs in 64 different states share the wave: every branch body is paid
-// by all of them), four dwords of the diagonal's lane column fetched at a time.
+// by all of them), two tiles (two 64-byte lines: 32 dwords) of the diagonal's lane fetched at a time.
 __global__ __launch_bounds__(64) void k_sg_walk_band(DevStore S, const SgPair *__restrict__ pairs, const uint8_t *__restrict__ trace,
                                                       const int32_t *__restrict__ endinfo, uint32_t *__restrict__ ops,
                                                       uint32_t *__restrict__ opcount, int32_t *__restrict__ res, uint32_t n_pairs)
@@ -663,29 +684,70 @@ __global__ __launch_bounds__(64) void k_sg_walk_band(DevStore S, const SgPair *_
     int32_t nmatch = 0, nmis = 0;
     int64_t alen = (int64_t)(n - 1 - er) + (m - 1 - eq);
     bool left_window = false;
-    // Trace cache: 32 dwords (128 anti-diagonals = 64 diagonal steps) of the diagonal's lane column per thread, in LDS -- the walk
-    // moves towards smaller a on (mostly) the same four diagonals; with one thread per pair nothing hides a dependent HBM /
-    // Infinity-Cache load, so they are taken 32 at a time (unconditional addresses, one wait) and then read back from LDS
-    // (row stride 33: the 64 threads of the wave spread over the banks whatever their positions are).
-    __shared__ uint32_t s_cache[64][33];
+    // Trace cache, in LDS: two tiles (32 dwords: 256 / 128 anti-diagonals) of the diagonal's lane AND of the lanes either side of it, per
+    // thread.  With one thread per pair nothing hides a dependent HBM / Infinity-Cache load, and a load that ONE of the wave's 64 pairs
+    // waits for is waited for by all of them (each pair ran out of its own two tiles, or changed lane at an indel, every ~3rd iteration
+    // of the wave: 2.1 of the walk's 2.8 ms at C3).  So refills are collective: when any pair of the wave needs one, every pair takes
+    // the six lines around its current position (unconditional addresses, one wait) -- a wave then waits once per >= 64 iterations, an
+    // indel that moves a path to the next lane finds that lane's tiles in place.  Row stride 97: the threads spread over the banks.
+    __shared__ uint32_t s_cache[64][97];
     uint32_t *my = s_cache[threadIdx.x];
-    int32_t c_lane = -1, c_top = -(1 << 30);
+    int32_t c_lane = -(1 << 20), c_top = -(1 << 30);
+    uint32_t word = 0;                       // the dword in hand: dword w_q of lane w_lc
+    int32_t w_q = -1, w_lc = -1;
     const int32_t dlo = pr.dlo;
     while (i >= 0 && j >= 0) {
         const int32_t sl = (j - i) - dlo;
         if ((uint32_t)sl >= (uint32_t)DIAGS) { left_window = true; break; }
         const int32_t a = i + j, q = a >> SPW_LOG, lc = sl >> DPL_LOG;
-        if (lc != c_lane || q > c_top || q < c_top - 31) {
-            const uint32_t *col = tb + lc;
-            c_lane = lc; c_top = q;
-            uint32_t w[32];
+        const bool need = lc < c_lane - 1 || lc > c_lane + 1 || q > c_top || q < c_top - 31;
+        if (__ballot(need) != 0) {
+            const int32_t tile = q >> SG_TILE_LOG, below = tile > 0 ? tile - 1 : 0;
+            c_lane = lc; c_top = tile * SG_TILE_DWORDS + SG_TILE_DWORDS - 1;
+            uint4 w[3][8];
 #pragma unroll
-            for (int x = 0; x < 32; ++x) { const int32_t qq = q - x > 0 ? q - x : 0; w[x] = col[(size_t)qq * 64]; }
+            for (int side = 0; side < 3; ++side) {
+                int32_t ln = lc - 1 + side;
+                ln = ln < 0 ? 0 : (ln > 63 ? 63 : ln);
+                const uint4 *hi = reinterpret_cast<const uint4 *>(tb + ((size_t)tile * 64 + ln) * SG_TILE_DWORDS);
+                const uint4 *lo = reinterpret_cast<const uint4 *>(tb + ((size_t)below * 64 + ln) * SG_TILE_DWORDS);
 #pragma unroll
-            for (int x = 0; x < 32; ++x) my[x] = w[x];
+                for (int x = 0; x < 4; ++x) { w[side][x] = hi[x]; w[side][4 + x] = lo[x]; }
+            }
+#pragma unroll
+            for (int side = 0; side < 3; ++side) {
+                uint32_t *row = my + 32 * side;          // row[c_top - q']: the top dword first
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    row[15 - 4 * x] = w[side][x].x; row[14 - 4 * x] = w[side][x].y; row[13 - 4 * x] = w[side][x].z; row[12 - 4 * x] = w[side][x].w;
+                    row[31 - 4 * x] = w[side][4 + x].x; row[30 - 4 * x] = w[side][4 + x].y; row[29 - 4 * x] = w[side][4 + x].z; row[28 - 4 * x] = w[side][4 + x].w;
+                }
+            }
+            w_q = -1;
         }
-        const uint32_t word = my[c_top - q];
-        const uint32_t tr = (word >> (four ? 8 * (3 - (a & 3)) + ((sl & 2) ? 0 : 4) : 4 * (7 - (a & 7)))) & 15u;
+        if (q != w_q || lc != w_lc) { word = my[32 * (lc - c_lane + 1) + (c_top - q)]; w_q = q; w_lc = lc; }
+        const uint32_t x = word >> (four ? 8 * (3 - (a & 3)) + ((sl & 2) ? 0 : 4) : 4 * (7 - (a & 7)));
+        // plain matches first: the cells of this diagonal that the dword in hand holds below the current one lie 8 (two diagonals per
+        // lane) or 16 bits apart; as many of them as continue the path diagonally over equal bases are taken in one iteration
+        uint32_t c = 0;
+        if (where == 0) {
+            const uint32_t y = x & (four ? 0x00030003u : 0x03030303u);
+            const uint32_t held = four ? (uint32_t)((a & 3) >> 1) + 1u : (uint32_t)((a & 7) >> 1) + 1u;
+            c = y ? (uint32_t)__builtin_ctz(y) >> (four ? 4 : 3) : held;
+            c = c < held ? c : held;
+            const uint32_t room = (uint32_t)(i < j ? i : j) + 1u;
+            c = c < room ? c : room;
+        }
+        if (c) {
+            if (run_code == 0u) run_len += c;
+            else {
+                if (run_len) region[--pos] = (run_len << 4) | run_code;
+                run_code = 0u; run_len = c;
+            }
+            i -= (int32_t)c; j -= (int32_t)c; nmatch += (int32_t)c; alen += c;
+            continue;
+        }
+        const uint32_t tr = x & 15u;
         const uint32_t gap = (tr >> 1) & 1u, xbit = tr & 1u, fopen = (tr >> 3) & 1u, eopen = (tr >> 2) & 1u;
         const bool w0 = where == 0, w1 = where == 1;
         const bool prod = w0 ? gap == 0 : true;                                   // this step emits one alignment column
