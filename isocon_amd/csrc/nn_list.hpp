@@ -140,7 +140,9 @@ __global__ __launch_bounds__(64 * NN_SURV_WAVES) void k_nn_survivors(DevStore S,
 #define ISOCON_SURV_U 8
 #endif
     constexpr int U = ISOCON_SURV_U;             // batches of 64 partners per iteration: their loads are independent
-    for (int side = 0; side < 2; ++side) {
+    // (the side is a compile-time constant of the loop body: own row = contiguous partners, transposed row = partners through the slot map)
+    auto scan_side = [&](auto side_tag) {
+        constexpr int side = decltype(side_tag)::value;
         const uint32_t len = side == 0 ? up_len : dn_len;
         const uint8_t *row = side == 0 ? B.lb + up_off : B.lbT + dn_off;
         for (uint32_t c0 = 0; c0 < len; c0 += 64 * U) {
@@ -202,7 +204,9 @@ __global__ __launch_bounds__(64 * NN_SURV_WAVES) void k_nn_survivors(DevStore S,
                 if (fill + fill_n >= NN_LIST_CHUNK) emit_chunk(fill_n > fill);          // the buffer is full: its larger class leaves (>= half a chunk)
             }
         }
-    }
+    };
+    scan_side(std::integral_constant<int, 0>());
+    scan_side(std::integral_constant<int, 1>());
     // the end of the entry's pairs: a class with enough pairs leaves as a chunk of its own; too few of the 32-row class join the 64-row
     // class (its kernel takes any threshold) before that class is judged
     if (fill_n >= list_min) emit_chunk(true);
