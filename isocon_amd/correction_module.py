@@ -289,19 +289,22 @@ def _correct_all_from_ops(batch, partition_alignments, centres, seq_to_acc):
     todo = np.flatnonzero((deg == 1) & (n_cand > 0) & ok_row)
     if len(todo):
         H = _lib.pyhelp()
-        if H is not None and hasattr(H, "split_ascii"):
-            strs = H.split_ascii(packed.ctypes.data, np.ascontiguousarray(off, dtype=np.int64).ctypes.data, n_rows)
+        rows_todo = todo.tolist()
+        if H is not None and hasattr(H, "split_ascii_rows"):
+            # the corrected rows only, equal ones as ONE str object (they converge on their consensus: every dict built over them
+            # afterwards hashes an object once and compares by identity first)
+            off64, sel = np.ascontiguousarray(off, dtype=np.int64), np.ascontiguousarray(todo, dtype=np.int64)
+            strs_todo = H.split_ascii_rows(packed.ctypes.data, off64.ctypes.data, sel.ctypes.data, len(sel))
         else:
             flat = packed[:off[n_rows]].tobytes().decode()
-            strs = [flat[off[r]:off[r + 1]] for r in range(n_rows)]
-        rows_todo = todo.tolist()
+            strs_todo = [flat[off[r]:off[r + 1]] for r in rows_todo]
         acc_lists = list(map(seq_to_acc.__getitem__, map(keys.__getitem__, rows_todo)))
         if all(map((1).__eq__, map(len, acc_lists))):          # a read that is still being corrected has multiplicity 1: one accession each
-            out.update(zip(map(next, map(iter, acc_lists)), map(strs.__getitem__, rows_todo)))
+            out.update(zip(map(next, map(iter, acc_lists)), strs_todo))
         else:
-            for r, accs_of_r in zip(rows_todo, acc_lists):
+            for s_r, accs_of_r in zip(strs_todo, acc_lists):
                 for acc in accs_of_r:
-                    out[acc] = strs[r]
+                    out[acc] = s_r
     return out, [centres[p] for p in redo]
 
 

@@ -70,6 +70,37 @@ def check_split_ascii(H):
         H.split_ascii(buf.ctypes.data, np.array([4, 2], dtype=np.int64).ctypes.data, 1)
 
 
+def check_split_ascii_rows(H):
+    """selected rows of a packed buffer, equal rows as ONE object (also across different lengths of a common prefix, empty rows, the
+    threaded hashing above 8 MB, rows given in any order and more than once)"""
+    rng = np.random.Generator(np.random.PCG64(6))
+    for n, mean, distinct in ((0, 0, 1), (1, 0, 1), (9, 30, 3), (5000, 100, 40), (3000, 3200, 25)):
+        pool = [np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(0, 2 * mean + 1)))] for _ in range(distinct)]
+        if distinct > 2:
+            pool[1] = pool[0][:len(pool[0]) // 2]          # a proper prefix of another row
+            pool[2] = pool[0][:0]                          # empty
+        pick = rng.integers(0, distinct, size=n)
+        lens = np.array([len(pool[c]) for c in pick], dtype=np.int64)
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=ptr[1:])
+        buf = np.concatenate([pool[c] for c in pick] + [np.zeros(1, dtype=np.uint8)]).astype(np.uint8)
+        rows = rng.permutation(n).astype(np.int64)
+        if n > 2:
+            rows = np.concatenate([rows, rows[:3]])
+        out = H.split_ascii_rows(buf.ctypes.data, ptr.ctypes.data, rows.ctypes.data, len(rows))
+        raw = buf.tobytes()
+        assert out == [raw[ptr[r]:ptr[r + 1]].decode() for r in rows.tolist()]
+        first = {}
+        for r, s_r in zip(rows.tolist(), out):
+            assert first.setdefault(s_r, s_r) is s_r, "equal rows are one object"
+        assert len(set(map(id, out))) == len(set(out))
+    buf = np.frombuffer(b"ACGT", dtype=np.uint8).copy()
+    with pytest.raises(ValueError):
+        H.split_ascii_rows(buf.ctypes.data, np.array([4, 2], dtype=np.int64).ctypes.data, np.zeros(1, dtype=np.int64).ctypes.data, 1)
+    with pytest.raises(ValueError):
+        H.split_ascii_rows(buf.ctypes.data, np.array([0, 2], dtype=np.int64).ctypes.data, np.array([-1], dtype=np.int64).ctypes.data, 1)
+
+
 def check_csr_to_dict(H):
     keys = ["k%d" % i for i in range(6)]
     best = np.array([3, -1, 2, 2, 7, -1], dtype=np.int32)
@@ -268,6 +299,10 @@ def test_split_ascii():
     check_split_ascii(_helper())
 
 
+def test_split_ascii_rows():
+    check_split_ascii_rows(_helper())
+
+
 def test_csr_to_dict():
     check_csr_to_dict(_helper())
 
@@ -300,7 +335,7 @@ def test_under_address_and_undefined_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
                ISOCON_PYHELP_UNDER_TEST=so)
     code = ("import sys; sys.path.insert(0, %r); import test_pyhelp as T; H = T._helper(); "
-            "T.check_group_keys_by_value(H); T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_csr_to_dict(H); T.check_pair_ids(H); "
+            "T.check_group_keys_by_value(H); T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_split_ascii_rows(H); T.check_csr_to_dict(H); T.check_pair_ids(H); "
             "T.check_unique_values_by_length(H); T.check_flatten_pairs(H); T.check_alignment_dict(H); T.check_lazy_rows(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
