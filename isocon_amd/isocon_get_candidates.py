@@ -200,6 +200,7 @@ def find_candidate_transcripts(read_file, params):
             return {acc: seq for (acc, seq) in fasta_parser.read_fasta(fh)}
 
     S = read_all()
+    original_reads = dict(S)          # (the reference reads the file a second time after the loop, :259-261: the same mapping -- S's values are replaced, never changed)
     logfile = getattr(params, "logfile", None)
     step = 1
     exon_filtered = set()
@@ -258,7 +259,6 @@ def find_candidate_transcripts(read_file, params):
                 del c_acc_to_support[removed_c_acc]
                 del c_seq_to_read_acc[removed_c_seq]
 
-    original_reads = read_all()
     assert len(S) == len(original_reads)
     for c_acc in list(c_acc_to_seq.keys()):
         if c_acc_to_support[c_acc] < params.min_candidate_support:
