@@ -4,12 +4,15 @@
 // (/root/reference/modules/SW_alignment_module.py:64-86); semantics restated in oracle/isocon_oracle.c
 // (orc_sg_trace): Gotoh recurrences, free end gaps on both sequences, a gap of length g costs open+(g-1)*ext.
 //
-// Forward kernel: one wavefront per pair, systolic over text columns.  Lane l owns query rows [l*R, (l+1)*R) and
+// Two forward kernels.  Pairs with a certified band of at most 256 diagonals (the read pairs of the pipeline: their edit distances come
+// down as hints) run in k_sg_band, the band's diagonals on the lanes -- see there; everything else in k_sg_forward:
+// one wavefront per pair, systolic over text columns.  Lane l owns query rows [l*R, (l+1)*R) and
 // works on column s-l at step s; the bottom-row (H, F) of a strip and the text base travel one lane down per step.
 // Each cell emits a 4-bit trace code; a lane's R codes of one column are stored as R/2 contiguous bytes at
 // ((s*64 + lane) * R/2) -- i.e. indexed by STEP, not by column, so that all 64 lanes of a step write one contiguous
 // 32*R-byte block (coalesced HBM writes; this kernel is HBM-write bound: ~ m*n/2 bytes per pair).
-// Walk kernel: one thread per pair follows the codes back from the end cell and emits run-length CIGAR ops.
+// Walk kernels (k_sg_walk for the strips, k_sg_walk_band for the band kernel's tiled trace): one thread per pair follows the codes back
+// from the end cell and emits run-length CIGAR ops.
 #pragma once
 #include <type_traits>
 #include "common.hpp"
