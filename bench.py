@@ -559,6 +559,11 @@ def main():
             result["wrappers"] = wrappers(accs, seqs_all, pair_ed, sw_leg)
         except Exception as e:
             result["wrappers"] = {"error": repr(e)}
+        if is_default:
+            try:
+                result["two_set_graph"] = two_set_leg()
+            except Exception as e:
+                result["two_set_graph"] = {"error": repr(e)}
         if sw_leg:
             result["roofline_sw"] = roofline_sw(sw_leg, ctr if is_default else {})
             if is_default:
@@ -589,6 +594,8 @@ def main():
     if is_default and result["config"]["graph_digest"] != EXPECTED_GRAPH_DIGEST_C3:
         raise SystemExit("bench.py: the graph of the default workload has digest %s, the reference-loop fixture %s: the result is WRONG, the line above is not a measurement"
                          % (result["config"]["graph_digest"], EXPECTED_GRAPH_DIGEST_C3))
+    if is_default and result.get("two_set_graph", {}).get("every_row_equals_reference_loop_fixture") is False:
+        raise SystemExit("bench.py: the 2-set graph of the default workload's reads against the g19 candidates differs from the reference-loop fixture: the two_set_graph leg is WRONG")
     if is_default and result["config"].get("alignments_equal_oracle_fixture") is False:
         raise SystemExit("bench.py: the alignments of the default workload's partition pairs have digest %s, the oracle fixture %s: the wrappers leg is WRONG"
                          % (result["config"]["sw_digest"], EXPECTED_SW_DIGEST_C3))
@@ -739,6 +746,50 @@ def roofline_sw(leg, ctr):
             "digest": leg["digest"],
             "note": "algorithmic bytes = SURVEY 8(d): len(q) + len(t) + 2 len(alignment) + 12 per pair; traffic = PMC 2 x FETCH_SIZE + WRITE_SIZE of the dispatch; "
                     "cell_updates_per_s counts len(q) x len(t) per pair over ALL kernels of the call, band_cells_per_s the 128 (four diagonals per lane) or 64 (two) cells per anti-diagonal the band kernels compute"}
+
+
+def two_set_leg():
+    """The search the metric is named after, at the size it is quoted on: compute_2set_nearest_neighbor_graph (NNG:201-234) of the workload's
+    50 000 reads against the seeded candidate set of tests/golden/g19 (1 030 candidates: the isoforms, variants a few edits away, 20 reads),
+    strings in, dict of dicts out -- EVERY read's row compared with the fixture the oracle's reference loop produced on the CPU
+    (tests/golden/make_golden_g19.py; `reference_loop_alignments` is that loop's own count of edlib calls, NNG:387/403)."""
+    import importlib.util
+    from isocon_amd import nearest_neighbor_graph as NNG
+    root = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden_g19", os.path.join(root, "tests", "golden", "make_golden_g19.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    X, C = mod.candidates("c3")
+    merged = mod.merged_list(X, C)
+    z = np.load(os.path.join(root, "tests", "golden", "g19_c3_graph_2set.npz"))
+    if str(z["inputs_sha1"]) != mod.inputs_sha1(merged):
+        return {"error": "tests/golden/g19_c3_graph_2set.npz belongs to another read / candidate set"}
+
+    class P(object):
+        nr_cores = 1
+        neighbor_search_depth = 2 ** 32
+        verbose = False
+
+    t0 = time.perf_counter(); graph = NNG.compute_2set_nearest_neighbor_graph(X, C, P()); t_first = time.perf_counter() - t0
+    del graph
+    t0 = time.perf_counter(); graph = NNG.compute_2set_nearest_neighbor_graph(X, C, P()); t = time.perf_counter() - t0
+    kern = float(NNG.LAST_STATS.get("kernel_ms", 0.0))
+    pos = {a: i for i, (_, a) in enumerate(merged)}
+    best, row_ptr, cols = z["best"], z["row_ptr"], z["cols"]
+    is_t = z["is_target"]
+    same = list(graph) == [a for (_, a), tflag in zip(merged, is_t.tolist()) if not tflag]
+    edges = 0
+    for a, nbrs in graph.items():
+        i = pos[a]
+        edges += len(nbrs)
+        if [pos[b] for b in nbrs] != cols[row_ptr[i]:row_ptr[i + 1]].tolist() or any(d != int(best[i]) for d in nbrs.values()):
+            same = False
+    calls = int(z["edlib_calls"])
+    return {"reads": len(X), "candidates": len(C), "edges": edges, "reference_loop_alignments": calls,
+            "wall_ms": t * 1e3, "first_call_wall_ms": t_first * 1e3, "kernel_ms": kern,
+            "alignments_per_s_wall": calls / t if t > 0 else None, "alignments_per_s_kernel": calls / (kern / 1e3) if kern > 0 else None,
+            "every_row_equals_reference_loop_fixture": bool(same and edges == len(cols)),
+            "note": "public function end to end (Python strings in, dict of dicts out); fixture tests/golden/g19_c3_graph_2set.npz"}
 
 
 def wrappers(accs, seqs_all, pair_ed_out=None, sw_leg=None):

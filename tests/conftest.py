@@ -62,6 +62,21 @@ def g17(which):
     return seqs, z["best"], z["row_ptr"], z["cols"]
 
 
+def g19(which):
+    """The 2-set whole-graph fixture of a BASELINE configuration (tests/golden/make_golden_g19.py: the reads against a seeded candidate set,
+    every read's row by the oracle's statement of the reference loop NNG:341-424 on the CPU): (X, C, merged [(seq, acc)], arrays dict)."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("make_golden_g19", os.path.join(ROOT, "tests", "golden", "make_golden_g19.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    X, C = mod.candidates(which)
+    merged = mod.merged_list(X, C)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g19_%s_graph_2set.npz" % which))
+    assert str(z["inputs_sha1"]) == mod.inputs_sha1(merged), "the fixture belongs to another read / candidate set"
+    return X, C, merged, {k: z[k] for k in z.files}
+
+
 def g18(which):
     """The alignment fixture of a BASELINE configuration (tests/golden/make_golden_g18.py: every pair aligned on the CPU by the oracle's
     statement of SWM:64-86, tie policy 0): the npz as a dict of arrays.  Ids index the configuration's entries (g17's order)."""

@@ -167,3 +167,42 @@ def test_c2_every_row_equals_the_reference_loop_fixture(c2):
     counts = np.bincount(rows, minlength=len(seqs)) if len(rows) else np.zeros(len(seqs), np.int64)
     assert (np.concatenate([[0], np.cumsum(counts)]) == frow_ptr).all()
     assert (cols == fcols).all()          # (rows come out in key order, neighbours in the reference's insertion order)
+
+
+def _check_2set_fixture(which):
+    """compute_2set_nearest_neighbor_graph (NNG:201-234) on a configuration's reads against the seeded candidate set of g19: EVERY read's
+    row -- candidates, their order, the distance -- equals the fixture the oracle's reference loop produced on the CPU; outer keys = the
+    reads in merged-sorted order; reads without an admissible candidate map to {}."""
+    from conftest import g19
+    from isocon_amd import nearest_neighbor_graph as NNG
+    X, C, merged, fx = g19(which)
+    graph = NNG.compute_2set_nearest_neighbor_graph(X, C, Params(1))
+    is_t, fbest, frp, fcols = fx["is_target"], fx["best"], fx["row_ptr"], fx["cols"]
+    accs = [a for _, a in merged]
+    assert list(graph) == [a for a, t in zip(accs, is_t.tolist()) if not t]
+    pos = {a: i for i, a in enumerate(accs)}
+    n_edges = 0
+    bad = []
+    for a, nbrs in graph.items():
+        i = pos[a]
+        exp_cols = fcols[frp[i]:frp[i + 1]].tolist()
+        got_cols = [pos[b] for b in nbrs]
+        ok = got_cols == exp_cols and all(d == int(fbest[i]) for d in nbrs.values()) and (len(nbrs) > 0 or int(fbest[i]) == -1)
+        if not ok:
+            bad.append(i)
+        n_edges += len(nbrs)
+    assert not bad, "%d rows differ from the reference loop, first %s" % (len(bad), bad[:5])
+    assert n_edges == len(fcols)
+    assert (fbest[is_t == 0] == 0).sum() >= 1          # (a read that IS a candidate: distance 0 is admitted, NNG:388)
+    return len(graph), n_edges
+
+
+def test_c2_2set_every_row_equals_the_reference_loop_fixture():
+    rows, edges = _check_2set_fixture("c2")
+    assert rows == 5000
+
+
+def test_c3_2set_every_row_equals_the_reference_loop_fixture():
+    """the search the metric is named after (read x candidate alignments) at the size it is quoted on: 50 000 reads x 1 030 candidates"""
+    rows, edges = _check_2set_fixture("c3")
+    assert rows == 50000

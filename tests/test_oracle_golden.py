@@ -120,6 +120,34 @@ def test_g17_whole_graph_fixtures():
             assert bench.graph_digest(best, row_ptr, cols) == bench.EXPECTED_GRAPH_DIGEST_C3
 
 
+def test_g19_2set_graph_fixtures():
+    """tests/golden/g19_*_graph_2set.npz (make_golden_g19.py): the read / candidate sets still hash to what the fixture was made from, target
+    rows are empty, every edge joins a read to a candidate within the length window of its distance (NNG:369-381), sampled rows equal the
+    oracle loop again, and a brute-force scan over ALL candidates confirms the minimum for a few reads (the loop's stop rule loses nothing)."""
+    import numpy as np
+    from conftest import g19
+    from oracle import oracle as O
+    for which in ("c2", "c3"):
+        X, C, merged, fx = g19(which)
+        n = len(merged)
+        is_t, best, row_ptr, cols = fx["is_target"], fx["best"], fx["row_ptr"], fx["cols"].astype(np.int64)
+        assert len(is_t) == n == len(best) and len(row_ptr) == n + 1 and row_ptr[-1] == len(cols) and int(is_t.sum()) == len(C)
+        rows = np.repeat(np.arange(n), np.diff(row_ptr))
+        assert (is_t[rows] == 0).all() and (is_t[cols] == 1).all() and (best[is_t == 1] == -1).all()
+        lens = np.fromiter((len(s) for s, _ in merged), dtype=np.int64, count=n)
+        assert (np.abs(lens[cols] - lens[rows]) <= best[rows]).all() and (best[rows] >= 0).all()
+        seqs = [s for s, _ in merged]
+        pick = np.random.default_rng(19).choice(np.flatnonzero(is_t == 0), 5 if which == "c3" else 30, replace=False).tolist()
+        for i in pick:
+            rp, c, e, _ = O.nn_2set(seqs, is_t, i, 1)
+            assert cols[row_ptr[i]:row_ptr[i + 1]].tolist() == c.tolist() and (e == best[i]).all()
+        cand = np.flatnonzero(is_t == 1)
+        for i in pick[:3]:
+            d = O.ed_pairs(seqs, np.full(len(cand), i), cand, None)
+            assert int(d.min()) == int(best[i])
+            assert sorted(cand[d == d.min()].tolist()) == sorted(cols[row_ptr[i]:row_ptr[i + 1]].tolist())
+
+
 def test_g18_alignment_fixtures():
     """tests/golden/g18_*_sw.npz (make_golden_g18.py): the pair lists are the partition of the g17 graph (partition_ids_py, the statement g7 pins
     to the reference), sampled pairs give the same distance / bucket / result row / ops hash / exon flag when the oracle aligns them again, the
