@@ -139,12 +139,16 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
 #pragma unroll
         for (int r = 0; r < R; ++r) { Hp[r] = left0; Ep[r] = SG_NEG; }
         int32_t diag_in = left0;     // H[row0-1][j-1]
-        int32_t sendH = 0, sendFC = SG_NEG * 4;
+        int32_t sendH = 0, sendF = SG_NEG, sendC = 0;
         uint64_t tlo = 0, thi = 0;
         int32_t bndH = 0, bndF = SG_NEG;   // lane l: boundary (H, F) of column 64*(s/64) + l
         const bool lane_has_rows = row0 < m;
-#pragma unroll 1
-        for (int32_t s = 0; s < psteps; ++s) {
+        // One step of the pass.  INTERIOR (compile-time): every lane has rows and sits on a column strictly inside the window and left of
+        // the last ref column, and the pass is not the one with the last query row -- no lane predicate, no boundary-column select, no
+        // end-cell candidates; the loop over those steps (all but the first and last ~64 of a full pass) is a separate one, so that
+        // the general path's branches and their joins are not paid there.
+        auto step = [&](const int32_t s, auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
             const int32_t col0 = jlo + s;     // lane 0's column (jlo is a multiple of 64)
             if ((s & 63) == 0) {   // wave-uniform: next 64 ref bases
                 const int32_t tc = col0 >> 6;
@@ -169,25 +173,24 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
                 // serialises each step on the HBM write latency.
                 asm volatile("" : "+v"(bndH), "+v"(bndF));
             }
-            int32_t Hup = __shfl_up(sendH, 1, 64);
-            const int32_t FC = __shfl_up(sendFC, 1, 64);
-            int32_t Fup, ch;
+            // one lane down: DPP wave shifts (lane 0's values are replaced below); as __shfl_up these were ds_bpermute + address
+            // instructions and an LDS round trip in every step's dependency chain
+            int32_t Hup = __builtin_amdgcn_update_dpp(0, sendH, 0x138, 0xf, 0xf, false);
+            int32_t Fup = __builtin_amdgcn_update_dpp(0, sendF, 0x138, 0xf, 0xf, false);
+            int32_t ch = __builtin_amdgcn_update_dpp(0, sendC, 0x138, 0xf, 0xf, false);
             const int32_t b_h = __builtin_amdgcn_readlane(bndH, s & 63), b_f = __builtin_amdgcn_readlane(bndF, s & 63);
             if (lane == 0) {
                 ch = (int32_t)(((tlo >> (s & 63)) & 1) | (((thi >> (s & 63)) & 1) << 1));
                 if (pass == 0) { Hup = 0; Fup = SG_NEG; }
                 else { Hup = b_h; Fup = b_f; }
-            } else {
-                Fup = FC >> 2;
-                ch = FC & 3;
             }
             const int32_t j = col0 - lane;
-            const bool act = j >= jlo && j <= jhi && lane_has_rows;
+            const bool act = INTERIOR || (j >= jlo && j <= jhi && lane_has_rows);
             const int32_t diag_next = Hup;
             if (act) {
                 const uint64_t slo = (ch & 1) ? ~(uint64_t)0 : 0, shi = (ch & 2) ? ~(uint64_t)0 : 0;
                 const uint32_t eq = (uint32_t)(~(qlo ^ slo) & ~(qhi ^ shi));
-                int32_t diag = (j == jlo) ? left0 : diag_in;   // left boundary column: H[.][-1] = 0 / outside the window
+                int32_t diag = (!INTERIOR && j == jlo) ? left0 : diag_in;   // left boundary column: H[.][-1] = 0 / outside the window
                 uint32_t tw = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
                 }
                 // end-cell candidates.  Both guards are WAVE-UNIFORM on purpose (scalar branches): left to itself the
                 // compiler if-converts these blocks into ~180 predicated instructions that run on every step.
-                if (pass == pstar) {                      // last query row: lane lstar, row rstar of this pass
+                if (!INTERIOR && pass == pstar) {                      // last query row: lane lstar, row rstar of this pass
                     // (a select chain on the uniform rstar: indexing Hp[] dynamically would demote it to scratch)
                     int32_t hv = Hp[0];
 #pragma unroll
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
                         else if (hv == rowbest) rowj_last = j;
                     }
                 }
-                if (col0 >= n - 1) {                      // only then can some lane sit on the last ref column
+                if (!INTERIOR && col0 >= n - 1) {                      // only then can some lane sit on the last ref column
                     if (j == n - 1) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
@@ -256,8 +259,31 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
             }
             diag_in = diag_next;
             sendH = Hup;
-            sendFC = (int32_t)(((uint32_t)(Fup < SG_NEG ? SG_NEG : Fup) << 2) | (uint32_t)ch);
+            sendF = Fup < SG_NEG ? SG_NEG : Fup;          // (-inf must not drift towards the end of the int32 range over a long pass)
+            sendC = ch;
+        };
+        // interior steps: s in [s_in, s_out): lane 63 inside the window (s - 63 > 0 <=> its column > jlo), lane 0 at most on jhi and left
+        // of the last ref column
+        int32_t s_in = psteps, s_out = psteps;
+        if (pass != pstar && (pass + 1) * 64 * R <= m) {
+            s_in = 64;
+            s_out = jhi - jlo + 1;                                  // col0 <= jhi
+            if (s_out > n - 1 - jlo) s_out = n - 1 - jlo;           // col0 < n - 1
+            if (s_out > psteps) s_out = psteps;
+            if (s_out < s_in) s_in = s_out = psteps;
         }
+        int32_t s = 0;
+#pragma unroll 1
+        for (; s < psteps && s < s_in; ++s) step(s, std::false_type());
+        // (two steps per iteration: the rows' H / E registers alternate between two sets instead of being moved back at the loop edge --
+        // 42 v_mov per step in the one-step loop)
+#pragma unroll 1
+        for (; s + 1 < s_out; s += 2) {
+            step(s, std::true_type());
+            step(s + 1, std::true_type());
+        }
+#pragma unroll 1
+        for (; s < psteps; ++s) step(s, std::false_type());
         jhi_prev = jhi;
         if (pass + 1 < passes) __threadfence();
     }
