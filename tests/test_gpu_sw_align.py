@@ -313,4 +313,18 @@ def test_narrow_tries_certify_themselves_or_run_again(monkeypatch):
         seen_pass += runs["default"]["pairs_tried_narrow"] - runs["default"]["pairs_retried_wider"]
         seen_again += runs["all"]["pairs_retried_wider"]
     assert seen_pass > 0 and seen_again > 0
+    # hints that are too small: a band that is tried narrow, fails, runs again in the (too small) band of its bound, fails that certificate
+    # on the host and is aligned in full -- still the full-matrix result
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "sw_narrow_try_pct=1")
+    o0, p0, r0 = st.sg_trace(a, b, mm)
+    redone = 0
+    for f in (0.55, 0.7, 0.85):
+        small = np.maximum((ed * f).astype(np.int32), 1)
+        o, p, r = st.sg_trace(a, b, mm, ed_upper=small)
+        stats = sg_last_stats()
+        assert (r == r0).all() and (p == p0).all() and (o == o0).all(), f
+        redone += stats["pairs_redone"]
+        assert stats["pairs_retried_wider"] >= 0 and stats["pairs_tried_narrow"] >= 0
+    assert redone > 0
+    monkeypatch.delenv("ISOCON_DEBUG_VARIANT", raising=False)
     st.close()
