@@ -144,6 +144,8 @@ def _wide_slot_patches(members, wide, col_slot, longest):
     longest_l = longest.tolist()
     u_slot_l = u_slot.tolist()
     cache = _PLACEMENT_CACHE
+    H = _lib.pyhelp()
+    place = getattr(H, "best_solution", None) if H is not None else None          # (functions.get_best_solution in the CPython helper)
     for g in range(len(cuts) - 1):
         lo, hi = cuts[g], cuts[g + 1]
         lg = longest_l[u_slot_l[lo]]
@@ -154,7 +156,15 @@ def _wide_slot_patches(members, wide, col_slot, longest):
             if sol is None:
                 if len(cache) > 200000:
                     cache.clear()
-                sol = cache[key] = np.frombuffer("".join(get_best_solution(mx, strings[i])).encode(), dtype=np.uint8)
+                placed = None
+                if place is not None and len(mx) <= 255 and len(strings[i]) <= 255:
+                    try:
+                        placed = place(mx, strings[i])
+                    except TypeError:
+                        placed = None
+                if placed is None:
+                    placed = "".join(get_best_solution(mx, strings[i])).encode()
+                sol = cache[key] = np.frombuffer(placed, dtype=np.uint8)
             sol_bytes[sol_off_l[i]:sol_off_l[i + 1]] = sol
     # one patch per record: the bytes of its distinct insertion's placement, at its slot's first column
     p_len = sol_len[inv]

@@ -5,6 +5,9 @@
  * about Python objects.  Built by isocon_amd/_lib.py:build() with the system compiler; if it is missing the wrappers use their
  * pure-Python loops. */
 #define PY_SSIZE_T_CLEAN
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE          /* memmem */
+#endif
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
@@ -185,6 +188,129 @@ static PyObject *split_ascii_rows(PyObject *self, PyObject *args)
         PyList_SET_ITEM(out, i, s);
     }
     free(hash); free(table);
+    return out;
+}
+
+/* invariant_partners(seq1: str, seqs: list[str], thr: int) -> [i for i, seq2 in enumerate(seqs) if _pair_is_invariant(seq1, seq2, thr)]
+ * -- end_invariant_functions._pair_is_invariant / is_overlap (the reference's end_invariant_functions.py:933-946, :884-918) on ASCII strings:
+ *   seq2 inside seq1: its FIRST occurrence decides (at most thr characters of seq1 before and after it), nothing else is tried;
+ *   otherwise a suffix of one equal to a prefix of the other (after cutting the longer to the length of the shorter, as the reference does)
+ *   that leaves at most thr characters of either original string uncovered -- in either direction.
+ * One call per candidate against its partner list: the Python loop made 3.6 million calls of three functions for 9 000 candidates. */
+static int overlap_holds(const char *t1, Py_ssize_t l1, const char *t2, Py_ssize_t l2, Py_ssize_t thr)
+{
+    if (l1 == 0 || l2 == 0) return 0;
+    const char *a = l1 > l2 ? t1 + (l1 - l2) : t1;          /* text1[-len2:] */
+    const Py_ssize_t n = l1 < l2 ? l1 : l2;                 /* (text2[:len1]: the first n characters of t2) */
+    if (memcmp(a, t2, (size_t)n) == 0) return 1;
+    const Py_ssize_t need = (l1 > l2 ? l1 : l2) - thr;
+    if (need <= 0) return 1;
+    for (Py_ssize_t L = n; L >= need; --L)
+        if (memcmp(a + (n - L), t2, (size_t)L) == 0) return 1;
+    return 0;
+}
+
+static PyObject *invariant_partners(PyObject *self, PyObject *args)
+{
+    PyObject *seq1, *seqs;
+    Py_ssize_t thr;
+    if (!PyArg_ParseTuple(args, "UO!n", &seq1, &PyList_Type, &seqs, &thr)) return NULL;
+    if (PyUnicode_READY(seq1) < 0) return NULL;
+    if (PyUnicode_KIND(seq1) != PyUnicode_1BYTE_KIND) { PyErr_SetString(PyExc_TypeError, "invariant_partners: 1-byte strings only"); return NULL; }
+    const char *s1 = (const char *)PyUnicode_1BYTE_DATA(seq1);
+    const Py_ssize_t l1 = PyUnicode_GET_LENGTH(seq1), n = PyList_GET_SIZE(seqs);
+    PyObject *out = PyList_New(0);
+    if (!out) return NULL;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *o = PyList_GET_ITEM(seqs, i);
+        if (!PyUnicode_Check(o) || PyUnicode_READY(o) < 0 || PyUnicode_KIND(o) != PyUnicode_1BYTE_KIND) {
+            Py_DECREF(out);
+            PyErr_SetString(PyExc_TypeError, "invariant_partners: a list of 1-byte strings is required");
+            return NULL;
+        }
+        const char *s2 = (const char *)PyUnicode_1BYTE_DATA(o);
+        const Py_ssize_t l2 = PyUnicode_GET_LENGTH(o);
+        int holds;
+        /* first occurrence of seq2 in seq1: the caller's pairs differ by at most 2 thr in length -- a memcmp per offset (each fails within a
+         * few bytes) beats memmem, whose preprocessing of a 3 kb needle was the whole cost of the call; memmem for the general case */
+        const char *hit = NULL;
+        if (l2 == 0) hit = s1;
+        else if (l2 <= l1 && l1 - l2 <= 64) {
+            for (Py_ssize_t off = 0; off + l2 <= l1; ++off)
+                if (s1[off] == s2[0] && memcmp(s1 + off, s2, (size_t)l2) == 0) { hit = s1 + off; break; }
+        } else if (l2 <= l1) hit = (const char *)memmem(s1, (size_t)l1, s2, (size_t)l2);
+        if (hit) {
+            const Py_ssize_t start = (Py_ssize_t)(hit - s1), end = l1 - (start + l2);
+            holds = start <= thr && end <= thr;
+        } else holds = overlap_holds(s1, l1, s2, l2, thr) || overlap_holds(s2, l2, s1, l1, thr);
+        if (holds) {
+            PyObject *idx = PyLong_FromSsize_t(i);
+            if (!idx || PyList_Append(out, idx) < 0) { Py_XDECREF(idx); Py_DECREF(out); return NULL; }
+            Py_DECREF(idx);
+        }
+    }
+    return out;
+}
+
+/* best_solution(max_insertion: str, q_ins: str) -> bytes(len(max_insertion)): functions.get_best_solution (the reference's functions.py:635-676
+ * with min_ed :771-799 and the unit-cost global alignment that stands where it calls edlib, functions.nw_path_cigar) on ASCII strings:
+ *   "-" -> all gaps; q_ins found in max_insertion -> at its first occurrence; else threaded along ONE optimal global alignment that deletes
+ *   nothing from q_ins (backtracking from the end prefers a step in max_insertion alone, then one in q_ins alone, then the diagonal);
+ *   else at the offset with the most matching characters (first maximum; offset 0: q_ins left-aligned, cut to the width).
+ * The placement of every distinct insertion of a wide slot: 177 000 calls of the Python dynamic programme on 50 000 ONT-profile reads. */
+#define BS_MAX 255
+static PyObject *best_solution(PyObject *self, PyObject *args)
+{
+    PyObject *mxo, *qo;
+    if (!PyArg_ParseTuple(args, "UU", &mxo, &qo)) return NULL;
+    if (PyUnicode_READY(mxo) < 0 || PyUnicode_READY(qo) < 0) return NULL;
+    if (PyUnicode_KIND(mxo) != PyUnicode_1BYTE_KIND || PyUnicode_KIND(qo) != PyUnicode_1BYTE_KIND) {
+        PyErr_SetString(PyExc_TypeError, "best_solution: 1-byte strings only");
+        return NULL;
+    }
+    const char *mx = (const char *)PyUnicode_1BYTE_DATA(mxo), *q = (const char *)PyUnicode_1BYTE_DATA(qo);
+    const Py_ssize_t L = PyUnicode_GET_LENGTH(mxo), m = PyUnicode_GET_LENGTH(qo);
+    if (L > BS_MAX || m > BS_MAX) { PyErr_SetString(PyExc_ValueError, "best_solution: strings of at most 255 characters"); return NULL; }
+    PyObject *out = PyBytes_FromStringAndSize(NULL, L);
+    if (!out) return NULL;
+    char *o = PyBytes_AS_STRING(out);
+    memset(o, '-', (size_t)L);
+    if (m == 1 && q[0] == '-') return out;
+    /* first occurrence of q_ins in max_insertion ("" is found at 0) */
+    for (Py_ssize_t p = 0; p + m <= L; ++p)
+        if (memcmp(mx + p, q, (size_t)m) == 0) { memcpy(o + p, q, (size_t)m); return out; }
+    /* min_ed: global unit-cost alignment of max_insertion (rows) against q_ins (columns) */
+    if (L > 0) {
+        static _Thread_local uint16_t D[BS_MAX + 1][BS_MAX + 1];
+        for (Py_ssize_t i = 0; i <= L; ++i) D[i][0] = (uint16_t)i;
+        for (Py_ssize_t j = 0; j <= m; ++j) D[0][j] = (uint16_t)j;
+        for (Py_ssize_t i = 1; i <= L; ++i)
+            for (Py_ssize_t j = 1; j <= m; ++j) {
+                uint16_t best = (uint16_t)(D[i - 1][j - 1] + (mx[i - 1] != q[j - 1]));
+                if (D[i - 1][j] + 1 < best) best = (uint16_t)(D[i - 1][j] + 1);
+                if (D[i][j - 1] + 1 < best) best = (uint16_t)(D[i][j - 1] + 1);
+                D[i][j] = best;
+            }
+        /* backtrack; the threaded string is written from its end: an 'I' (row only) is a gap, anything else takes the next character of q_ins */
+        Py_ssize_t i = L, j = m;
+        int deleted = 0;
+        while (i > 0 || j > 0) {
+            if (i > 0 && D[i - 1][j] + 1 == D[i][j]) { o[i - 1] = '-'; --i; }
+            else if (j > 0 && D[i][j - 1] + 1 == D[i][j]) { deleted = 1; break; }
+            else { o[i - 1] = q[j - 1]; --i; --j; }
+        }
+        if (!deleted) return out;
+        memset(o, '-', (size_t)L);
+    }
+    /* the offset with the most matching characters (the first maximum above 0 matches) */
+    Py_ssize_t max_p = 0, max_matches = 0;
+    for (Py_ssize_t p = 0; p + m <= L; ++p) {
+        Py_ssize_t nr = 0;
+        for (Py_ssize_t t = 0; t < m; ++t) nr += q[t] == mx[p + t];
+        if (nr > max_matches) { max_p = p; max_matches = nr; }
+    }
+    if (max_p > 0) memcpy(o + max_p, q, (size_t)m);
+    else memcpy(o, q, (size_t)(m < L ? m : L));
     return out;
 }
 
@@ -647,6 +773,8 @@ static PyMethodDef methods[] = {
     {"csr_to_dict", csr_to_dict, METH_VARARGS, "dict of dicts from the CSR arrays of a nearest-neighbour graph"},
     {"str_pointers", str_pointers, METH_VARARGS, "addresses and lengths of a list of ASCII str"},
     {"split_ascii", split_ascii, METH_VARARGS, "list of str cut out of an ASCII buffer"},
+    {"best_solution", best_solution, METH_VARARGS, "functions.get_best_solution on ASCII strings, as bytes"},
+    {"invariant_partners", invariant_partners, METH_VARARGS, "indices of the strings of a list that equal a string up to their ends"},
     {"split_ascii_rows", split_ascii_rows, METH_VARARGS, "list of str for selected rows of an ASCII buffer, equal rows sharing one object"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_pyhelp", NULL, -1, methods};

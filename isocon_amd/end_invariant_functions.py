@@ -94,6 +94,10 @@ def get_invariants_under_ignored_edge_ends_speed(candidate_transcripts, candidat
     import bisect
 
     import networkx as nx
+    from . import _lib
+    H = _lib.pyhelp()
+    if H is not None and not hasattr(H, "invariant_partners"):
+        H = None
     thr = params.ignore_ends_len
     G = nx.DiGraph()
     for acc in candidate_transcripts:
@@ -123,6 +127,18 @@ def get_invariants_under_ignored_edge_ends_speed(candidate_transcripts, candidat
             todo = [by_len[k] for k in todo]
         else:
             todo = [x for x in by_len[lo:hi] if x[0] != acc1]
+        if H is not None and todo:
+            # the reference's test for all partners of seq1 in one call of the CPython helper (cpy/_pyhelp.c: invariant_partners)
+            try:
+                hits = H.invariant_partners(seq1, [x[1] for x in todo], thr)
+            except TypeError:               # (not plain ASCII strings)
+                H, hits = None, None
+            if hits is not None:
+                for k in hits:
+                    acc2 = todo[k][0]
+                    G.add_edge(acc2, acc1)
+                    G.add_edge(acc1, acc2)
+                continue
         for acc2, seq2 in todo:
             if indexed and not (_shift_consistent(seq2, seq1, thr) or _shift_consistent(seq1, seq2, thr)):
                 continue                    # (candidates of one isoform share the anchor but differ inside)

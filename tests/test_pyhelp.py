@@ -101,6 +101,78 @@ def check_split_ascii_rows(H):
         H.split_ascii_rows(buf.ctypes.data, np.array([0, 2], dtype=np.int64).ctypes.data, np.array([-1], dtype=np.int64).ctypes.data, 1)
 
 
+def check_invariant_partners(H):
+    """the C statement of end_invariant_functions._pair_is_invariant against the Python one (itself pinned to the reference by g13): substrings
+    whose FIRST occurrence decides (repeats: a later occurrence would pass), suffix-prefix overlaps in both directions, thresholds 0 .. 20,
+    empty strings, equal strings, pairs outside the length window the caller uses"""
+    import random
+    sys.path.insert(0, ROOT)
+    from isocon_amd import end_invariant_functions as END
+    rng = random.Random(13)
+    for thr in (0, 1, 5, 15, 20):
+        for rep in range(60):
+            L = rng.choice([0, 1, 3, 30, 120, 400])
+            alpha = rng.choice(["ACGT", "AC", "A"])          # (short alphabets: repeats, many occurrences)
+            base = "".join(rng.choice(alpha) for _ in range(L))
+            others = []
+            for _ in range(40):
+                r = rng.random()
+                cut_a, cut_b = rng.randint(0, thr + 3), rng.randint(0, thr + 3)
+                t = base[cut_a:len(base) - cut_b] if r < 0.35 else base
+                if 0.35 <= r < 0.55:
+                    t = "".join(rng.choice(alpha) for _ in range(rng.randint(0, thr + 2))) + base[rng.randint(0, thr + 2):]
+                elif 0.55 <= r < 0.75:
+                    t = base[:len(base) - rng.randint(0, thr + 2)] + "".join(rng.choice(alpha) for _ in range(rng.randint(0, thr + 2)))
+                elif 0.75 <= r < 0.9 and t:
+                    k = rng.randrange(len(t))
+                    t = t[:k] + rng.choice(alpha) + t[k + 1:]
+                elif r >= 0.97:
+                    t = "".join(rng.choice(alpha) for _ in range(rng.randint(0, L + 5)))
+                others.append(t)
+            got = H.invariant_partners(base, others, thr)
+            assert got == [i for i, t in enumerate(others) if END._pair_is_invariant(base, t, thr)], (thr, rep, base)
+    assert H.invariant_partners("ACGT", [], 3) == []
+    with pytest.raises(TypeError):
+        H.invariant_partners("ACGT", ["AC", 5], 3)
+    with pytest.raises(TypeError):
+        H.invariant_partners("AC\u0394T", ["AC"], 3)
+
+
+def check_best_solution(H):
+    """the C statement of functions.get_best_solution (first occurrence, threading along the optimal alignment with its tie rule, best-offset
+    fallback, the all-gap and the too-long cases) against the Python one, which the correction fixtures (g11) pin to the reference"""
+    import random
+    sys.path.insert(0, ROOT)
+    from isocon_amd.functions import get_best_solution
+    rng = random.Random(31)
+    for it in range(30000):
+        L = rng.randint(0, 12)
+        core = "".join(rng.choice("ACGT") for _ in range(L))
+        mx = "-" + core + "-" if rng.random() < 0.8 else core
+        r = rng.random()
+        if r < 0.05:
+            q = "-"
+        elif r < 0.5:
+            q = list(core)
+            for _ in range(rng.randint(0, 3)):
+                if q and rng.random() < 0.5:
+                    del q[rng.randrange(len(q))]
+                elif q:
+                    q[rng.randrange(len(q))] = rng.choice("ACGT")
+                else:
+                    q.append(rng.choice("ACGT"))
+            q = "".join(q)
+        else:
+            q = "".join(rng.choice("AC" if it % 3 else "ACGT") for _ in range(rng.randint(0, 14)))
+        assert H.best_solution(mx, q) == "".join(get_best_solution(mx, q)).encode(), (mx, q)
+    long_mx = "-" + "ACGT" * 60 + "-"
+    assert H.best_solution(long_mx, "ACGTTACG") == "".join(get_best_solution(long_mx, "ACGTTACG")).encode()
+    with pytest.raises(ValueError):
+        H.best_solution("A" * 256, "A")
+    with pytest.raises(TypeError):
+        H.best_solution("A\u0394", "A")
+
+
 def check_csr_to_dict(H):
     keys = ["k%d" % i for i in range(6)]
     best = np.array([3, -1, 2, 2, 7, -1], dtype=np.int32)
@@ -303,6 +375,14 @@ def test_split_ascii_rows():
     check_split_ascii_rows(_helper())
 
 
+def test_invariant_partners():
+    check_invariant_partners(_helper())
+
+
+def test_best_solution():
+    check_best_solution(_helper())
+
+
 def test_csr_to_dict():
     check_csr_to_dict(_helper())
 
@@ -335,7 +415,7 @@ def test_under_address_and_undefined_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
                ISOCON_PYHELP_UNDER_TEST=so)
     code = ("import sys; sys.path.insert(0, %r); import test_pyhelp as T; H = T._helper(); "
-            "T.check_group_keys_by_value(H); T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_split_ascii_rows(H); T.check_csr_to_dict(H); T.check_pair_ids(H); "
+            "T.check_group_keys_by_value(H); T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_split_ascii_rows(H); T.check_invariant_partners(H); T.check_best_solution(H); T.check_csr_to_dict(H); T.check_pair_ids(H); "
             "T.check_unique_values_by_length(H); T.check_flatten_pairs(H); T.check_alignment_dict(H); T.check_lazy_rows(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
