@@ -100,6 +100,17 @@ int isocon_qgram_params(int32_t *out);
 int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, uint64_t n_pairs, int32_t *out_bound);
 
 /*
+ * The SECOND lower bound of the main pass, for explicit pairs (tests, diagnostics): out_count[i] = the greedy number of pairwise disjoint
+ * 8-grams of sequence partner[i] -- probed at the positions 0, s, 2 s, ... (probe_stride s = 4 or 2: the main pass runs 4 on every pair and 2 on
+ * what is left) of the whole 16-base words of the sequence all of whose grams lie inside it -- that
+ * occur NOWHERE in sequence owner[i].  Every such gram holds an edited position of any alignment of the two, so out_count[i] <=
+ * edit distance; the main pass drops a surviving pair of its q-gram bound whose count exceeds the pair's threshold before any alignment
+ * kernel sees it (csrc/nn_filter.hpp).  The reference evaluates those pairs with edlib and gets -1 (modules/nearest_neighbor_graph.py:156-162,
+ * :171-178).  Same alphabet rule as isocon_qgram_bound_pairs.
+ */
+int isocon_block_bound_pairs(isocon_store *s, const uint32_t *owner, const uint32_t *partner, uint64_t n_pairs, int32_t probe_stride, int32_t *out_count);
+
+/*
  * The bound matrix the main pass of isocon_nn_graph / isocon_nn_partial consults for the shard (q_begin, q_end, q_stride, q_block) --
  * see isocon_nn_partial -- of a length-sorted store, read back for tests: row r belongs to the shard's r-th entry q, its bytes
  * out_bounds[out_row_ptr[r] .. out_row_ptr[r + 1]) are min(255, bound) of the pairs (q, p), p = q + 1, q + 2, ... while
@@ -133,6 +144,8 @@ typedef struct {
     uint64_t narrow_columns;      /* of cells_columns: columns run by the 32-row form of the table kernel */
     uint64_t pairs_narrow;        /* pairs listed in chunks of the 32-row class */
     uint64_t pairs_bytes;         /* pairs with a sequence that holds symbols outside the 2-bit map, aligned on the bytes (see "Alphabet") */
+    uint64_t pairs_block_rejected;/* survivors of the q-gram bound that the block filter rejected (greedy count of disjoint absent 8-grams > threshold; never aligned) */
+    float filter_kernel_ms;       /* HIP-event time of the block filter (part of list_kernel_ms) */
 } isocon_nn_stats;
 
 /*

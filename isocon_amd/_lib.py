@@ -34,7 +34,8 @@ class NNStats(ctypes.Structure):
                 ("scan_launches", ctypes.c_uint32), ("pairs_prefiltered", ctypes.c_uint64), ("bound_kernel_ms", ctypes.c_float),
                 ("list_kernel_ms", ctypes.c_float), ("lanes_kernel_ms", ctypes.c_float), ("narrow_kernel_ms", ctypes.c_float),
                 ("pairs_lanes", ctypes.c_uint64), ("bound_tiles", ctypes.c_uint64), ("pairs_wide_to_lanes", ctypes.c_uint64),
-                ("narrow_columns", ctypes.c_uint64), ("pairs_narrow", ctypes.c_uint64), ("pairs_bytes", ctypes.c_uint64)]
+                ("narrow_columns", ctypes.c_uint64), ("pairs_narrow", ctypes.c_uint64), ("pairs_bytes", ctypes.c_uint64),
+                ("pairs_block_rejected", ctypes.c_uint64), ("filter_kernel_ms", ctypes.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -58,6 +59,7 @@ SYMBOLS = {
     "isocon_ed_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, i32p, ctypes.c_uint64, i32p, f32p]),
     "isocon_qgram_params": (ctypes.c_int, [i32p]),
     "isocon_qgram_bound_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, i32p]),
+    "isocon_block_bound_pairs": (ctypes.c_int, [ctypes.c_void_p, u32p, u32p, ctypes.c_uint64, ctypes.c_int32, i32p]),
     "isocon_qgram_bound_matrix": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, u64p, u8p,
                                                  ctypes.c_uint64, u64p]),
     "isocon_nn_graph": (ctypes.c_int, [ctypes.c_void_p, u8p, u8p, ctypes.c_uint64, i32p, u64p, u32p, ctypes.c_uint64,

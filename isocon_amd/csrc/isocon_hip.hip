@@ -17,6 +17,7 @@
 #include "qgram_mm.hpp"
 #include "nn.hpp"
 #include "nn_list.hpp"
+#include "nn_filter.hpp"
 #include "nn_finalize.hpp"
 #include "nn_finalize_host.hpp"
 #include "partition_host.hpp"
@@ -93,7 +94,7 @@ struct HeldHits { uint64_t store_serial = 0; uint64_t rows = 0; };
 // hipMalloc/hipFree (tens of ms for the multi-GB trace scratch) every time.
 struct ScratchPool {
     struct Slot { void *p = nullptr; size_t cap = 0; };
-    Slot slots[152];
+    Slot slots[160];
     BoundTag bound_tag;
     HeldHits held_hits;
     MsaTag msa_tag;
@@ -124,14 +125,14 @@ struct ScratchPool {
 
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
-    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_SLOTORDER, SLOT_NN_LBCHUNKS, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B, SLOT_NN_SEED_N, SLOT_NN_LBT, SLOT_NN_LBT_OFF, SLOT_NN_LBT_SLO, SLOT_NN_LBT_LEN, SLOT_NN_LBT_PAD, SLOT_NN_SCORE, SLOT_NN_LDEST, SLOT_NN_FIN_HITS, SLOT_NN_FIN_CNT, SLOT_NN_FIN_START, SLOT_NN_FIN_CUR, SLOT_NN_FIN_NB, SLOT_NN_FIN_LEN2, SLOT_NN_FIN_ROWPTR, SLOT_NN_FIN_COLS, SLOT_NN_FIN_FLAG, SLOT_NN_FIN_BEST, SLOT_NN_ACC_HITS, SLOT_NN_LTOT, SLOT_NN_LCHUNKS, SLOT_NN_LIST, SLOT_NN_LPA, SLOT_NN_LPB,
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_SLOTORDER, SLOT_NN_LBCHUNKS, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B, SLOT_NN_SEED_N, SLOT_NN_LBT, SLOT_NN_LBT_OFF, SLOT_NN_LBT_SLO, SLOT_NN_LBT_LEN, SLOT_NN_LBT_PAD, SLOT_NN_SCORE, SLOT_NN_LDEST, SLOT_NN_FIN_HITS, SLOT_NN_FIN_CNT, SLOT_NN_FIN_START, SLOT_NN_FIN_CUR, SLOT_NN_FIN_NB, SLOT_NN_FIN_LEN2, SLOT_NN_FIN_ROWPTR, SLOT_NN_FIN_COLS, SLOT_NN_FIN_FLAG, SLOT_NN_FIN_BEST, SLOT_NN_ACC_HITS, SLOT_NN_LTOT, SLOT_NN_LCHUNKS, SLOT_NN_LIST, SLOT_NN_LPA, SLOT_NN_LPB, SLOT_NN_TEXT2,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED, SLOT_MSA_ROWS, SLOT_MSA_OPS, SLOT_MSA_OPTR, SLOT_MSA_LONGEST, SLOT_MSA_WIDTH, SLOT_MSA_CSLOT, SLOT_MSA_LTOT, SLOT_MSA_WIDE, SLOT_MSA_PROW, SLOT_MSA_PCOL, SLOT_MSA_PPTR, SLOT_MSA_PBYTES, SLOT_MSAB_PART, SLOT_MSAB_FIRST, SLOT_MSAB_LM, SLOT_MSAB_SBASE, SLOT_MSAB_NCOLS, SLOT_MSAB_MOFF, SLOT_MSAB_CBASE, SLOT_MSAB_CBP, SLOT_MSAB_CBC, SLOT_MSAB_CBR,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES, SLOT_HW_PQ, SLOT_HW_KEY, SLOT_HW_HIST, SLOT_HW_CURSOR, SLOT_HW_TBASE, SLOT_HW_CLS,
     SLOT_PACK_ASCII, SLOT_PACK_OFF, SLOT_PACK_BAD, SLOT_PACK_HIST, SLOT_PACK_FLAGS, SLOT_EB_A, SLOT_EB_B, SLOT_EB_K, SLOT_EB_OUT, SLOT_EB_ROWS, SLOT_SCAN_TMP, SLOT_SCAN_SUMS,
     SLOT_COUNT
 };
-static_assert(SLOT_COUNT <= 152, "ScratchPool::slots too small");
+static_assert(SLOT_COUNT <= 160, "ScratchPool::slots too small");
 
 // One pool per process (one process drives one GPU): scratch outlives the individual stores, because the Python
 // wrappers create a fresh store per call (the reference's functions are stateless).
@@ -965,6 +966,30 @@ extern "C" int isocon_qgram_bound_pairs(isocon_store *s, const uint32_t *a, cons
     for (uint64_t i = 0; i < n_pairs; ++i)
         if (a[i] >= n || b[i] >= n) { g_last_error = "pair index out of range"; return ISOCON_E_ARG; }
     return qgram_bounds_for_pairs(s, a, b, n_pairs, out_bound, nullptr);
+}
+
+// ... and the block bound behind it (nn_filter.hpp), one workgroup per pair
+extern "C" int isocon_block_bound_pairs(isocon_store *s, const uint32_t *owner, const uint32_t *partner, uint64_t n_pairs, int32_t probe_stride, int32_t *out_count)
+{
+    if (probe_stride != 4 && probe_stride != 2) return ISOCON_E_ARG;
+    if (!s || (n_pairs && (!owner || !partner || !out_count))) return ISOCON_E_ARG;
+    if (!n_pairs) return ISOCON_OK;
+    if (s->n_exc) { g_last_error = "block bounds are defined on the 2-bit planes: the set holds more than four distinct symbols"; return ISOCON_E_ALPHABET; }
+    const uint32_t n = s->dev.n;
+    if (n_pairs >= ((uint64_t)1 << 31)) return ISOCON_E_ARG;
+    for (uint64_t i = 0; i < n_pairs; ++i)
+        if (owner[i] >= n || partner[i] >= n) { g_last_error = "pair index out of range"; return ISOCON_E_ARG; }
+    const uint32_t stride = nnf_text2_stride(s->maxlen);
+    DevBuf d_text(&s->pool, SLOT_NN_TEXT2), d_a(&s->pool, SLOT_ED_TS), d_b(&s->pool, SLOT_ED_IDS), d_out(&s->pool, SLOT_ED_OUT);
+    int rc;
+    if ((rc = d_text.alloc((size_t)n * stride * 4)) || (rc = d_a.alloc(n_pairs * 4)) || (rc = d_b.alloc(n_pairs * 4)) || (rc = d_out.alloc(n_pairs * 4))) return rc;
+    ISO_HIP_CHECK(copy_h2d(d_a.p, owner, n_pairs * 4));
+    ISO_HIP_CHECK(copy_h2d(d_b.p, partner, n_pairs * 4));
+    hipLaunchKernelGGL(k_build_text2, dim3(n), dim3(256), 0, 0, s->dev, d_text.as<uint32_t>(), stride);
+    hipLaunchKernelGGL(k_nn_block_count_pairs, dim3((unsigned)n_pairs), dim3(256), 0, 0, d_text.as<uint32_t>(), stride, s->dev.lens, d_a.as<uint32_t>(), d_b.as<uint32_t>(), d_out.as<int32_t>(), probe_stride);
+    ISO_HIP_CHECK(hipGetLastError());
+    ISO_HIP_CHECK(copy_d2h(out_count, d_out.p, n_pairs * 4));
+    return ISOCON_OK;
 }
 
 #include "nn_context.inc"

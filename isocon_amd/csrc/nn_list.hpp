@@ -40,6 +40,8 @@ struct NNPlanTotals {
     unsigned long long n_pairs, pad0[15], n_list, pad1[15], n_small, pad2[15], n_chunks, pad3[15], n_filtered, pad4[15], overflow, pad5[15];
     unsigned long long n_chunks_narrow, pad6[15];          // chunks of the 32-row class (n_chunks counts the 64-row class)
     unsigned long long n_wide_pairs, n_narrow_listed, pad7[14];          // pairs sent to the pair-per-lane kernel for their threshold (class mode 1); pairs in narrow chunks
+    // the block filter behind the list builder (nn_filter.hpp): its work queue, the chunks it leaves per class, the pairs it rejected
+    unsigned long long f_next, pad8[15], f_chunks, pad9[15], f_chunks_narrow, pad10[15], f_rejected, f_narrow_listed, f_listed, pad11[13];          // f_listed: pairs in the chunks it leaves (both classes)
 };
 
 // Threshold classes of the listed launch.  A pair whose threshold max(k of its two directions) is <= NN_NARROW_K is exact on 32

@@ -40,6 +40,9 @@ def is_overlap(text1, text2, ignore_ends_threshold):
     need = max(len1, len2) - ignore_ends_threshold
     if need <= 0:
         return True          # (best >= 0 always satisfies both offsets)
+    if n < need:
+        return False         # (lengths more than the threshold apart: no overlap of the truncated strings is long enough;
+                             #  without this the probe's end index below goes negative and str.find reads it from the end)
     if need >= 16:
         # an overlap of L >= need characters starts at position n - L <= n - need of text1 and begins with text2[:16]:
         # let str.find look for that probe in the admissible start range (one C call instead of a Python loop)

@@ -109,6 +109,17 @@ class SeqStore(object):
                    "isocon_qgram_bound_pairs")
         return out
 
+    def block_bound_pairs(self, owner, partner, probe_stride=4):
+        """Second lower bound of ed(owner[i], partner[i]) (csrc/nn_filter.hpp): the greedy count of disjoint 8-grams of the partner that
+        occur nowhere in the owner -- what the main pass tests on the survivors of the q-gram bound (isocon_block_bound_pairs; tests)."""
+        a = np.ascontiguousarray(owner, dtype=np.uint32)
+        b = np.ascontiguousarray(partner, dtype=np.uint32)
+        if len(a) != len(b):
+            raise ValueError("pair arrays differ in length")
+        out = np.zeros(len(a), dtype=np.int32)
+        _lib.check(self._L.isocon_block_bound_pairs(self._h, _ptr(a, _lib.u32p), _ptr(b, _lib.u32p), len(a), probe_stride, _ptr(out, _lib.i32p)), "isocon_block_bound_pairs")
+        return out
+
     def qgram_bound_matrix(self, q_begin=0, q_end=None, q_stride=1, depth=2 ** 32, q_block=1):
         """The bound matrix the NN main pass consults for the shard (q_begin, q_end, q_stride, q_block) (isocon_qgram_bound_matrix; tests):
         (row_ptr[rows + 1], bytes) -- row r = the shard's r-th entry (shard_entries) against the entries behind it within 63 of its length."""

@@ -48,6 +48,30 @@ OVERLAPS = [("ACGTACGTAC", "GTACGTACGG", 3), ("ACGTACGTAC", "GTACGTACGG", 1), ("
             ("ACGT", "ACGT", 0), ("", "ACGT", 5), ("ACGTTT", "ACG", 2), ("TTACGT", "ACGTAA", 2), ("TTACGT", "ACGTAA", 1), ("ACGTACGT", "TTTTTTTT", 15)]
 
 
+def wide_overlaps():
+    """thresholds above 16 with the two lengths more than thr + 16 apart (the region where an end index of the restatement's probe search
+    went negative), and ordinary near misses at those thresholds"""
+    rng = random.Random(77)
+    out = [("".join(random.Random(3).choice("ACGT") for _ in range(400)),) * 2]
+    s = out.pop()[0]
+    out.append((s, s[60:] + "A", 40))                     # (the advisor's case: prefix offset 60 > 40)
+    for thr in (17, 25, 40, 64):
+        for _ in range(12):
+            L = rng.randint(3 * thr + 20, 420)
+            a = "".join(rng.choice("ACGT") for _ in range(L))
+            gap = rng.choice([rng.randint(thr + 17, 2 * thr), rng.randint(0, thr), thr, thr + 1, thr + 16, thr + 17])
+            gap = min(gap, L - 2)
+            tail = "".join(rng.choice("ACGT") for _ in range(rng.randint(0, thr + 2)))
+            b = a[gap:] + tail
+            if rng.random() < 0.25:
+                k = rng.randrange(len(b)); b = b[:k] + rng.choice("ACGT") + b[k + 1:]
+            out.append((a, b, thr) if rng.random() < 0.7 else (b, a, thr))
+    return out
+
+
+OVERLAPS = OVERLAPS + wide_overlaps()
+
+
 def child(ci):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(HERE, "shims"))

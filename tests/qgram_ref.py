@@ -63,3 +63,19 @@ def bound_matrix(seqs, q=Q):
     sums = T.sum(axis=1).astype(np.int64)
     M = (T @ T.T).astype(np.int64)
     return (np.maximum(sums[:, None], sums[None, :]) - M + q - 1) // q
+
+
+# ---- the block bound behind it (isocon_amd/csrc/nn_filter.hpp) -----------------------------------------------------------------------
+
+def block_count(owner, partner, b=8, s=4):
+    """greedy number of pairwise disjoint b-grams of `partner`, probed at the positions 0, s, 2 s, ... of the whole 16-base words
+    all of whose grams lie inside the sequence (word j counts when 16 j + 24 - s <= len), which occur nowhere in `owner`: a counted gram skips the probes that overlap it"""
+    grams = set(owner[i:i + b] for i in range(len(owner) - b + 1))
+    n = len(partner)
+    nd = (n - (24 - s)) // 16 + 1 if n >= 24 - s else 0
+    cnt, nxt = 0, 0
+    for p in range(0, 16 * nd, s):
+        if p >= nxt and partner[p:p + b] not in grams:
+            cnt += 1
+            nxt = p + b
+    return cnt

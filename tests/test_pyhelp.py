@@ -109,7 +109,7 @@ def check_invariant_partners(H):
     sys.path.insert(0, ROOT)
     from isocon_amd import end_invariant_functions as END
     rng = random.Random(13)
-    for thr in (0, 1, 5, 15, 20):
+    for thr in (0, 1, 5, 15, 20, 25, 40):
         for rep in range(60):
             L = rng.choice([0, 1, 3, 30, 120, 400])
             alpha = rng.choice(["ACGT", "AC", "A"])          # (short alphabets: repeats, many occurrences)
@@ -118,9 +118,11 @@ def check_invariant_partners(H):
             for _ in range(40):
                 r = rng.random()
                 cut_a, cut_b = rng.randint(0, thr + 3), rng.randint(0, thr + 3)
+                if thr > 16 and rng.random() < 0.4:            # lengths more than thr + 16 apart, still inside the caller's window of 2 thr
+                    cut_a, cut_b = rng.randint(thr + 17, 2 * thr), 0
                 t = base[cut_a:len(base) - cut_b] if r < 0.35 else base
                 if 0.35 <= r < 0.55:
-                    t = "".join(rng.choice(alpha) for _ in range(rng.randint(0, thr + 2))) + base[rng.randint(0, thr + 2):]
+                    t = "".join(rng.choice(alpha) for _ in range(rng.randint(0, thr + 2))) + base[rng.choice([rng.randint(0, thr + 2), cut_a]):]
                 elif 0.55 <= r < 0.75:
                     t = base[:len(base) - rng.randint(0, thr + 2)] + "".join(rng.choice(alpha) for _ in range(rng.randint(0, thr + 2)))
                 elif 0.75 <= r < 0.9 and t:
