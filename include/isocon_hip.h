@@ -66,6 +66,13 @@ int isocon_store_create(const uint8_t *ascii, const uint64_t *offsets, uint32_t 
  * has -- the library gathers them into its pinned staging buffer while the previous piece is on its way to the device, so the
  * caller does not have to build one contiguous copy first (125 MB at 50 000 x 2.5 kb). */
 int isocon_store_create_ptrs(const uint8_t *const *seq_ptrs, const uint64_t *seq_lens, uint32_t n, isocon_store **out);
+/* ... with options.  ISOCON_STORE_PRIVATE_SCRATCH: the store keeps a scratch pool of its own (bound matrix, held candidate edges, counters,
+ * released with the store) instead of the process-wide one -- for a process that drives SEVERAL searches side by side, each of which
+ * expects its scratch to survive the others' calls (the sharded protocol's phases: tests that run the ranks of isocon_amd/dist.py as
+ * threads of one process).  One process per GPU -- the reference's Pool workers (modules/nearest_neighbor_graph.py:30-72) are processes
+ * too -- needs no flag. */
+#define ISOCON_STORE_PRIVATE_SCRATCH 1u
+int isocon_store_create_ptrs_ex(const uint8_t *const *seq_ptrs, const uint64_t *seq_lens, uint32_t n, uint32_t flags, isocon_store **out);
 /* Pinned host memory for the caller's large input / output buffers (gapped alignments: 2 x 130 MB at 50 000 pairs): copies between
  * the device and these buffers skip the library's staging.  NULL if the allocation fails.  Ordinary memory works everywhere too. */
 void *isocon_host_alloc(uint64_t bytes);
@@ -89,7 +96,7 @@ int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const
                     int32_t *out_ed, float *kernel_ms);
 
 /*
- * Lower bounds of the pairs' edit distances from q-gram count profiles (isocon_amd/csrc/qgram_mm.hpp: 9-grams hashed into 24576
+ * Lower bounds of the pairs' edit distances from q-gram count profiles (isocon_amd/csrc/qgram_mm.hpp: 9-grams hashed into 16384
  * presence bins plus 2 levels of 2048 excess bins; isocon_qgram_params): out_bound[p] <= ed(a[p], b[p]) always.  The main pass of the
  * nearest-neighbour search skips a pair whose bound exceeds its threshold -- the pair edlib would have answered with -1
  * (modules/nearest_neighbor_graph.py:156-162).  The reference has no counterpart; exposed so that the bound can be tested by itself.
@@ -146,6 +153,7 @@ typedef struct {
     uint64_t pairs_bytes;         /* pairs with a sequence that holds symbols outside the 2-bit map, aligned on the bytes (see "Alphabet") */
     uint64_t pairs_block_rejected;/* survivors of the q-gram bound that the block filter rejected (greedy count of disjoint absent 8-grams > threshold; never aligned) */
     float filter_kernel_ms;       /* HIP-event time of the block filter (part of list_kernel_ms) */
+    float mm_kernel_ms;           /* ... of the bound matrix contraction k_qgram_mm alone (part of bound_kernel_ms) */
 } isocon_nn_stats;
 
 /*

@@ -35,7 +35,7 @@ class NNStats(ctypes.Structure):
                 ("list_kernel_ms", ctypes.c_float), ("lanes_kernel_ms", ctypes.c_float), ("narrow_kernel_ms", ctypes.c_float),
                 ("pairs_lanes", ctypes.c_uint64), ("bound_tiles", ctypes.c_uint64), ("pairs_wide_to_lanes", ctypes.c_uint64),
                 ("narrow_columns", ctypes.c_uint64), ("pairs_narrow", ctypes.c_uint64), ("pairs_bytes", ctypes.c_uint64),
-                ("pairs_block_rejected", ctypes.c_uint64), ("filter_kernel_ms", ctypes.c_float)]
+                ("pairs_block_rejected", ctypes.c_uint64), ("filter_kernel_ms", ctypes.c_float), ("mm_kernel_ms", ctypes.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -50,6 +50,7 @@ SYMBOLS = {
     "isocon_release_scratch": (None, []),
     "isocon_store_create": (ctypes.c_int, [u8p, u64p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
     "isocon_store_create_ptrs": (ctypes.c_int, [u64p, u64p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
+    "isocon_store_create_ptrs_ex": (ctypes.c_int, [u64p, u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
     "isocon_host_alloc": (ctypes.c_void_p, [ctypes.c_uint64]),
     "isocon_host_free": (None, [ctypes.c_void_p]),
     "isocon_store_destroy": (None, [ctypes.c_void_p]),

@@ -143,11 +143,12 @@ static uint64_t g_store_serial = 0;
 struct isocon_store {
     uint64_t serial = ++g_store_serial;
     DevStore dev;
-    // ISOCON_DEBUG_VARIANT=store_private_pool (read when the store is created): the store gets a scratch pool of its own, released with it --
+    // isocon_store_create_ptrs_ex(..., ISOCON_STORE_PRIVATE_SCRATCH): the store gets a scratch pool of its own, released with it --
     // for runs that emulate SEVERAL ranks inside one process (tests/baton_dist.py): a rank's bound matrix, held candidate edges and
     // counters must not be another rank's.  A real rank is a process, and its stores share the process' pool.
-    std::unique_ptr<ScratchPool> own_pool{variant("store_private_pool") ? new ScratchPool() : nullptr};
-    ScratchPool &pool = own_pool ? *own_pool : g_scratch;
+    explicit isocon_store(bool private_scratch = false) : own_pool(private_scratch ? new ScratchPool() : nullptr), pool(own_pool ? *own_pool : g_scratch) {}
+    std::unique_ptr<ScratchPool> own_pool;
+    ScratchPool &pool;
     std::vector<int32_t> lens;   // host copy
     uint64_t device_bytes = 0;
     uint64_t *d_planes = nullptr;
@@ -376,7 +377,7 @@ int isocon_init(int device_ordinal)
 // ascii != nullptr: one contiguous buffer addressed by offsets; else the sequences lie at seq_ptrs[i] (offsets still hold the prefix
 // sums of their lengths) and are gathered into the two halves of the pinned staging buffer, one half on its way to the device
 // while the other is being filled.
-static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptrs, const uint64_t *offsets, uint32_t n, isocon_store **out)
+static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptrs, const uint64_t *offsets, uint32_t n, isocon_store **out, bool private_scratch = false)
 {
     *out = nullptr;
     int32_t maxlen = 0;
@@ -389,7 +390,7 @@ static int store_create_impl(const uint8_t *ascii, const uint8_t *const *seq_ptr
     std::vector<int32_t> lens(nn, 0);
     for (uint32_t i = 0; i < n; ++i) lens[i] = (int32_t)(offsets[i + 1] - offsets[i]);
     const uint64_t base = n ? offsets[0] : 0, total = n ? offsets[n] - offsets[0] : 0;
-    isocon_store *st = new isocon_store();
+    isocon_store *st = new isocon_store(private_scratch);
     st->lens = lens;
     st->maxlen = maxlen;
     const size_t pbytes = (size_t)nchunks * nn * 2 * sizeof(uint64_t), lbytes = lens.size() * sizeof(int32_t);
@@ -581,6 +582,17 @@ int isocon_store_create_ptrs(const uint8_t *const *seq_ptrs, const uint64_t *seq
         offsets[i + 1] = offsets[i] + seq_lens[i];
     }
     return store_create_impl(nullptr, seq_ptrs, offsets.data(), n, out);
+}
+
+int isocon_store_create_ptrs_ex(const uint8_t *const *seq_ptrs, const uint64_t *seq_lens, uint32_t n, uint32_t flags, isocon_store **out)
+{
+    if (!out || (n && (!seq_ptrs || !seq_lens)) || (flags & ~(uint32_t)ISOCON_STORE_PRIVATE_SCRATCH)) return ISOCON_E_ARG;
+    std::vector<uint64_t> offsets((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (seq_lens[i] && !seq_ptrs[i]) return ISOCON_E_ARG;
+        offsets[i + 1] = offsets[i] + seq_lens[i];
+    }
+    return store_create_impl(nullptr, seq_ptrs, offsets.data(), n, out, (flags & ISOCON_STORE_PRIVATE_SCRATCH) != 0);
 }
 
 void *isocon_host_alloc(uint64_t bytes)

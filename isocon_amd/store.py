@@ -22,7 +22,9 @@ _utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
 class SeqStore(object):
     """Uploads a list of ACGT strings once; ids are positions in that list."""
 
-    def __init__(self, seqs):
+    def __init__(self, seqs, private_pool=False):
+        """private_pool: the store keeps its own scratch (bound matrix, held edges, counters) instead of the process-wide pool
+        (ISOCON_STORE_PRIVATE_SCRATCH): several ranks of the sharded search emulated inside one process, tests/baton_dist.py"""
         L = _lib.lib()
         self.n = len(seqs)
         h = ctypes.c_void_p()
@@ -36,7 +38,10 @@ class SeqStore(object):
             except ValueError as e:
                 raise _lib.IsoconError("isocon_store_create failed: %s" % e)
             self.lens = lens[:self.n].astype(np.int64)
-            _lib.check(L.isocon_store_create_ptrs(_ptr(ptrs, _lib.u64p), _ptr(lens, _lib.u64p), self.n, ctypes.byref(h)), "isocon_store_create")
+            if private_pool:
+                _lib.check(L.isocon_store_create_ptrs_ex(_ptr(ptrs, _lib.u64p), _ptr(lens, _lib.u64p), self.n, 1, ctypes.byref(h)), "isocon_store_create")
+            else:
+                _lib.check(L.isocon_store_create_ptrs(_ptr(ptrs, _lib.u64p), _ptr(lens, _lib.u64p), self.n, ctypes.byref(h)), "isocon_store_create")
         else:
             lens = np.fromiter(map(len, seqs), dtype=np.uint64, count=self.n)
             self.lens = lens.astype(np.int64)
@@ -50,8 +55,13 @@ class SeqStore(object):
             if joined and (not addr or size.value != int(off[self.n])):
                 raise _lib.IsoconError("isocon_store_create failed: sequence contains a symbol outside ACGT (non-ASCII character)")
             dummy = (ctypes.c_uint8 * 1)()
-            _lib.check(L.isocon_store_create(ctypes.cast(addr, _lib.u8p) if addr else dummy, _ptr(off, _lib.u64p), self.n, ctypes.byref(h)),
-                       "isocon_store_create")
+            if private_pool:
+                ptrs = (off[:-1] + np.uint64(addr or 0)).astype(np.uint64) if self.n else np.zeros(1, np.uint64)
+                lens64 = np.ascontiguousarray(lens if self.n else np.zeros(1, np.uint64), dtype=np.uint64)
+                _lib.check(L.isocon_store_create_ptrs_ex(_ptr(ptrs, _lib.u64p), _ptr(lens64, _lib.u64p), self.n, 1, ctypes.byref(h)), "isocon_store_create")
+            else:
+                _lib.check(L.isocon_store_create(ctypes.cast(addr, _lib.u8p) if addr else dummy, _ptr(off, _lib.u64p), self.n, ctypes.byref(h)),
+                           "isocon_store_create")
             del joined
         self._h = h
         self._L = L

@@ -181,9 +181,9 @@ def nn_1set(seqs, converged, start, count, depth=2 ** 32, packed=None):
     return _nn(lib().orc_nn_1set, seqs, converged, start, count, depth, packed)
 
 
-def nn_2set(seqs, is_target, start, count, depth=2 ** 32):
-    """C restatement of NNG:341-424; rows of target entries are empty."""
-    return _nn(lib().orc_nn_2set, seqs, is_target, start, count, depth)
+def nn_2set(seqs, is_target, start, count, depth=2 ** 32, packed=None):
+    """C restatement of NNG:341-424; rows of target entries are empty.  `packed` as in nn_1set."""
+    return _nn(lib().orc_nn_2set, seqs, is_target, start, count, depth, packed)
 
 
 _OPS = "=XID"

@@ -71,7 +71,7 @@ def classify(rows):
             calls[-1].append(r)
         prev = kind
     # one NN-graph step: k_qgram_profile4, k_qgram_mm, k_qgram_seed_pairs, k_ed_lanes<true> (seeds), k_nn_entry_meta, k_nn_survivors,
-    # k_nn_scan_refill (tables), k_ed_lanes<true> (entries with few pairs)
+    # k_nn_block_filter, [k_nn_scan_refill (tables) when enough chunks are left,] k_ed_lanes<true> (what the filter leaves + entries with few pairs)
     lanes = [r for r in rows if "k_ed_lanes<true>" in r[1]]
     for r in rows:
         # the two table launches of a step: the 64-row class (<.., false>) and the 32-row class (<.., true>)
@@ -83,6 +83,8 @@ def classify(rows):
             cls["nn_bound"] = [r]
         if "k_nn_survivors" in r[1] and "nn_lists" not in cls:
             cls["nn_lists"] = [r]
+        if "k_nn_block_filter" in r[1] and "nn_filter" not in cls:
+            cls["nn_filter"] = [r]
     if lanes:
         cls["nn_seed"] = lanes[:1]
     if len(lanes) > 1:
@@ -138,10 +140,10 @@ bj = os.path.join(out, "bench_sq_%s.json" % tag)
 if os.path.exists(bj) and "nn_main" in counters:
     try:
         line = [ln for ln in open(bj) if ln.startswith("{")][-1]
-        rl = json.loads(line)["roofline"]
+        rl = json.loads(line)["roofline"].get("table_pass") or {}          # (only when table launches ran: the block filter usually leaves them nothing)
         counters["nn_main"]["wave_columns"] = rl["wave_columns_this_run"]
-        if "nn_main_narrow" in counters and rl.get("narrow_pass"):
-            counters["nn_main_narrow"]["wave_columns"] = rl["narrow_pass"]["wave_columns_this_run"]
+        if "nn_main_narrow" in counters:
+            counters["nn_main_narrow"]["wave_columns"] = rl["narrow_wave_columns_this_run"]
     except Exception as ex:
         print("no wave_columns:", ex)
 lines.append("HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE doubled: gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md)")

@@ -23,15 +23,7 @@ def _sharded(seqs, world):
     from isocon_amd.store import SeqStore
     torch.cuda.set_device(0)
     # every emulated rank needs what a real rank's process has for itself: its own scratch pool (bound matrix, held edges, counters)
-    old = os.environ.get("ISOCON_DEBUG_VARIANT")
-    os.environ["ISOCON_DEBUG_VARIANT"] = "store_private_pool"
-    try:
-        stores = [SeqStore(seqs) for _ in range(world)]
-    finally:
-        if old is None:
-            del os.environ["ISOCON_DEBUG_VARIANT"]
-        else:
-            os.environ["ISOCON_DEBUG_VARIANT"] = old
+    stores = [SeqStore(seqs, private_pool=True) for _ in range(world)]
 
     def rank_main(dist, rank):
         torch.cuda.set_device(0)

@@ -14,12 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(n_gpus, extra_env):
+def _bench(n_gpus, extra_env, workload=("--reads", "6000", "--length", "1200", "--isoforms", "4", "--seed", "40001"), warmup=0):
     env = dict(os.environ)
     env.update(extra_env)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_gpus), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras",
-           "--reads", "6000", "--length", "1200", "--isoforms", "4", "--seed", "40001"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_gpus), "--steps", "1", "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras"] + list(workload)
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -34,6 +33,22 @@ def test_bench_two_ranks_equal_one_rank():
     for key in ("alignments_per_step", "edges", "median_nn_distance", "graph_digest"):
         assert one["config"][key] == two["config"][key], key
     assert two["scaling"] == "strong" and two["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_four_real_ranks_at_configuration_size():
+    """configs[3]'s launcher and collectives with REAL process groups at the size of the headline workload: `python bench.py --gpus 4` on C3
+    (50 000 x 2.5 kb), four processes started by bench.py's own launcher, each with its own HIP context on the one GPU of the test box,
+    torch.distributed collectives over gloo (RCCL refuses ranks that share a device) -- what the thread-baton emulation of
+    tests/test_gpu_configs3.py cannot exercise.  Every rank must hold the graph of fixture g17_c3 (bench.py exits non-zero otherwise; the
+    digest is asserted here too).  Four ranks, not eight: this pool allows at most six processes on a GPU box's card, and the test
+    runner itself is one of them."""
+    import bench
+    line = _bench(4, {"ISOCON_DIST_BACKEND": "gloo"}, workload=(), warmup=1)
+    assert line["n_gpus"] == 4 and line["rccl_ranks"] == 4 and line["dist_backend"] == "gloo"
+    assert len(line["per_rank_kernel_ms"]) == 4 and all(ms > 0 for ms in line["per_rank_kernel_ms"])
+    assert line["config"]["graph_digest"] == bench.EXPECTED_GRAPH_DIGEST_C3 and line["config"]["graph_equals_reference_loop_fixture"] is True
+    assert line["config"]["edges"] == 78526 and line["scaling"] == "strong"
 
 
 @pytest.mark.timeout(600)

@@ -353,10 +353,13 @@ def test_device_resident_phases_equal_the_single_call():
         st.close()
 
 
-def test_narrow_mode_on_reads_with_few_errors(monkeypatch):
+@pytest.mark.parametrize("tables", ["nn_no_block_filter", "nn_table_chunks=0,nn_list_min=16"])
+def test_narrow_mode_on_reads_with_few_errors(monkeypatch, tables):
     """Reads whose nearest neighbour is a few edits away: the list builder files nearly every pair under the 32-row class (thresholds
     <= 31), the few pairs above go to 64-row chunks or one per lane.  Same graph as with every pair on 64 rows (ISOCON_DEBUG_VARIANT=nn_narrow=0) and
-    as with the pairs above 31 forced out of the lists (=1), and the rows of some reads against the reference loop."""
+    as with the pairs above 31 forced out of the lists (=1), and the rows of some reads against the reference loop.
+    The table launches only run on what the block filter (csrc/nn_filter.hpp) leaves, and not at all when that is little: `tables` = without
+    the filter / with it and chunks of any size kept for the tables; the graph is also the default path's (filter, survivors one per lane)."""
     from isocon_amd import synth
     from isocon_amd.store import SeqStore
     from oracle import oracle as O
@@ -364,12 +367,16 @@ def test_narrow_mode_on_reads_with_few_errors(monkeypatch):
     seqs = sorted(dict.fromkeys(seqs), key=len)
     st = SeqStore(seqs)
     try:
+        default = st.nn_graph()
+        assert default[3]["pairs_block_rejected"] > 0
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", tables)
         got = st.nn_graph()
+        assert all((x == y).all() for x, y in zip(got[:3], default[:3]))
         assert got[3]["pairs_narrow"] > 0 and got[3]["narrow_columns"] > 0 and got[3]["narrow_kernel_ms"] > 0, got[3]
         assert got[3]["narrow_kernel_ms"] <= got[3]["scan_kernel_ms"] and got[3]["narrow_columns"] <= got[3]["cells_columns"]
-        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_narrow=0")
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", tables + ",nn_narrow=0")
         wide = st.nn_graph()
-        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_narrow=1")
+        monkeypatch.setenv("ISOCON_DEBUG_VARIANT", tables + ",nn_narrow=1")
         forced = st.nn_graph()
         monkeypatch.delenv("ISOCON_DEBUG_VARIANT")
         assert wide[3]["pairs_narrow"] == 0 and wide[3]["narrow_columns"] == 0 and wide[3]["pairs_wide_to_lanes"] == 0

@@ -125,13 +125,17 @@ def test_graph_with_the_filter_is_the_graph_without_it_and_the_filter_is_used():
         for env in ("nn_old_seed", "nn_waves=8", "nn_order=0", "nn_order=1", "nn_no_list", "nn_list_min=1", "nn_list_min=1000000", "nn_list_cap=1000",
                     "nn_list_waves=4", "nn_list_waves=8", "nn_host_finalize", "nn_narrow=1", "nn_narrow=0", "nn_narrow=1,nn_list_waves=4", "nn_narrow=0,nn_list_waves=4",
                     "nn_seed_classes=1", "nn_seed_classes=2"):
-            os.environ["ISOCON_DEBUG_VARIANT"] = env          # (the one switch behind which the A/B variants sit: DESIGN.md section 8)
-            try:
-                b2, r2, c2, s2 = st.nn_graph(is_converged=conv)
-            finally:
-                del os.environ["ISOCON_DEBUG_VARIANT"]
-            assert s2["pairs_prefiltered"] > 0
-            assert (best == b2).all() and (row_ptr == r2).all() and (cols == c2).all(), env
+            # ... each of them behind the block filter (csrc/nn_filter.hpp: default, the survivors one per lane), with the filter and the table
+            # launches on whatever it leaves, and without the filter (every survivor of the q-gram bound through the tables)
+            for tables in ("", ",nn_table_chunks=0", ",nn_no_block_filter"):
+                os.environ["ISOCON_DEBUG_VARIANT"] = env + tables          # (the one switch behind which the A/B variants sit: DESIGN.md section 8)
+                try:
+                    b2, r2, c2, s2 = st.nn_graph(is_converged=conv)
+                finally:
+                    del os.environ["ISOCON_DEBUG_VARIANT"]
+                assert s2["pairs_prefiltered"] > 0
+                assert (s2["pairs_block_rejected"] > 0) == (tables != ",nn_no_block_filter" and env not in ("nn_no_list", "nn_list_cap=1000")), (env, tables)
+                assert (best == b2).all() and (row_ptr == r2).all() and (cols == c2).all(), (env, tables)
         # the same with a finite depth and a strided shard (the row layout follows the launch slots)
         is_t = np.zeros(len(seqs), np.uint8); is_t[::5] = 1
         g1 = st.nn_graph(is_target=is_t)
