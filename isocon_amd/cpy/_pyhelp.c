@@ -630,6 +630,140 @@ fail:
     return NULL;
 }
 
+/* distance_dict(pairs: list[(k1, k2)], ed_addr: int (int32[len(pairs)])) -> {k1: {k2: ed}} in the pairs' order: the return value of
+ * edlib_align_sequences (edlib_alignment_module.py:42-49: every pair's distance filed under its two keys) without 50 000 rounds of the
+ * interpreter loop (13 of the call's 19 ms at C3). */
+static PyObject *distance_dict(PyObject *self, PyObject *args)
+{
+    PyObject *pairs;
+    unsigned long long ea;
+    if (!PyArg_ParseTuple(args, "OK", &pairs, &ea)) return NULL;
+    if (!PyList_CheckExact(pairs)) { PyErr_SetString(PyExc_TypeError, "distance_dict: a list of pairs is required"); return NULL; }
+    const int32_t *ed = (const int32_t *)(uintptr_t)ea;
+    const Py_ssize_t n = PyList_GET_SIZE(pairs);
+    PyObject *out = PyDict_New();
+    if (!out) return NULL;
+    PyObject *last_key = NULL, *last_row = NULL;          /* (consecutive pairs of one outer key: no second lookup) */
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *p = PyList_GET_ITEM(pairs, i);
+        if (!PyTuple_CheckExact(p) || PyTuple_GET_SIZE(p) != 2) { PyErr_Format(PyExc_TypeError, "pair %zd is not a 2-tuple", i); Py_DECREF(out); return NULL; }
+        PyObject *k1 = PyTuple_GET_ITEM(p, 0), *k2 = PyTuple_GET_ITEM(p, 1);
+        PyObject *row = k1 == last_key ? last_row : PyDict_GetItemWithError(out, k1);
+        if (!row) {
+            if (PyErr_Occurred()) { Py_DECREF(out); return NULL; }
+            row = PyDict_New();
+            if (!row || PyDict_SetItem(out, k1, row) < 0) { Py_XDECREF(row); Py_DECREF(out); return NULL; }
+            Py_DECREF(row);          /* (the outer dict holds it) */
+        }
+        last_key = k1; last_row = row;
+        PyObject *v = PyLong_FromLong((long)ed[i]);
+        if (!v || PyDict_SetItem(row, k2, v) < 0) { Py_XDECREF(v); Py_DECREF(out); return NULL; }
+        Py_DECREF(v);
+    }
+    return out;
+}
+
+/* pairs_of(matches: dict of (dict | set | frozenset | list | tuple), index: dict[str, int], a_addr, b_addr, cap) ->
+ * (outer: list, counts_addr-less: list[int], inner: list) or None: the (outer key, inner key) pairs of `matches` in iteration order WITHOUT a tuple
+ * per pair -- outer keys with at least one member, how many members each has, the members flat -- and their ids under `index` written to the
+ * uint32 arrays a / b (capacity cap pairs).  None when a key is not in `index` (the caller then packs its own store) or cap is too small.
+ * With distance_rows below: edlib_align_sequences (edlib_alignment_module.py:10-49) on 49 990 pairs in 10 instead of 16 ms. */
+static PyObject *pairs_of(PyObject *self, PyObject *args)
+{
+    PyObject *matches, *index;
+    unsigned long long aa, ba;
+    Py_ssize_t cap;
+    if (!PyArg_ParseTuple(args, "OOKKn", &matches, &index, &aa, &ba, &cap)) return NULL;
+    if (!PyDict_CheckExact(matches) || !PyDict_CheckExact(index)) { PyErr_SetString(PyExc_TypeError, "pairs_of: two dicts are required"); return NULL; }
+    uint32_t *a = (uint32_t *)(uintptr_t)aa, *b = (uint32_t *)(uintptr_t)ba;
+    PyObject *outer = PyList_New(0), *counts = PyList_New(0), *inner_keys = PyList_New(0);
+    if (!outer || !counts || !inner_keys) goto fail;
+    {
+        Py_ssize_t pos = 0, n = 0;
+        PyObject *k1, *inner;
+        while (PyDict_Next(matches, &pos, &k1, &inner)) {
+            /* only containers whose iteration runs no Python code (it could change `matches` under PyDict_Next) */
+            if (!PyDict_CheckExact(inner) && !PyAnySet_CheckExact(inner) && !PyList_CheckExact(inner) && !PyTuple_CheckExact(inner)) {
+                PyErr_SetString(PyExc_TypeError, "pairs_of: inner values must be dict, set, frozenset, list or tuple");
+                goto fail;
+            }
+            PyObject *v1 = NULL;
+            Py_ssize_t cnt = 0;
+            PyObject *it = PyObject_GetIter(inner);
+            if (!it) goto fail;
+            PyObject *k2;
+            while ((k2 = PyIter_Next(it)) != NULL) {
+                if (!v1) v1 = PyDict_GetItemWithError(index, k1);
+                PyObject *v2 = v1 ? PyDict_GetItemWithError(index, k2) : NULL;
+                if (!v1 || !v2 || n >= cap) {
+                    Py_DECREF(k2); Py_DECREF(it);
+                    if (PyErr_Occurred()) goto fail;
+                    Py_DECREF(outer); Py_DECREF(counts); Py_DECREF(inner_keys);
+                    Py_RETURN_NONE;
+                }
+                const unsigned long x1 = PyLong_AsUnsignedLong(v1), x2 = PyLong_AsUnsignedLong(v2);
+                if ((x1 == (unsigned long)-1 || x2 == (unsigned long)-1) && PyErr_Occurred()) { Py_DECREF(k2); Py_DECREF(it); goto fail; }
+                a[n] = (uint32_t)x1; b[n] = (uint32_t)x2; ++n; ++cnt;
+                const int rc = PyList_Append(inner_keys, k2);
+                Py_DECREF(k2);
+                if (rc < 0) { Py_DECREF(it); goto fail; }
+            }
+            Py_DECREF(it);
+            if (PyErr_Occurred()) goto fail;
+            if (cnt) {
+                PyObject *c = PyLong_FromSsize_t(cnt);
+                if (!c || PyList_Append(outer, k1) < 0 || PyList_Append(counts, c) < 0) { Py_XDECREF(c); goto fail; }
+                Py_DECREF(c);
+            }
+        }
+    }
+    {
+        PyObject *out = PyTuple_Pack(3, outer, counts, inner_keys);
+        Py_DECREF(outer); Py_DECREF(counts); Py_DECREF(inner_keys);
+        return out;
+    }
+fail:
+    Py_XDECREF(outer); Py_XDECREF(counts); Py_XDECREF(inner_keys);
+    return NULL;
+}
+
+/* distance_rows(outer: list, counts: list[int], inner: list, ed_addr: int (int32[len(inner)])) -> {outer[r]: {inner[p]: ed[p]}}: the rows of
+ * pairs_of with their distances (a key that occurs again keeps its dict and gets the later values, as the reference's loop would) */
+static PyObject *distance_rows(PyObject *self, PyObject *args)
+{
+    PyObject *outer, *counts, *inner;
+    unsigned long long ea;
+    if (!PyArg_ParseTuple(args, "OOOK", &outer, &counts, &inner, &ea)) return NULL;
+    if (!PyList_CheckExact(outer) || !PyList_CheckExact(counts) || !PyList_CheckExact(inner) || PyList_GET_SIZE(outer) != PyList_GET_SIZE(counts)) {
+        PyErr_SetString(PyExc_TypeError, "distance_rows: three lists (outer keys, their counts, inner keys) are required");
+        return NULL;
+    }
+    const int32_t *ed = (const int32_t *)(uintptr_t)ea;
+    const Py_ssize_t n_in = PyList_GET_SIZE(inner);
+    PyObject *out = PyDict_New();
+    if (!out) return NULL;
+    Py_ssize_t p = 0;
+    for (Py_ssize_t r = 0; r < PyList_GET_SIZE(outer); ++r) {
+        const Py_ssize_t cnt = PyLong_AsSsize_t(PyList_GET_ITEM(counts, r));
+        if (cnt < 0 || p + cnt > n_in) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "distance_rows: counts do not match the inner keys"); Py_DECREF(out); return NULL; }
+        PyObject *k1 = PyList_GET_ITEM(outer, r);
+        PyObject *row = PyDict_GetItemWithError(out, k1);
+        if (!row) {
+            if (PyErr_Occurred()) { Py_DECREF(out); return NULL; }
+            row = PyDict_New();
+            if (!row || PyDict_SetItem(out, k1, row) < 0) { Py_XDECREF(row); Py_DECREF(out); return NULL; }
+            Py_DECREF(row);
+        }
+        for (Py_ssize_t e = 0; e < cnt; ++e, ++p) {
+            PyObject *v = PyLong_FromLong((long)ed[p]);
+            if (!v || PyDict_SetItem(row, PyList_GET_ITEM(inner, p), v) < 0) { Py_XDECREF(v); Py_DECREF(out); return NULL; }
+            Py_DECREF(v);
+        }
+    }
+    if (p != n_in) { PyErr_SetString(PyExc_ValueError, "distance_rows: counts do not match the inner keys"); Py_DECREF(out); return NULL; }
+    return out;
+}
+
 /* alignment_dict(pairs: list[(k1, k2)], aln_a: list[str], aln_b: list[str], res_addr: int (int32[n][6]: .., matches, mismatches, indels)) ->
  * (out: list of (aln_a[p], aln_b[p], (matches, mismatches, indels)), d: {k1: {k2: out[p]}}): the return value of sw_align_sequences
  * (SW_alignment_module.py:146-164: every pair's stats filed under its two keys) and the flat list of the same tuple objects. */
@@ -765,6 +899,9 @@ static PyMethodDef methods[] = {
     {"lazy_rows_intact", lazy_rows_intact, METH_VARARGS, "the values of a partition are still the lazily expanded alignments filed there"},
     {"unique_values_by_length", unique_values_by_length, METH_VARARGS, "unique values of a dict, stably sorted by length, with their last keys"},
     {"flatten_pairs", flatten_pairs, METH_VARARGS, "(outer key, inner key) pairs of a dict of dicts / sets, and the inner values"},
+    {"distance_dict", distance_dict, METH_VARARGS, "dict of dicts of the distances of a list of pairs"},
+    {"pairs_of", pairs_of, METH_VARARGS, "pairs of a dict of containers without a tuple per pair, and their ids"},
+    {"distance_rows", distance_rows, METH_VARARGS, "dict of dicts of the distances of the rows of pairs_of"},
     {"alignment_dict", alignment_dict, METH_VARARGS, "alignment tuples and the dict of dicts that files them under their pairs"},
     {"lazy_rows", lazy_rows, METH_VARARGS, "files lazily expanded alignment values under their centres"},
     {"group_keys_by_value", group_keys_by_value, METH_VARARGS, "{value: [keys]} of a dict, in insertion order"},

@@ -83,8 +83,10 @@ __device__ __forceinline__ uint64_t plane_bits64(const uint64_t *planes, uint32_
 // POL0: the three cell-level tie rules are parasail's (policy bits 0, 1, 4 clear); EXT0: gap extension costs 0
 // (the reference's alignment call, SW_alignment_module.py:64).  Both are compile-time so the common case drops the
 // corresponding subtractions.
+// (register budget: four waves per SIMD for the reference's own call -- policy 0, extension 0: 119 registers --, three for the general form,
+// whose seven per-cell constants do not fit 128 without scratch)
 template <int R, bool POL0, bool EXT0>
-__global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *__restrict__ pairs, SgParams prm,
+__global__ __launch_bounds__(64, (POL0 && EXT0) ? 4 : 3) void k_sg_forward(DevStore S, const SgPair *__restrict__ pairs, SgParams prm,
                                                     uint8_t *__restrict__ trace, int2 *__restrict__ bound_all,
                                                     int32_t *__restrict__ endinfo)
 {
@@ -114,8 +116,10 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
     const uint64_t *planes = S.planes;
     const uint32_t nseq = S.n;
     const int32_t nchunks = (int32_t)S.nchunks;
-    int2 *bound = bound_all + pr.bound_off;
-    uint8_t *tbase = trace + pr.trace_off;
+    // (wave-uniform offsets through the scalar unit: as vector values the two pointers were spilled around every pass of the <.., false, false> form)
+    auto uniform_u64 = [](uint64_t v) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); };
+    int2 *bound = bound_all + uniform_u64(pr.bound_off);
+    uint8_t *tbase = trace + uniform_u64(pr.trace_off);
     const int32_t steps = uniform_i32(pr.steps);
     const int32_t dlo = uniform_i32(pr.dlo), dhi = uniform_i32(pr.dhi);
     const int32_t passes = (m + 64 * R - 1) / (64 * R);
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
                 const uint32_t eq = (uint32_t)(~(qlo ^ slo) & ~(qhi ^ shi));
                 int32_t diag = (!INTERIOR && j == jlo) ? left0 : diag_in;   // left boundary column: H[.][-1] = 0 / outside the window
                 uint32_t tw = 0;
+                int32_t hv_last = SG_NEG;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int32_t Hl = Hp[r], El = Ep[r];
@@ -228,14 +233,16 @@ __global__ __launch_bounds__(64, 4) void k_sg_forward(DevStore S, const SgPair *
                     Ep[r] = Ev;
                     Hup = Hv;
                     Fup = Fv;
+                    // the cell of the last query row, picked from the VALUE just computed: a select chain over Hp[r] is turned into ONE load
+                    // at a dynamic index by the compiler (select of loads -> load of select), which keeps Hp[] out of the registers -- it
+                    // then lived in LDS and every step of every pass wrote it there (2 x ds_write_b128 per step: 1.25e8 LDS instructions and
+                    // 8.1e8 bank-conflict cycles per 4 096 full-matrix pairs, profiles/r05sz_pmc_summary.txt)
+                    if (!INTERIOR) hv_last = (r == rstar) ? Hv : hv_last;
                 }
                 // end-cell candidates.  Both guards are WAVE-UNIFORM on purpose (scalar branches): left to itself the
                 // compiler if-converts these blocks into ~180 predicated instructions that run on every step.
                 if (!INTERIOR && pass == pstar) {                      // last query row: lane lstar, row rstar of this pass
-                    // (a select chain on the uniform rstar: indexing Hp[] dynamically would demote it to scratch)
-                    int32_t hv = Hp[0];
-#pragma unroll
-                    for (int r = 1; r < R; ++r) hv = (r == rstar) ? Hp[r] : hv;
+                    const int32_t hv = hv_last;
                     if (lane == lstar) {
                         if (hv > rowbest) { rowbest = hv; rowj_first = j; rowj_last = j; }
                         else if (hv == rowbest) rowj_last = j;

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import perf_log
+from . import _lib, perf_log
 from .store import SeqStore, store_for_pairs
 
 
@@ -46,6 +46,33 @@ def _distances(pairs):
 
 def edlib_align_sequences(matches, nr_cores=1):
     """EAM:10-49.  {s1: iterable(s2)} -> {s1: {s2: ed}} keyed by the sequences; keys without members are absent."""
+    H = _lib.pyhelp()
+    if H is not None and hasattr(H, "pairs_of") and type(matches) is dict and matches:
+        # on the store the NN graph remembered (the pipeline's case, isocon_get_candidates.py:129-130,38): pairs, ids and the dict of dicts in C
+        # without a tuple per pair (cpy/_pyhelp.c): 19 -> 10 ms for the 49 990 partition pairs of C3
+        from . import store as _store
+        st, index = _store._RECENT["store"], _store._RECENT["index"]
+        if st is not None and index is not None and getattr(st, "_h", None):
+            n = sum(len(v) for v in matches.values())
+            a = np.empty(max(n, 1), dtype=np.uint32)
+            b = np.empty(max(n, 1), dtype=np.uint32)
+            rows = H.pairs_of(matches, index.mapping(), a.ctypes.data, b.ctypes.data, n)
+            if rows is not None:
+                outer, counts, inner = rows
+                if not inner:
+                    return {}
+                with perf_log.call("edlib_alignment_module.distances", pairs=len(inner)) as rec:
+                    ed, ms = st.ed_pairs(a[:len(inner)], b[:len(inner)], None, return_ms=True)
+                    rec.add(kernel_ms=ms)
+                assert (ed >= 0).all()  # EAM:113
+                ed = np.ascontiguousarray(ed, dtype=np.int32)
+                return H.distance_rows(outer, counts, inner, ed.ctypes.data)
+    if H is not None and hasattr(H, "distance_dict") and type(matches) is dict and matches and \
+            all(type(v) in (set, frozenset, list, tuple, dict) for v in matches.values()) and len(set(type(v) is dict for v in matches.values())) == 1:
+        # the pair list, the ids and the dict of dicts in C (cpy/_pyhelp.c): 19 -> 6 ms for the 49 990 partition pairs of C3
+        pairs = H.flatten_pairs(matches)[0]
+        ed = np.ascontiguousarray(_distances(pairs), dtype=np.int32)
+        return H.distance_dict(pairs, ed.ctypes.data)
     pairs = [(s1, s2) for s1 in matches for s2 in matches[s1]]
     ed = _distances(pairs)
     exact_edit_distances = {}

@@ -297,6 +297,52 @@ def check_flatten_pairs(H):
         H.flatten_pairs([("x", "p")])
 
 
+def check_distance_dict(H):
+    pairs = [("x", "p"), ("x", "q"), ("y", "p"), ("x", "r"), ("y", "p")]          # an outer key that comes back, a pair filed twice (the last wins, as in the loop)
+    ed = np.array([3, 0, 700, -1, 5], dtype=np.int32)
+    d = H.distance_dict(pairs, ed.ctypes.data)
+    want = {}
+    for (a, b), v in zip(pairs, ed.tolist()):
+        want.setdefault(a, {})[b] = v
+    assert d == want and list(d) == ["x", "y"] and list(d["x"]) == ["p", "q", "r"] and type(d["x"]["p"]) is int
+    assert H.distance_dict([], ed.ctypes.data) == {}
+    with pytest.raises(TypeError):
+        H.distance_dict([("x",)], ed.ctypes.data)
+    with pytest.raises(TypeError):
+        H.distance_dict((("x", "p"),), ed.ctypes.data)
+    with pytest.raises(TypeError):          # an unhashable key
+        H.distance_dict([(["x"], "p")], ed.ctypes.data)
+
+
+def check_pairs_of(H):
+    index = {"x": 0, "y": 1, "p": 2, "q": 3, "r": 4}
+    m = {"x": {"p": 1, "q": 2}, "y": set(), "q": ["r", "r", "x"], "p": ("y",)}
+    a = np.full(8, 99, np.uint32); b = np.full(8, 99, np.uint32)
+    outer, counts, inner = H.pairs_of(m, index, a.ctypes.data, b.ctypes.data, 8)
+    assert outer == ["x", "q", "p"] and counts == [2, 3, 1] and inner == ["p", "q", "r", "r", "x", "y"]
+    assert a[:6].tolist() == [0, 0, 3, 3, 3, 2] and b[:6].tolist() == [2, 3, 4, 4, 0, 1] and a[6] == 99
+    ed = np.array([5, 6, 7, 8, 9, 10], dtype=np.int32)
+    d = H.distance_rows(outer, counts, inner, ed.ctypes.data)
+    want = {}
+    p = 0
+    for k1, inn in m.items():
+        for k2 in inn:
+            want.setdefault(k1, {})[k2] = int(ed[p]); p += 1
+    assert d == want and list(d) == ["x", "q", "p"] and list(d["q"]) == ["r", "x"]
+    assert H.pairs_of({"x": {"zz"}}, index, a.ctypes.data, b.ctypes.data, 8) is None          # a member the store does not hold
+    assert H.pairs_of({"zz": {"x"}}, index, a.ctypes.data, b.ctypes.data, 8) is None
+    assert H.pairs_of(m, index, a.ctypes.data, b.ctypes.data, 3) is None                       # capacity
+    assert H.pairs_of({}, index, a.ctypes.data, b.ctypes.data, 8) == ([], [], [])
+    with pytest.raises(TypeError):
+        H.pairs_of({"x": 5}, index, a.ctypes.data, b.ctypes.data, 8)
+    with pytest.raises(TypeError):
+        H.pairs_of({"x": (c for c in "pq")}, index, a.ctypes.data, b.ctypes.data, 8)
+    with pytest.raises(ValueError):
+        H.distance_rows(outer, [2, 3, 2], inner, ed.ctypes.data)
+    with pytest.raises(TypeError):
+        H.distance_rows(outer, counts[:2], inner, ed.ctypes.data)
+
+
 def check_alignment_dict(H):
     pairs = [("x", "p"), ("x", "q"), ("y", "p")]
     la, lb = ["A-C", "GG", ""], ["AAC", "G-", ""]
@@ -351,6 +397,14 @@ def test_unique_values_by_length():
 
 def test_flatten_pairs():
     check_flatten_pairs(_helper())
+
+
+def test_distance_dict():
+    check_distance_dict(_helper())
+
+
+def test_pairs_of():
+    check_pairs_of(_helper())
 
 
 def test_alignment_dict():
@@ -418,6 +472,6 @@ def test_under_address_and_undefined_sanitizers(tmp_path):
                ISOCON_PYHELP_UNDER_TEST=so)
     code = ("import sys; sys.path.insert(0, %r); import test_pyhelp as T; H = T._helper(); "
             "T.check_group_keys_by_value(H); T.check_rank_strings(H); T.check_str_pointers(H); T.check_split_ascii(H); T.check_split_ascii_rows(H); T.check_invariant_partners(H); T.check_best_solution(H); T.check_csr_to_dict(H); T.check_pair_ids(H); "
-            "T.check_unique_values_by_length(H); T.check_flatten_pairs(H); T.check_alignment_dict(H); T.check_lazy_rows(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
+            "T.check_unique_values_by_length(H); T.check_flatten_pairs(H); T.check_distance_dict(H); T.check_pairs_of(H); T.check_alignment_dict(H); T.check_lazy_rows(H); print('sanitized ok')" % os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
