@@ -139,7 +139,7 @@ def _align_pairs_impl(pairs, mismatch, match_score, opening_penalty, gap_ext, ed
         if want_dict and hasattr(H, "alignment_dict") and isinstance(pairs, list):
             # the result tuples and the dict of dicts that files them under their pairs, in one pass (SWM:146-164)
             res_c = np.ascontiguousarray(res, dtype=np.int32)
-            out, filed = H.alignment_dict(pairs, sa, sb, res_c.ctypes.data)
+            out, filed = H.alignment_dict(pairs, sa, sb, res_c.ctypes.data, len(res_c))
             _OPS_CACHE.set(out, ops, ops_ptr)
             return out, filed
         counts = list(zip(res[:, 3].tolist(), res[:, 4].tolist(), res[:, 5].tolist()))          # (matches, mismatches, indels) tuples

@@ -304,7 +304,7 @@ def _correct_all_from_ops(batch, partition_alignments, centres, seq_to_acc):
             # the corrected rows only, equal ones as ONE str object (they converge on their consensus: every dict built over them
             # afterwards hashes an object once and compares by identity first)
             off64, sel = np.ascontiguousarray(off, dtype=np.int64), np.ascontiguousarray(todo, dtype=np.int64)
-            strs_todo = H.split_ascii_rows(packed.ctypes.data, off64.ctypes.data, sel.ctypes.data, len(sel))
+            strs_todo = H.split_ascii_rows(packed.ctypes.data, off64.ctypes.data, len(off64) - 1, sel.ctypes.data, len(sel))
         else:
             flat = packed[:off[n_rows]].tobytes().decode()
             strs_todo = [flat[off[r]:off[r + 1]] for r in rows_todo]

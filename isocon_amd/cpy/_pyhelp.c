@@ -128,15 +128,15 @@ static void *rowhash_worker(void *arg)
 static PyObject *split_ascii_rows(PyObject *self, PyObject *args)
 {
     unsigned long long ba, pa, ra;
-    Py_ssize_t k;
-    if (!PyArg_ParseTuple(args, "KKKn", &ba, &pa, &ra, &k)) return NULL;
+    Py_ssize_t k, n_rows;
+    if (!PyArg_ParseTuple(args, "KKnKn", &ba, &pa, &n_rows, &ra, &k)) return NULL;
     const char *buf = (const char *)(uintptr_t)ba;
-    const int64_t *ptr = (const int64_t *)(uintptr_t)pa;
+    const int64_t *ptr = (const int64_t *)(uintptr_t)pa;          /* n_rows + 1 offsets */
     const int64_t *rows = (const int64_t *)(uintptr_t)ra;
-    if (k < 0) { PyErr_SetString(PyExc_ValueError, "split_ascii_rows: negative count"); return NULL; }
+    if (k < 0 || n_rows < 0) { PyErr_SetString(PyExc_ValueError, "split_ascii_rows: negative count"); return NULL; }
     int64_t total = 0;
     for (Py_ssize_t i = 0; i < k; ++i) {
-        const int64_t len = rows[i] < 0 ? -1 : ptr[rows[i] + 1] - ptr[rows[i]];
+        const int64_t len = (rows[i] < 0 || rows[i] >= (int64_t)n_rows) ? -1 : ptr[rows[i] + 1] - ptr[rows[i]];
         if (len < 0) { PyErr_SetString(PyExc_ValueError, "split_ascii_rows: bad row or descending offsets"); return NULL; }
         total += len;
     }
@@ -771,12 +771,14 @@ static PyObject *alignment_dict(PyObject *self, PyObject *args)
 {
     PyObject *pairs, *la, *lb;
     unsigned long long ra;
-    if (!PyArg_ParseTuple(args, "OOOK", &pairs, &la, &lb, &ra)) return NULL;
+    Py_ssize_t n_res;
+    if (!PyArg_ParseTuple(args, "OOOKn", &pairs, &la, &lb, &ra, &n_res)) return NULL;
     if (!PyList_Check(pairs) || !PyList_Check(la) || !PyList_Check(lb) || PyList_GET_SIZE(la) != PyList_GET_SIZE(pairs) ||
         PyList_GET_SIZE(lb) != PyList_GET_SIZE(pairs)) {
         PyErr_SetString(PyExc_TypeError, "alignment_dict: three lists of one length are required");
         return NULL;
     }
+    if (n_res < PyList_GET_SIZE(pairs)) { PyErr_SetString(PyExc_ValueError, "alignment_dict: fewer result rows than pairs"); return NULL; }
     const int32_t *res = (const int32_t *)(uintptr_t)ra;
     const Py_ssize_t n = PyList_GET_SIZE(pairs);
     PyObject *out = PyList_New(n), *d = PyDict_New();
@@ -824,13 +826,17 @@ static PyObject *lazy_rows(PyObject *self, PyObject *args)
 {
     PyObject *cls, *batch, *pairs, *out, *rows_of;
     unsigned long long ka, ea;
-    if (!PyArg_ParseTuple(args, "OOOKKOO", &cls, &batch, &pairs, &ka, &ea, &out, &rows_of)) return NULL;
+    Py_ssize_t n_arr;
+    if (!PyArg_ParseTuple(args, "OOOKKnOO", &cls, &batch, &pairs, &ka, &ea, &n_arr, &out, &rows_of)) return NULL;
     if (!PyList_Check(pairs) || !PyDict_Check(out) || !PyDict_Check(rows_of)) { PyErr_SetString(PyExc_TypeError, "lazy_rows: list, dict, dict"); return NULL; }
     const uint8_t *keep = (const uint8_t *)(uintptr_t)ka;
     const int32_t *edit = (const int32_t *)(uintptr_t)ea;
     const Py_ssize_t n = PyList_GET_SIZE(pairs);
+    if (n_arr != n) { PyErr_SetString(PyExc_ValueError, "lazy_rows: keep / edit hold another number of entries than pairs"); return NULL; }
     Py_ssize_t made = 0;
     for (Py_ssize_t p = 0; p < n; ++p) {
+        /* (cls(...) below runs Python code: it must not have shortened the list) */
+        if (PyList_GET_SIZE(pairs) != n) { PyErr_SetString(PyExc_RuntimeError, "lazy_rows: pairs changed size during the call"); return NULL; }
         if (!keep[p]) continue;
         PyObject *pr = PyList_GET_ITEM(pairs, p);
         if (!PyTuple_Check(pr) || PyTuple_GET_SIZE(pr) < 2) { PyErr_Format(PyExc_TypeError, "pair %zd is not a 2-tuple", p); return NULL; }

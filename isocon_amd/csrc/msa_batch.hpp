@@ -104,7 +104,11 @@ __global__ __launch_bounds__(256) void k_msab_fill(DevStore S, MsaBatch B, const
         // its own op's record, ONE atomic per batch reserves the records (one atomic per record -- 6 10^5 on one address at C3 -- was what the
         // kernel's 3.7 ms were: same-address atomics serialise in L2).
         {
-            const bool wide_l = (uint32_t)lane < n_here && code_l == 3u && t_l <= Lm && longest[t_l] > 1u;
+            // (a malformed op stream -- an op that runs past the member row -- ends the row at that op below: the records of the ops behind it
+            // are not listed either: the lanes in front of the first op that fails the bound)
+            const unsigned long long bad = __ballot((uint32_t)lane < n_here && t_l + (code_l == 3u ? 0u : len_l) > Lm);
+            const bool before_bad = bad == 0ull || (uint32_t)lane < (uint32_t)__builtin_ctzll(bad);
+            const bool wide_l = before_bad && (uint32_t)lane < n_here && code_l == 3u && t_l <= Lm && longest[t_l] > 1u;
             const unsigned long long wm = __ballot(wide_l);
             if (wm != 0ull) {
                 unsigned long long at0 = 0;

@@ -44,7 +44,7 @@ struct NNParams {
     const struct NNChunk *chunks;
     const uint32_t *list;          // partner | 0x40000000 (the chunk's entry queries it) | 0x80000000 (it queries the chunk's entry)
     // 1: best[] holds FIXED thresholds -- every pair within its query's threshold is a hit and nothing is tightened (the collecting pass
-    // over a set whose planes are class-merged images of the sequences, nn_host.inc: nn_phase_a_images)
+    // over a set whose planes are class-merged images of the sequences, nn_images.inc: nn_phase_a_images)
     int32_t fixed;
 };
 
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_filter_hits(const int32_t *__restrict__
 //
 // Neighbours are drawn 64 at a time from a workgroup-wide counter, filtered (roles, |length difference| <= threshold and,
 // when the launch comes with them, the pair's q-gram lower bound <= threshold: qgram.hpp) with coalesced loads, and queued
-// in a small per-wave ring in LDS.  With the bounds the host launches 4 waves per table instead of 8 (nn_host.inc) and may
+// in a small per-wave ring in LDS.  With the bounds the host launches 4 waves per table instead of 8 (nn_main.inc) and may
 // hand the workgroups their entries widest window first (P.slot_order).
 static constexpr int NN_RING = 96;       // entries per wave (8 B each)
 static constexpr int NN_TEXT_PAD_FRONT = 4, NN_TEXT_PAD_BACK = 6;     // dwords around each sequence of the nibble store

@@ -1,7 +1,7 @@
 // nn_finalize.hpp -- the CSR of the nearest-neighbour graph on the device: the hits that attain their endpoint's minimum, bucketed by
 // endpoint, every row in the reference's insertion order (ascending offset, the lower neighbour before the upper:
 // /root/reference/modules/nearest_neighbor_graph.py:155-178), duplicates dropped.  Same result as the host routine nn_finalize_impl
-// (nn_host.inc), which stays for small inputs, for rows longer than NN_FIN_MAX_ROW and as the checker of tests/.
+// (nn_finalize_host.hpp), which stays for small inputs, for rows longer than NN_FIN_MAX_ROW and as the checker of tests/.
 #pragma once
 #include "nn_list.hpp"
 

@@ -2,7 +2,7 @@
 // streaming pass over the bound matrix, the alignment kernels only see survivors, and every survivor is aligned against the
 // match-mask table of whichever of its two ends has more pairs.
 //
-// Why (C3, 50 000 reads, measured: scripts/dev/survivor_graph.py): of the 3.5 10^8 window pairs ~1.1 10^7 survive (bound <= threshold),
+// Why (C3, 50 000 reads, measured: profiles/r03b_survivor_graph.txt): of the 3.5 10^8 window pairs ~1.1 10^7 survive (bound <= threshold),
 // and they are spread very unevenly -- per entry as the lower index: median 22, 75 % 123, 90 % 449, 99 % 3 716, largest 10 904 (reads with
 // few errors are near everybody).  A workgroup per entry that walks its whole window inside the alignment kernel (~110 batches of
 // dependent loads per entry) spends its life finding 22 pairs and then runs them on 256 lanes; a 48 KB table in LDS pays only
@@ -16,7 +16,7 @@
 //                       threshold from the same best[], bound); the pairs it owns are staged in LDS and leave as chunks of a list
 //                       (one k_nn_scan_refill workgroup per chunk: the entry's table in LDS, lanes refilled from the chunk) or, for
 //                       entries with few pairs, as flat pairs for the one-pair-per-lane kernel (ed_lanes.hpp: no table);
-//   2. the two alignment launches (nn_host.inc).
+//   2. the block filter on the chunks (nn_filter.hpp), then the alignment launches on what it leaves (nn_lists.inc, nn_main.inc).
 // The pair set is exactly the one the in-kernel admission evaluates, so the graph is unchanged; replaces the window walk of
 // /root/reference/modules/nearest_neighbor_graph.py:136-178.
 #pragma once

@@ -16,7 +16,7 @@
 // the i8 rate, at 4 bits per element (scripts/ubench/mfma_fp4.hip: operand layout checked with asymmetric data, 40 cycles per
 // MFMA at the nominal clock).  The v_sad_u8 kernel this replaces moved 308 B per pair and took 17.6 ms at C3.
 //
-// Parameters (scripts/dev/qgram_mm_study.py, C3, final thresholds; survivors per query / K): 8-grams in 6144 byte bins, what the
+// Parameters (profiles/r03a_qgram_mm_study_mixed.txt, C3, final thresholds; survivors per query / K): 8-grams in 6144 byte bins, what the
 // v_sad_u8 kernel used: 396; uniform thermometer 6144 x 3: 456 / 18432; 16384 x 2: 271 / 32768; see DESIGN.md for the mixed designs.
 #pragma once
 #include "common.hpp"
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
 #endif
 }
 
-// Row layout of the transposed matrix (nn_host.inc, build_bounds): for entry p the launch slots whose window holds p -- the slots s with
+// Row layout of the transposed matrix (nn_bounds.inc, build_bounds): for entry p the launch slots whose window holds p -- the slots s with
 // q(s) < p <= q(s) + row_len[s], a run because both q(s) and q(s) + row_len[s] ascend with s: sloT[p] = its first slot, lenT[p] = its
 // length, padT[p] = the bytes of its storage (from slot sloT & ~15 to the next multiple of 16 behind its last slot).  k_lbt_offsets
 // turns the exclusive prefix sums of padT into the address of the first slot.

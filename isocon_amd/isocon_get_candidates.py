@@ -137,7 +137,7 @@ def _partition_alignments_from_ops(graph_partition, M, G_star, exon_filtered, pa
         if H is not None and hasattr(H, "lazy_rows") and all(m in out for m in graph_partition):
             keep_c = np.ascontiguousarray(keep, dtype=np.uint8)
             edit_c = np.ascontiguousarray(res[:, 4] + res[:, 5], dtype=np.int32)
-            H.lazy_rows(LazyAlignment, batch, pairs, keep_c.ctypes.data, edit_c.ctypes.data, out, batch.rows_of)
+            H.lazy_rows(LazyAlignment, batch, pairs, keep_c.ctypes.data, edit_c.ctypes.data, min(len(keep_c), len(edit_c)), out, batch.rows_of)
         else:
             for p in np.flatnonzero(keep).tolist():
                 m, s = pairs[p]

@@ -43,7 +43,7 @@ for world in (2, 4, 8):
                 qb, qe, qs, qk = r, n, world, 1
             if ph == 1 and not os.environ.get("NO_REUSE"):
                 # A real rank is a process of its own: the bound matrix its phase 0 built is still in its scratch pool when phase 1 starts and is
-                # reused (csrc/nn_host.inc: bound_tag).  Here all ranks share ONE pool, so the rank's phase 0 is repeated (untimed, results dropped)
+                # reused (csrc/nn_bounds.inc: bound_tag).  Here all ranks share ONE pool, so the rank's phase 0 is repeated (untimed, results dropped)
                 # to put its matrix back.  NO_REUSE=1: as before round 4's last measurements (every phase 1 rebuilds its matrix: + 1.2 ms at 8 ranks).
                 st.nn_partial(qb, qe, 0, np.full(n, _lib.NN_INF, dtype=np.int32), q_stride=qs, q_block=qk)
             t = time.time(); hits, stats = st.nn_partial(qb, qe, ph, b, q_stride=qs, q_block=qk, wide_queries=wide if ph == 2 else None); walls.append(time.time() - t)

@@ -5,8 +5,9 @@ the first N_READS reads of that generator -- i.e. the whole candidate phase (par
 end-invariant collapse with the default ignore_ends_len = 15, read-to-candidate alignment), imported from /root/reference with
 tests/golden/shims standing in for the absent edlib / parasail wheels (they forward to the CPU oracle: arithmetic pinned by definition,
 alignment tie-breaks "parity unpinned").  nr_cores = 8: the reference's own Pool fan-out (NNG:19-82, EAM:25-47, SWM:121-162).
-Stored: the converged candidates (accession, digest, length), the read -> candidate assignment with alignment digests, the reads left to
-realign, the number of correction steps and the number of candidates written after every step.
+Stored PER HASH SEED (the reference's partition step iterates over sets of sequences: above toy size its outcome depends on PYTHONHASHSEED --
+3 000 reads: 607 candidates under seed 0, 618 under seed 1): the converged candidates (accession, digest, length), the number of correction
+steps, the candidates written after every step and their digests, the reads left to realign.
 
 The 200 000-read run of configs[4] (tests/test_gpu_c5_full.py) is checked by invariants only; this fixture is the largest read set of that
 shape on which every output of the candidate phase is compared with the reference's.
@@ -82,9 +83,10 @@ def child(n):
                 cands.append([acc, sha(line.strip()), len(line.strip())])
         step_files = sorted(glob.glob(os.path.join(tmp, "candidates_step_*.fa")), key=lambda f: int(f.rsplit("_", 1)[1].split(".")[0]))
         per_step = [sum(1 for ln in open(f) if ln.startswith(">")) for f in step_files]
+        step_sets = [sorted(sha(ln.strip()) for ln in open(f) if not ln.startswith(">")) for f in step_files]
         steps = 1 + len(step_files)
     rp = sorted([c, r, sha(t[0]), sha(t[1]), list(t[2])] for c in read_partition for r, t in read_partition[c].items())
-    sys.stdout.write(json.dumps({"candidates": cands, "read_partition": rp, "to_realign": sorted(to_realign), "steps": steps, "candidates_per_step": per_step}))
+    sys.stdout.write(json.dumps({"candidates": cands, "read_partition": rp, "to_realign": sorted(to_realign), "steps": steps, "candidates_per_step": per_step, "candidate_digests_per_step": step_sets}))
 
 
 def main():
@@ -105,15 +107,22 @@ def main():
             seed, n, len(e["candidates"]), e["steps"], e["candidates_per_step"], len(e["read_partition"]), len(e["to_realign"]), time.time() - t0), flush=True)
     agree = all(o == outs[0] for o in outs)
     print("hash seeds agree:", agree)
-    if not agree:
-        raise SystemExit("the outcome depends on PYTHONHASHSEED at this size: no fixture written")
+    # The reference's partition step iterates over sets of sequences (modules/partitions.py:319-343): above toy size its candidates depend
+    # on PYTHONHASHSEED.  Every seed's outcome is stored; the test compares exactly what all seeds agree on (the leading steps) and asks of the
+    # rest that the build's (deterministic) outcome is as close to each seed's as the seeds are to each other.
+    by_seed = {}
+    for seed, o in zip(SEEDS, outs):
+        e = json.loads(o)
+        by_seed[str(seed)] = {"candidates": e["candidates"], "steps": e["steps"], "candidates_per_step": e["candidates_per_step"],
+                              "candidate_digests_per_step": e["candidate_digests_per_step"], "assigned": len(e["read_partition"]),
+                              "to_realign": e["to_realign"], "read_partition": e["read_partition"] if agree else None}
     S = reads(n)
     h = hashlib.sha1()
     for a, s in S.items():
         h.update(a.encode()); h.update(b"\t"); h.update(s.encode()); h.update(b"\n")
     json.dump({"generator": "tests/golden/make_golden_g20.py %d" % n, "reads": "isocon_amd.synth.make_reads(%d, 0, 50, 50001, profile=ONT_PROFILE, families=5, length_range=(1000, 5000))" % n,
                "n_reads": n, "inputs_sha1": h.hexdigest(), "hash_seeds": list(SEEDS),
-               "params": {"ignore_ends_len": 15, "min_exon_diff": 20, "min_candidate_support": 2, "nr_cores": 8}, "expect": json.loads(outs[0])},
+               "params": {"ignore_ends_len": 15, "min_exon_diff": 20, "min_candidate_support": 2, "nr_cores": 8}, "hash_seeds_agree": agree, "by_seed": by_seed},
               open(os.path.join(HERE, "g20_candidates_c5shape.json"), "w"), indent=0)
 
 

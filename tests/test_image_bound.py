@@ -1,4 +1,4 @@
-"""The two inequalities the search over sets with more than four symbols rests on (csrc/nn_host.inc nn_phase_a_images):
+"""The two inequalities the search over sets with more than four symbols rests on (csrc/nn_images.inc nn_phase_a_images):
 with f = the class-merging map of the planes (lower case onto upper case, every byte outside ACGT onto one code) and
 e(s) = number of bytes of s outside ACGT,
         d(f(x), f(y))  <=  d(x, y)  <=  d(f(x), f(y)) + e(x) + e(y).

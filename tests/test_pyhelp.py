@@ -87,7 +87,7 @@ def check_split_ascii_rows(H):
         rows = rng.permutation(n).astype(np.int64)
         if n > 2:
             rows = np.concatenate([rows, rows[:3]])
-        out = H.split_ascii_rows(buf.ctypes.data, ptr.ctypes.data, rows.ctypes.data, len(rows))
+        out = H.split_ascii_rows(buf.ctypes.data, ptr.ctypes.data, len(ptr) - 1, rows.ctypes.data, len(rows))
         raw = buf.tobytes()
         assert out == [raw[ptr[r]:ptr[r + 1]].decode() for r in rows.tolist()]
         first = {}
@@ -96,9 +96,11 @@ def check_split_ascii_rows(H):
         assert len(set(map(id, out))) == len(set(out))
     buf = np.frombuffer(b"ACGT", dtype=np.uint8).copy()
     with pytest.raises(ValueError):
-        H.split_ascii_rows(buf.ctypes.data, np.array([4, 2], dtype=np.int64).ctypes.data, np.zeros(1, dtype=np.int64).ctypes.data, 1)
+        H.split_ascii_rows(buf.ctypes.data, np.array([4, 2], dtype=np.int64).ctypes.data, 1, np.zeros(1, dtype=np.int64).ctypes.data, 1)
     with pytest.raises(ValueError):
-        H.split_ascii_rows(buf.ctypes.data, np.array([0, 2], dtype=np.int64).ctypes.data, np.array([-1], dtype=np.int64).ctypes.data, 1)
+        H.split_ascii_rows(buf.ctypes.data, np.array([0, 2], dtype=np.int64).ctypes.data, 1, np.array([-1], dtype=np.int64).ctypes.data, 1)
+    with pytest.raises(ValueError):          # a row behind the offsets
+        H.split_ascii_rows(buf.ctypes.data, np.array([0, 2], dtype=np.int64).ctypes.data, 1, np.array([1], dtype=np.int64).ctypes.data, 1)
 
 
 def check_invariant_partners(H):
@@ -347,15 +349,17 @@ def check_alignment_dict(H):
     pairs = [("x", "p"), ("x", "q"), ("y", "p")]
     la, lb = ["A-C", "GG", ""], ["AAC", "G-", ""]
     res = np.arange(18, dtype=np.int32).reshape(3, 6)
-    out, d = H.alignment_dict(pairs, la, lb, res.ctypes.data)
+    out, d = H.alignment_dict(pairs, la, lb, res.ctypes.data, len(res))
     assert out == [("A-C", "AAC", (3, 4, 5)), ("GG", "G-", (9, 10, 11)), ("", "", (15, 16, 17))]
     assert d == {"x": {"p": out[0], "q": out[1]}, "y": {"p": out[2]}} and list(d) == ["x", "y"] and list(d["x"]) == ["p", "q"]
     assert d["x"]["q"] is out[1]                     # the very tuple objects (the ops cache finds an alignment by identity)
-    assert H.alignment_dict([], [], [], res.ctypes.data) == ([], {})
+    assert H.alignment_dict([], [], [], res.ctypes.data, 0) == ([], {})
+    with pytest.raises(ValueError):          # fewer result rows than pairs
+        H.alignment_dict(pairs, la, lb, res.ctypes.data, 2)
     with pytest.raises(TypeError):
-        H.alignment_dict(pairs, la[:2], lb, res.ctypes.data)
+        H.alignment_dict(pairs, la[:2], lb, res.ctypes.data, len(res))
     with pytest.raises(TypeError):
-        H.alignment_dict([("x",)], ["A"], ["A"], res.ctypes.data)
+        H.alignment_dict([("x",)], ["A"], ["A"], res.ctypes.data, len(res))
 
 
 def check_lazy_rows(H):
@@ -371,7 +375,9 @@ def check_lazy_rows(H):
     edit = np.array([5, 6, 70000, 8, 0], dtype=np.int32)
     out = {"c1": {"c1": 0}, "c2": {"c2": 0}}
     rows_of = {}
-    assert H.lazy_rows(V, batch, pairs, keep.ctypes.data, edit.ctypes.data, out, rows_of) == 4
+    assert H.lazy_rows(V, batch, pairs, keep.ctypes.data, edit.ctypes.data, len(keep), out, rows_of) == 4
+    with pytest.raises(ValueError):          # arrays of another length than the pair list
+        H.lazy_rows(V, batch, pairs, keep.ctypes.data, edit.ctypes.data, len(keep) - 1, {k: {} for k in out}, {})
     assert rows_of == {"c1": [0, 4], "c2": [2, 3]}
     assert list(out["c1"]) == ["c1", "a", "c"] and list(out["c2"]) == ["c2", "a", "z"]
     v = out["c2"]["a"]
@@ -384,7 +390,7 @@ def check_lazy_rows(H):
     out["c2"]["z"] = (8, "A", "A", 1)                                                  # replaced by a plain tuple
     assert H.lazy_rows_intact(out["c2"], "c2", V, batch, pairs) is False
     with pytest.raises(KeyError):
-        H.lazy_rows(V, batch, [("nope", "a")], keep.ctypes.data, edit.ctypes.data, {}, {})
+        H.lazy_rows(V, batch, [("nope", "a")], keep.ctypes.data, edit.ctypes.data, 1, {}, {})
 
 
 def test_group_keys_by_value():
