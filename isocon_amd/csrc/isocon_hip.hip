@@ -125,7 +125,7 @@ struct ScratchPool {
 
 enum {
     SLOT_ED_TS = 0, SLOT_ED_IDS, SLOT_ED_K, SLOT_ED_OUT, SLOT_FULL_A, SLOT_FULL_B, SLOT_FULL_K, SLOT_FULL_OUT,
-    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_SLOTORDER, SLOT_NN_LBCHUNKS, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B, SLOT_NN_SEED_N, SLOT_NN_LBT, SLOT_NN_LBT_OFF, SLOT_NN_LBT_SLO, SLOT_NN_LBT_LEN, SLOT_NN_LBT_PAD, SLOT_NN_SCORE, SLOT_NN_LDEST, SLOT_NN_FIN_HITS, SLOT_NN_FIN_CNT, SLOT_NN_FIN_START, SLOT_NN_FIN_CUR, SLOT_NN_FIN_NB, SLOT_NN_FIN_LEN2, SLOT_NN_FIN_ROWPTR, SLOT_NN_FIN_COLS, SLOT_NN_FIN_FLAG, SLOT_NN_FIN_BEST, SLOT_NN_ACC_HITS, SLOT_NN_LTOT, SLOT_NN_LCHUNKS, SLOT_NN_LIST, SLOT_NN_LPA, SLOT_NN_LPB, SLOT_NN_TEXT2,
+    SLOT_NN_BEST, SLOT_NN_QF, SLOT_NN_TF, SLOT_NN_HITS, SLOT_NN_HITCOUNT, SLOT_NN_STATS, SLOT_NN_TS, SLOT_NN_IDS, SLOT_NN_PLANES2, SLOT_NN_PERM, SLOT_NN_IL, SLOT_NN_IL2, SLOT_NN_HITS2, SLOT_NN_HITCOUNT2, SLOT_NN_QPROF, SLOT_NN_QSUM, SLOT_NN_LB, SLOT_NN_LBROW, SLOT_NN_LBLEN, SLOT_NN_SLOTORDER, SLOT_NN_LBCHUNKS, SLOT_NN_ROWMIN, SLOT_NN_COLMIN, SLOT_NN_SEED_A, SLOT_NN_SEED_B, SLOT_NN_SEED_N, SLOT_NN_LBT, SLOT_NN_LBT_OFF, SLOT_NN_LBT_SLO, SLOT_NN_LBT_LEN, SLOT_NN_LBT_PAD, SLOT_NN_SCORE, SLOT_NN_LDEST, SLOT_NN_FIN_HITS, SLOT_NN_FIN_CNT, SLOT_NN_FIN_START, SLOT_NN_FIN_CUR, SLOT_NN_FIN_NB, SLOT_NN_FIN_LEN2, SLOT_NN_FIN_ROWPTR, SLOT_NN_FIN_COLS, SLOT_NN_FIN_FLAG, SLOT_NN_FIN_BEST, SLOT_NN_ACC_HITS, SLOT_NN_LTOT, SLOT_NN_LCHUNKS, SLOT_NN_LIST, SLOT_NN_LPA, SLOT_NN_LPB, SLOT_NN_TEXT2, SLOT_NN_LTASKS,
     SLOT_SG_PAIRS, SLOT_SG_R, SLOT_SG_TRACE, SLOT_SG_END, SLOT_SG_OPS, SLOT_SG_CNT, SLOT_SG_RES, SLOT_SG_OFF, SLOT_SG_DENSE, SLOT_SG_BOUND, SLOT_SG_AOFF, SLOT_SG_ALNA, SLOT_SG_ALNB,
     SLOT_MSA_IN, SLOT_MSA_OUT, SLOT_MSA_DEG, SLOT_MSA_COUNTS, SLOT_MSA_MAJ, SLOT_MSA_FLAGS, SLOT_MSA_TOT, SLOT_MSA_NCAND, SLOT_MSA_LEN, SLOT_MSA_OFF, SLOT_MSA_PACKED, SLOT_MSA_ROWS, SLOT_MSA_OPS, SLOT_MSA_OPTR, SLOT_MSA_LONGEST, SLOT_MSA_WIDTH, SLOT_MSA_CSLOT, SLOT_MSA_LTOT, SLOT_MSA_WIDE, SLOT_MSA_PROW, SLOT_MSA_PCOL, SLOT_MSA_PPTR, SLOT_MSA_PBYTES, SLOT_MSAB_PART, SLOT_MSAB_FIRST, SLOT_MSAB_LM, SLOT_MSAB_SBASE, SLOT_MSAB_NCOLS, SLOT_MSAB_MOFF, SLOT_MSAB_CBASE, SLOT_MSAB_CBP, SLOT_MSAB_CBC, SLOT_MSAB_CBR,
     SLOT_HW_Q, SLOT_HW_T, SLOT_HW_K, SLOT_HW_OUT, SLOT_HW_TRACE, SLOT_HW_CTR, SLOT_HW_TILEQ, SLOT_HW_LANES, SLOT_HW_PQ, SLOT_HW_KEY, SLOT_HW_HIST, SLOT_HW_CURSOR, SLOT_HW_TBASE, SLOT_HW_CLS,

@@ -30,6 +30,11 @@ static constexpr int NNF_BATCH = 16;        // text dwords (256 bases) per piece
 static constexpr uint32_t NNF_LIST_MIN = 32;        // with the filter on, the list builder makes chunks of owners with at least this many pairs
 static constexpr uint32_t NNF_TABLE_CHUNKS = 1024;  // fewer chunks than this behind the filter: their pairs go to the pair-per-lane kernel (k_nn_chunks_to_pairs)
 static constexpr uint32_t NNF_GRID = 256 * 8;       // workgroups of the filter launch (they share a queue of chunks)
+static constexpr uint32_t NNF_PASS2_MIN = 16;       // a chunk that keeps at least this many pairs (and too few for a table) sends them through the second pass
+static constexpr uint32_t NNF_GRID2 = 256 * 4;      // workgroups of the second pass (four waves each, a task per wave at a time)
+
+// a task of the second pass: up to 64 pairs of one owner, list[begin .. begin + count)
+struct NNFTask { uint32_t owner, count; unsigned long long begin; };
 
 __host__ __device__ __forceinline__ uint32_t nnf_text2_stride(int32_t maxlen)
 {
@@ -77,11 +82,11 @@ __device__ __forceinline__ uint32_t nnf_absent(const uint32_t *bitmap, uint32_t 
     return (word >> (c & 31u)) & 1u;
 }
 
-// the grams of a sequence (all positions) leave the workgroup's ABSENT bitmap (all ones before); 256 threads
-__device__ __forceinline__ void nnf_add_grams(uint32_t *bitmap, const uint32_t *rx, int32_t len)
+// the grams of a sequence (all positions) leave an ABSENT bitmap (all ones before); thread `tid` of `nthreads` that share the bitmap
+__device__ __forceinline__ void nnf_add_grams(uint32_t *bitmap, const uint32_t *rx, int32_t len, int32_t tid = (int32_t)threadIdx.x, int32_t nthreads = 256)
 {
     const int32_t ng = len - 7;
-    for (int32_t j = (int32_t)threadIdx.x; j * 16 < ng; j += 256) {
+    for (int32_t j = tid; j * 16 < ng; j += nthreads) {
         const uint32_t w0 = rx[j], w1 = rx[j + 1];
         const uint64_t ww = ((uint64_t)w1 << 32) | w0;
 #pragma unroll
@@ -157,7 +162,8 @@ __device__ __forceinline__ uint32_t nnf_count(const uint32_t *bitmap, const uint
 __global__ __launch_bounds__(256, ISOCON_NNF_WAVES) void k_nn_block_filter(const uint32_t *__restrict__ text, uint32_t stride, const int32_t *__restrict__ lens, const uint32_t *__restrict__ meta,
                                                           int32_t kcap, uint32_t *__restrict__ list, const NNChunk *__restrict__ chunks_in, unsigned long long cap_in,
                                                           NNChunk *__restrict__ chunks_out, unsigned long long cap_out, uint32_t *__restrict__ pa, uint32_t *__restrict__ pb,
-                                                          unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min)
+                                                          unsigned long long small_cap, NNPlanTotals *__restrict__ totals, uint32_t list_min, NNFTask *__restrict__ tasks,
+                                                          unsigned long long tasks_cap)
 {
     __shared__ uint32_t bitmap[2048];
     __shared__ uint32_t pass[NN_STAGE];
@@ -202,14 +208,22 @@ __global__ __launch_bounds__(256, ISOCON_NNF_WAVES) void k_nn_block_filter(const
         }
         __syncthreads();
         const uint32_t np = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_npass);
+        // what is left stays a chunk for the table kernels when it is enough for a table AND the test rejected less than half of the chunk (a set on
+        // which the grams decide little); otherwise the second pass looks at it, or -- a handful -- it joins the flat pairs as it is
+        const bool to_table = np >= list_min && (tasks == nullptr || 2u * np >= ch.count);
         if (threadIdx.x == 0) {
             unsigned long long base = 0;
-            if (np >= list_min) {
+            if (to_table) {
                 const unsigned long long ci = atomicAdd(narrow ? &totals->f_chunks_narrow : &totals->f_chunks, 1ull);
                 if (ci < cap_out) { NNChunk o; o.slot = x; o.count = np; o.begin = ch.begin; chunks_out[(narrow ? cap_out : 0ull) + ci] = o; }
                 else { atomicOr(&totals->overflow, 1ull); base = ~0ull; }
                 if (narrow) atomicAdd(&totals->f_narrow_listed, (unsigned long long)np);
                 atomicAdd(&totals->f_listed, (unsigned long long)np);
+            } else if (tasks != nullptr && np >= NNF_PASS2_MIN) {
+                // the second pass takes them (k_nn_block_filter2): they go back to the chunk's own part of the list, 64 per task
+                const uint32_t nt = (np + 63u) / 64u;
+                base = atomicAdd(&totals->f_tasks, (unsigned long long)nt);
+                if (base + nt > tasks_cap) { atomicOr(&totals->overflow, 1ull); base = ~0ull; }
             } else if (np) {
                 base = atomicAdd(&totals->n_small, (unsigned long long)np);
                 if (base + np > small_cap) { atomicOr(&totals->overflow, 1ull); base = ~0ull; }
@@ -220,9 +234,74 @@ __global__ __launch_bounds__(256, ISOCON_NNF_WAVES) void k_nn_block_filter(const
         __syncthreads();
         const unsigned long long base = nnf_uniform64(s_base);
         if (base != ~0ull) {
-            if (np >= list_min) { for (uint32_t i = threadIdx.x; i < np; i += 256) list[ch.begin + i] = pass[i]; }
+            if (to_table) { for (uint32_t i = threadIdx.x; i < np; i += 256) list[ch.begin + i] = pass[i]; }
+            else if (tasks != nullptr && np >= NNF_PASS2_MIN) {
+                for (uint32_t i = threadIdx.x; i < np; i += 256) list[ch.begin + i] = pass[i];
+                for (uint32_t j = threadIdx.x; j * 64u < np; j += 256) {
+                    NNFTask t; t.owner = x; t.count = np - j * 64u < 64u ? np - j * 64u : 64u; t.begin = ch.begin + (unsigned long long)j * 64ull;
+                    tasks[base + j] = t;
+                }
+            }
             else { for (uint32_t i = threadIdx.x; i < np; i += 256) { pa[base + i] = x; pb[base + i] = pass[i] & 0x3fffffffu; } }
         }
+    }
+}
+
+// The second pass: what the first leaves of a chunk (7 % at C3), on the finer grid -- a probe every 2 bases separates errors that the 4-base
+// grid merges (the study: 99.0 % of the non-hits rejected against 95.7 %).  Inside k_nn_block_filter it would run per chunk on a seventh of
+// the lanes and costs what it saves (profiles/r06d_filter_second_pass.txt); here a WAVE takes 64 pairs of one owner at a time from a task
+// queue, with an 8 KB bitmap of its own (the owner's grams are filed again: 40 LDS atomics per lane), and appends its survivors to the flat
+// pairs of the one-pair-per-lane kernel.  Waves of a workgroup never wait for each other (no barrier: a wave only reads the LDS it wrote).
+__global__ __launch_bounds__(256, 3) void k_nn_block_filter2(const uint32_t *__restrict__ text, uint32_t stride, const int32_t *__restrict__ lens, const uint32_t *__restrict__ meta,
+                                                             int32_t kcap, const uint32_t *__restrict__ list, const NNFTask *__restrict__ tasks, unsigned long long tasks_cap,
+                                                             uint32_t *__restrict__ pa, uint32_t *__restrict__ pb, unsigned long long small_cap, NNPlanTotals *__restrict__ totals)
+{
+    __shared__ uint32_t bitmaps[4][2048];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *bitmap = bitmaps[wave];
+    if (totals->overflow) return;
+    const unsigned long long n_tasks = totals->f_tasks < tasks_cap ? totals->f_tasks : tasks_cap;
+    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
+    for (;;) {
+        unsigned long long ti = 0;
+        if (lane == 0) ti = atomicAdd(&totals->f_task_next, 1ull);
+        ti = nnf_uniform64(ti);
+        if (ti >= n_tasks) break;
+        const NNFTask t = tasks[ti];
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.owner), count = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.count);
+        const unsigned long long begin = nnf_uniform64(t.begin);
+        for (int i = lane; i < 2048; i += 64) bitmap[i] = 0xffffffffu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        nnf_add_grams(bitmap, text + (size_t)x * stride, lens[x], lane, 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int32_t kx0 = nn_meta_thr(meta[x]);
+        const bool active = (uint32_t)lane < count;
+        const uint32_t word = active ? list[begin + (unsigned long long)lane] : 0u;
+        const uint32_t y = word & 0x3fffffffu;
+        int32_t k = -1;
+        if (active) {
+            if (word & 0x40000000u) k = kx0;
+            if (word & 0x80000000u) { const int32_t ky = nn_meta_thr(meta[y]); k = ky > k ? ky : k; }
+            if (k > kcap) k = kcap;
+        }
+        const uint32_t cnt = nnf_count<2>(bitmap, text + (size_t)y * stride, active ? nnf_dwords<2>(lens[y]) : 0, k, active);
+        const bool keep = active && (int32_t)cnt <= k;
+        const uint64_t km = __ballot(keep);
+        const uint32_t nk = (uint32_t)__popcll(km);
+        unsigned long long base = 0;
+        if (lane == 0) {
+            if (nk) {
+                base = atomicAdd(&totals->n_small, (unsigned long long)nk);
+                if (base + nk > small_cap) { atomicOr(&totals->overflow, 1ull); base = ~0ull; }
+            }
+            if (count > nk) atomicAdd(&totals->f_rejected2, (unsigned long long)(count - nk));
+        }
+        base = nnf_uniform64(base);
+        if (keep && base != ~0ull) {
+            const unsigned long long at = base + (unsigned long long)__popcll(km & lt_mask);
+            pa[at] = x; pb[at] = y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the next task's bitmap writes behind this task's reads)
     }
 }
 

@@ -41,7 +41,8 @@ struct NNPlanTotals {
     unsigned long long n_chunks_narrow, pad6[15];          // chunks of the 32-row class (n_chunks counts the 64-row class)
     unsigned long long n_wide_pairs, n_narrow_listed, pad7[14];          // pairs sent to the pair-per-lane kernel for their threshold (class mode 1); pairs in narrow chunks
     // the block filter behind the list builder (nn_filter.hpp): its work queue, the chunks it leaves per class, the pairs it rejected
-    unsigned long long f_next, pad8[15], f_chunks, pad9[15], f_chunks_narrow, pad10[15], f_rejected, f_narrow_listed, f_listed, pad11[13];          // f_listed: pairs in the chunks it leaves (both classes)
+    unsigned long long f_next, pad8[15], f_chunks, pad9[15], f_chunks_narrow, pad10[15], f_rejected, f_narrow_listed, f_listed, f_rejected2, pad11[12];          // f_listed: pairs in the chunks it leaves (both classes); f_rejected2: by its second pass
+    unsigned long long f_tasks, pad12[15], f_task_next, pad13[15];          // tasks of the second pass (nn_filter.hpp) and its queue
 };
 
 // Threshold classes of the listed launch.  A pair whose threshold max(k of its two directions) is <= NN_NARROW_K is exact on 32

@@ -8,7 +8,7 @@ accs, seqs, _ = synth.make_reads(50000, 2500, 10, 30001)
 seqs = sorted(dict.fromkeys(seqs), key=len)
 st = SeqStore(seqs)
 ref = None
-variants = sys.argv[1:] or ["", "nn_filter_one_pass", "nn_list_min=1024", "nn_list_min=100000", "nn_filter_one_pass,nn_list_min=100000", "nn_no_block_filter"]
+variants = sys.argv[1:] or ["", "nn_filter_one_pass", "nn_table_chunks=0", "nn_no_block_filter"]
 for v in variants:
     if v: os.environ["ISOCON_DEBUG_VARIANT"] = v
     else: os.environ.pop("ISOCON_DEBUG_VARIANT", None)

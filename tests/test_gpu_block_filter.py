@@ -66,6 +66,10 @@ def test_graph_with_and_without_the_filter(n, length, iso, seed, monkeypatch):
     st = SeqStore(seqs)
     best, rp, cols, stats = st.nn_graph()
     assert stats["pairs_block_rejected"] > 0 and stats["filter_kernel_ms"] > 0
+    monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_filter_one_pass")          # without the second pass (a probe every 2 bases on what the first leaves)
+    best1, rp1, cols1, stats1 = SeqStore(seqs).nn_graph()
+    assert (best == best1).all() and (rp == rp1).all() and (cols == cols1).all()
+    assert 0 < stats1["pairs_block_rejected"] <= stats["pairs_block_rejected"] and stats1["pairs_evaluated"] >= stats["pairs_evaluated"]
     monkeypatch.setenv("ISOCON_DEBUG_VARIANT", "nn_no_block_filter")
     best0, rp0, cols0, stats0 = SeqStore(seqs).nn_graph()
     monkeypatch.delenv("ISOCON_DEBUG_VARIANT")

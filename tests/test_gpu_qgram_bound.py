@@ -127,7 +127,7 @@ def test_graph_with_the_filter_is_the_graph_without_it_and_the_filter_is_used():
                     "nn_seed_classes=1", "nn_seed_classes=2"):
             # ... each of them behind the block filter (csrc/nn_filter.hpp: default, the survivors one per lane), with the filter and the table
             # launches on whatever it leaves, and without the filter (every survivor of the q-gram bound through the tables)
-            for tables in ("", ",nn_table_chunks=0", ",nn_no_block_filter"):
+            for tables in ("", ",nn_filter_one_pass", ",nn_table_chunks=0", ",nn_no_block_filter"):
                 os.environ["ISOCON_DEBUG_VARIANT"] = env + tables          # (the one switch behind which the A/B variants sit: DESIGN.md section 8)
                 try:
                     b2, r2, c2, s2 = st.nn_graph(is_converged=conv)
