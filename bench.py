@@ -587,7 +587,7 @@ def main():
                               "kernel_ms": pm["list_kernel_ms"] - pm["filter_kernel_ms"], "hbm_bytes": hbm("nn_lists", pm["list_kernel_ms"] - pm["filter_kernel_ms"])[0],
                               "hbm_frac": hbm("nn_lists", pm["list_kernel_ms"] - pm["filter_kernel_ms"])[1],
                               "valu_frac": valu_frac("nn_lists", pm["list_kernel_ms"] - pm["filter_kernel_ms"])},
-                "window_pairs": int(st0["pairs_prefiltered"]) + int(st0["pairs_block_rejected"]) + pairs_eval,
+                "pairs_inside_their_threshold_window": int(st0["pairs_prefiltered"]) + int(st0["pairs_block_rejected"]) + pairs_eval,
                 "pairs_rejected_by_qgram_bound": int(st0["pairs_prefiltered"]), "pairs_rejected_by_block_filter": int(st0["pairs_block_rejected"]),
                 "pairs_aligned": pairs_eval, "pairs_aligned_one_per_lane": int(st0["pairs_lanes"]),
                 "algorithmic": {"bytes_per_pair": 2.0 * mean_len + 8.0, "pairs_per_launch": pairs_eval,

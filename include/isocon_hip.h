@@ -96,7 +96,7 @@ int isocon_ed_pairs(isocon_store *s, const uint32_t *a, const uint32_t *b, const
                     int32_t *out_ed, float *kernel_ms);
 
 /*
- * Lower bounds of the pairs' edit distances from q-gram count profiles (isocon_amd/csrc/qgram_mm.hpp: 9-grams hashed into 16384
+ * Lower bounds of the pairs' edit distances from q-gram count profiles (isocon_amd/csrc/qgram_mm.hpp: 9-grams hashed into 12288
  * presence bins plus 2 levels of 2048 excess bins; isocon_qgram_params): out_bound[p] <= ed(a[p], b[p]) always.  The main pass of the
  * nearest-neighbour search skips a pair whose bound exceeds its threshold -- the pair edlib would have answered with -1
  * (modules/nearest_neighbor_graph.py:156-162).  The reference has no counterpart; exposed so that the bound can be tested by itself.

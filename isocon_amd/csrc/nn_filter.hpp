@@ -27,6 +27,10 @@
 namespace isocon {
 
 static constexpr int NNF_BATCH = 16;        // text dwords (256 bases) per piece: one 64-byte line per lane
+#ifndef ISOCON_NNF_GROUP             // text dwords (4 probes each) the scheduler may interleave in the first pass (experiments: scripts/dev/build_variant.sh)
+#define ISOCON_NNF_GROUP 2
+#endif
+static constexpr int NNF_GROUP = ISOCON_NNF_GROUP;
 static constexpr uint32_t NNF_LIST_MIN = 32;        // with the filter on, the list builder makes chunks of owners with at least this many pairs
 static constexpr uint32_t NNF_TABLE_CHUNKS = 1024;  // fewer chunks than this behind the filter: their pairs go to the pair-per-lane kernel (k_nn_chunks_to_pairs)
 static constexpr uint32_t NNF_GRID = 256 * 8;       // workgroups of the filter launch (they share a queue of chunks)
@@ -141,7 +145,7 @@ __device__ __forceinline__ uint32_t nnf_count(const uint32_t *bitmap, const uint
             }
             cnt += sum;
             // (without this the scheduler hoists the whole piece's 64 / 128 lookups: 234 registers, two waves per SIMD)
-            if ((jj & (S == 4 ? 1 : 0)) == (S == 4 ? 1 : 0)) __builtin_amdgcn_sched_barrier(0);
+            if ((jj & (S == 4 ? NNF_GROUP - 1 : 0)) == (S == 4 ? NNF_GROUP - 1 : 0)) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // one piece in registers at a time: eight waves per SIMD hide a piece's load behind the other waves' probes (two register sets with the

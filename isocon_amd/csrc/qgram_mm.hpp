@@ -25,11 +25,12 @@ namespace isocon {
 
 static constexpr int QG_Q = 9;            // gram length
 #ifndef ISOCON_QG_B0                      // (experiments: scripts/dev/build_variant.sh NAME -DISOCON_QG_B0=...)
-#define ISOCON_QG_B0 16384
+#define ISOCON_QG_B0 12288
 #endif
 static constexpr int QG_B0 = ISOCON_QG_B0;       // presence bins (the 4^q gram codes hashed into them).  24 576 until round 6: with the block filter
-                                                 // (nn_filter.hpp) behind this bound a survivor costs 0.12 ns instead of 1.1, and the cheaper contraction wins --
-                                                 // C3 step 9.67 / 9.33 / 8.81 / 8.91 ms at 24 576 / 20 480 / 16 384 / 12 288 bins (profiles/r06b_b0_sweep.txt)
+                                                 // (nn_filter.hpp) behind this bound a survivor costs 0.13 ns instead of 1.1, and the cheaper contraction wins --
+                                                 // C3 step 9.04 / 8.55 / 8.46 / 8.33 / 8.43 / 8.67 ms at 20 480 / 16 384 / 14 336 / 12 288 / 10 240 / 8 192 bins
+                                                 // (profiles/r06b_b0_sweep.txt)
 static constexpr int QG_B1 = 2048;        // excess bins (presence bin mod QG_B1)
 static constexpr int QG_CAP = 2;          // levels kept of an excess bin
 static constexpr int QM_K = QG_B0 + QG_B1 * QG_CAP;     // binary elements per profile

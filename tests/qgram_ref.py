@@ -14,7 +14,7 @@ def _params():
         _lib.load().isocon_qgram_params(out)
         return tuple(int(v) for v in out)
     except Exception:
-        return 9, 16384, 2048, 2
+        return 9, 12288, 2048, 2
 
 
 Q, B0, B1, CAP = _params()
