@@ -43,7 +43,10 @@ static constexpr int QM_STAGES = 4;       // LDS ring: QM_STAGES x 2 operands x 
 static constexpr int QM_STAGE_BYTES = 2 * QM_TILE * QM_ROWB;
 static constexpr int QM_OUT_STRIDE = QM_TILE + 8;       // bytes per row of the epilogue's byte tile in LDS (66 dwords: 2-way on the dword writes)
 static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 2 * 16 * 2 + 256 * 4 + 256 * (4 + 4 + 8 + 4);
-static constexpr int QM_SEEDS = 4;             // seed candidates kept per row and per column of the matrix: the smallest bound of every fourth tile
+#ifndef ISOCON_QM_SEEDS
+#define ISOCON_QM_SEEDS 4
+#endif
+static constexpr int QM_SEEDS = ISOCON_QM_SEEDS;             // seed candidates kept per row and per column of the matrix: the smallest bound of every fourth tile
 static constexpr uint32_t QM_HUB_BOUND = 36;   // a pair with a bound up to this counts towards its ends' hub scores (nn_list.hpp: which end's table a pair uses)
 static constexpr size_t QM_LDS_BYTES = (size_t)QM_STAGES * QM_STAGE_BYTES + QM_META_BYTES;
 static_assert(QG_B0 % 128 == 0 && QG_B1 % 256 == 0 && QG_B0 % QG_B1 == 0, "K-blocks of 128 elements; excess bin = presence bin mod QG_B1");
