@@ -69,10 +69,10 @@ def bound_matrix(seqs, q=Q):
 
 def block_count(owner, partner, b=8, s=4):
     """greedy number of pairwise disjoint b-grams of `partner`, probed at the positions 0, s, 2 s, ... of the whole 16-base words
-    all of whose grams lie inside the sequence (word j counts when 16 j + 24 - s <= len), which occur nowhere in `owner`: a counted gram skips the probes that overlap it"""
+    all of whose grams lie inside the sequence (word j counts when 16 j + 16 - s + b <= len; the kernel: b = 8), which occur nowhere in `owner`: a counted gram skips the probes that overlap it"""
     grams = set(owner[i:i + b] for i in range(len(owner) - b + 1))
     n = len(partner)
-    nd = (n - (24 - s)) // 16 + 1 if n >= 24 - s else 0
+    nd = (n - (16 - s + b)) // 16 + 1 if n >= 16 - s + b else 0
     cnt, nxt = 0, 0
     for p in range(0, 16 * nd, s):
         if p >= nxt and partner[p:p + b] not in grams:

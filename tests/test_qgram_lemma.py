@@ -90,3 +90,40 @@ def test_bound_never_exceeds_the_edit_distance():
     # and it is not vacuous (short sequences with dense edits included; 0.76 on 2.5 kb reads at 1 % errors)
     rel = (d > 0) & (d <= 60)
     assert np.median(lb[rel] / d[rel]) > 0.4
+
+
+def test_greedy_block_count_is_a_lower_bound():
+    """The second bound of the main pass (isocon_amd/csrc/nn_filter.hpp; restated in tests/qgram_ref.block_count): the greedy number of pairwise
+    disjoint b-grams of one sequence that occur nowhere in the other never exceeds the edit distance -- every probe stride, random pairs, related
+    pairs with every kind of edit (also clustered ones), homopolymers, repeats, sequences shorter than a gram or a word."""
+    from tests import qgram_ref
+    rng = random.Random(77)
+    cases = []
+    for _ in range(300):
+        L = rng.choice([5, 19, 20, 21, 36, 64, 100, 257, 700])
+        alpha = rng.choice(["ACGT", "ACGT", "AC", "A"])
+        a = "".join(rng.choice(alpha) for _ in range(L))
+        kind = rng.random()
+        if kind < 0.6:
+            b = _edits(rng, a, rng.randint(0, 12), rng.choice(["sid", "i", "d", "s", "id"]))
+        elif kind < 0.8:          # a burst of edits inside a few bases, and another one close behind
+            s = list(a)
+            p = rng.randrange(max(1, len(s) - 12))
+            for j in range(rng.randint(1, 5)):
+                s.insert(p + j, rng.choice("ACGT"))
+            if len(s) > p + 9:
+                del s[p + 8]
+            b = "".join(s)
+        else:
+            b = "".join(rng.choice(alpha) for _ in range(max(1, L + rng.randint(-6, 6))))
+        cases.append((a, b or "A"))
+    cases += [("ACGT" * 40, "ACGT" * 39 + "ACG"), ("A" * 100, "A" * 99 + "C"), ("ACGTTGCA" * 12, "TGCAACGT" * 12), ("", "ACGT" * 8), ("ACGT" * 8, "")]
+    tight = 0
+    for a, b in cases:
+        d = O.ed_bounded(a, b) if a and b else max(len(a), len(b))
+        for gram, stride in ((8, 4), (8, 2), (8, 1), (4, 4), (4, 2), (12, 4)):
+            for x, y in ((a, b), (b, a)):
+                c = qgram_ref.block_count(x, y, b=gram, s=stride)
+                assert c <= d, (x, y, gram, stride, c, d)
+        tight += qgram_ref.block_count(a, b) == d and d > 0
+    assert tight > 10          # (and it is not a trivial bound: it meets the distance on some pairs)
