@@ -1,6 +1,6 @@
 // nn_filter.hpp -- the SECOND rejection test of the main pass: a greedy block bound on the pairs that survive the q-gram bound.
 //
-// What the alignment kernels were doing at C3 (50 000 CCS reads): 99 % of the 9.1 10^6 survivors of the q-gram bound are reads of one
+// What the alignment kernels were doing at C3 (50 000 CCS reads): 99 % of the ~10^7 survivors of the q-gram bound are reads of one
 // isoform whose distance lies 12-26 % above their threshold; the banded DP ran 90 % of their columns to find that out.  The q-gram
 // bound (qgram_mm.hpp) reaches 0.82 of the true distance on those pairs; this one reaches 0.93-0.97 for a twelfth of a DP's work
 // (scripts/dev/second_stage_study*.py, profiles/r06a_second_stage_study.txt: 95.7 % of the non-hits rejected, no hit ever).
@@ -18,8 +18,11 @@
 //   k_build_text2        2-bit texts: row i = the bases of sequence i, 16 per dword (base j at bits 2j, 2j + 1 of dword j / 16), zero padded
 //   k_nn_block_filter    one workgroup per chunk of the list builder (nn_list.hpp): the owner's 8-gram set as a bitmap in LDS (bit set =
 //                        ABSENT), one partner per lane streaming its text in 64-byte pieces, four probes per dword (b = 8, s = 4);
-//                        survivors are compacted in LDS and leave as a chunk of the same class (>= list_min of them) or as flat
-//                        pairs for the one-pair-per-lane kernel.
+//                        survivors are compacted in LDS and leave as a chunk of the same class (enough of them AND less than half of
+//                        the chunk rejected: a set on which grams decide little), as tasks of the second pass, or -- a handful -- as
+//                        flat pairs for the one-pair-per-lane kernel;
+//   k_nn_block_filter2   the second pass on the finer grid (s = 2): a wave per 64 surviving pairs of one owner, its own 8 KB bitmap;
+//   k_nn_chunks_to_pairs what is left in table chunks when they are too few for a table launch joins the flat pairs.
 // The pair set only shrinks by pairs with d > threshold, so the graph is the one of /root/reference/modules/nearest_neighbor_graph.py:134-192.
 #pragma once
 #include "nn_list.hpp"
