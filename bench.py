@@ -627,7 +627,7 @@ def main():
         if is_default:
             try:
                 result["two_set_graph"] = two_set_leg()
-                result["roofline_2set"] = roofline_2set(result["two_set_graph"], kk)
+                result["roofline_2set"] = roofline_2set(result["two_set_graph"], kk, ctr if is_default else {})
             except Exception as e:
                 result["two_set_graph"] = {"error": repr(e)}
         if sw_leg:
@@ -859,7 +859,7 @@ def two_set_leg():
             "note": "public function end to end (Python strings in, dict of dicts out); fixture tests/golden/g19_c3_graph_2set.npz"}
 
 
-def roofline_2set(leg, kk):
+def roofline_2set(leg, kk, ctr=None):
     """Where the 2-set leg's kernel time goes (HIP events of its own call) and why it costs more per REFERENCE alignment than the 1-set step."""
     st = leg.get("stats") or {}
     if not st:
@@ -873,7 +873,10 @@ def roofline_2set(leg, kk):
     window_pairs_all = int(st.get("pairs_prefiltered", 0)) + int(st.get("pairs_block_rejected", 0)) + int(st.get("pairs_evaluated", 0))
     return {"bound": "mfma", "kernel": "isocon::k_qgram_mm (the same bound kernel as the 1-set step)", "dominant_phase": dom, "kernels_ms": phases, "kernel_ms": mm_ms,
             "achieved": 2.0 * macs / (mm_ms / 1e3) / 1e12 if mm_ms > 0 else None, "peak": 2.0 * MFMA_FP4_PEAK_MACS / 1e12, "unit": "TFLOP/s",
-            "frac": (2.0 * macs / (mm_ms / 1e3) / 1e12) / (2.0 * MFMA_FP4_PEAK_MACS / 1e12) if mm_ms > 0 else None, "traffic": None,
+            "frac": (2.0 * macs / (mm_ms / 1e3) / 1e12) / (2.0 * MFMA_FP4_PEAK_MACS / 1e12) if mm_ms > 0 else None,
+            "traffic": float(ctr["nn_2set"]["hbm_bytes"]) if ctr and ctr.get("nn_2set", {}).get("hbm_bytes") else None,
+            "hbm_frac": float(ctr["nn_2set"]["hbm_bytes"]) / (mm_ms / 1e3) / 1e9 / HBM_PEAK_GBS if ctr and ctr.get("nn_2set", {}).get("hbm_bytes") and mm_ms > 0 else None,
+            "valu_frac_of_the_bound_kernel": float(ctr["nn_2set"]["SQ_INSTS_VALU"]) / (mm_ms / 1e3) / VALU_PEAK_WAVE_INSTR if ctr and ctr.get("nn_2set", {}).get("SQ_INSTS_VALU") and mm_ms > 0 else None,
             "tiles_256x256": int(st.get("bound_tiles", 0)),
             "read_x_candidate_pairs_with_a_role": window_pairs_all, "pairs_rejected_by_qgram_bound": int(st.get("pairs_prefiltered", 0)),
             "pairs_rejected_by_block_filter": int(st.get("pairs_block_rejected", 0)), "pairs_aligned": int(st.get("pairs_evaluated", 0)),
