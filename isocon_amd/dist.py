@@ -85,20 +85,48 @@ def protocol_steps(rank, world, n, phase2_steps=None):
     return steps
 
 
-def _agree(store, n, dist, device):
-    """ONE all_reduce(MIN) per search of (fingerprint, -fingerprint, capability): every rank learns from the reduced values alone whether
-    all ranks packed the very same sequences in the very same order (min == max) and whether EVERY rank can run the device-resident
-    protocol.  Done on every call: a decision cached per store would let a rank whose store was rebuilt enter a collective that the
-    others skip, and a rank deciding from its local state could pair a CUDA tensor with a CPU tensor in one collective.
-    Returns (same set, device path)."""
-    import torch
-    can = (device.type == "cuda" and hasattr(store, "nn_partial_dev") and n > 0 and len(_lib.hip_runtimes_loaded()) == 1 and torch.cuda.is_available())
-    fp = getattr(store, "fingerprint", None)
-    fp = 0 if fp is None else int(fp)
-    t = torch.tensor([fp, -fp, 1 if can else 0], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    lo, neg_hi, agreed = (int(x) for x in t.tolist())
-    return lo == -neg_hi, bool(agreed)
+class _Agreement(object):
+    """ONE all_reduce(MIN) per search of (fingerprint, -fingerprint): every rank learns from the reduced pair alone whether all ranks packed
+    the very same sequences in the very same order (min == max).  Done on every call (a decision cached per store would let a rank whose
+    store was rebuilt enter a collective that the others skip) -- but NOT waited for: the reduction is issued first, the rank's phase 0 (no
+    collective in it, the rank's own store only) runs meanwhile, and confirm() is called before the first collective whose size
+    depends on n.  A mismatch therefore still raises on every rank before any exchange of best[]; what it no longer costs is a
+    launch + host round trip in front of the first kernel (0.36 ms of an 8.5 ms search at C3, profiles/r06l_sharded_overhead.txt).
+
+    Whether a rank keeps best[] and its edges in device memory (`device_resident`) is the rank's OWN business: the two ways of
+    running a phase issue the same collectives on tensors of the same shape, dtype and device (sharded_nn_graph below), so nothing is agreed."""
+
+    def __init__(self, store, dist, device):
+        import torch
+        fp = getattr(store, "fingerprint", None)
+        fp = 0 if fp is None else int(fp)
+        self.t = torch.tensor([fp, -fp], dtype=torch.int64).to(device, non_blocking=True)
+        self.work = dist.all_reduce(self.t, op=dist.ReduceOp.MIN, async_op=True)
+        self.same = None
+
+    def confirm(self):
+        if self.same is None:
+            if self.work is not None:
+                self.work.wait()
+            lo, neg_hi = (int(x) for x in self.t.tolist())
+            self.same = lo == -neg_hi
+        if not self.same:
+            raise RuntimeError("sharded_nn_graph: the ranks hold different sequence sets / orders (fingerprint mismatch); "
+                               "build the store from a deterministic order (not from set())")
+
+
+_ONE_HIP_RUNTIME = None          # this process maps exactly one libamdhip64 (read from /proc/self/maps ONCE: 0.3 ms in a torch process)
+
+
+def device_resident(store, n, device):
+    """this rank can keep best[] and its candidate edges in device memory between the exchange steps"""
+    global _ONE_HIP_RUNTIME
+    if not (device.type == "cuda" and hasattr(store, "nn_partial_dev") and n > 0):
+        return False
+    if _ONE_HIP_RUNTIME is None:          # (asked after the library and torch's runtime are both loaded: the store exists, the device is torch's)
+        import torch
+        _ONE_HIP_RUNTIME = len(_lib.hip_runtimes_loaded()) == 1 and torch.cuda.is_available()
+    return _ONE_HIP_RUNTIME
 
 
 def _all_gather_rows(dist, rows, device):
@@ -159,7 +187,7 @@ def _staging(store, name, n_int32, device):
     return t[:n_int32]
 
 
-def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap):
+def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap, agreement):
     """The protocol of sharded_nn_graph with best[] and the candidate edges in device memory from the first phase to the CSR
     (SeqStore.nn_partial_dev / nn_hits_dev / nn_finalize_dev): RCCL reduces and gathers the device buffers themselves, the host sees
     1 + world status words per reduction and the final graph.  The library works on the null stream, which is torch's current
@@ -211,6 +239,7 @@ def _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap):
         tail_host[0] = -1 if err is not None else 0
         tail_host[1 + rank] = -held
         t[n:].copy_(tail_host, non_blocking=True)
+        agreement.confirm()                                # (the fingerprints: reduced while phase 0 ran; raises on every rank alike)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)           # THE exchange of thresholds
         tail_host.copy_(t[n:])
         if int(tail_host[0]) != 0:
@@ -262,13 +291,10 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     n = store.n
     tl = time.perf_counter()
-    same, device_path = _agree(store, n, dist, device)
-    if not same:
-        raise RuntimeError("sharded_nn_graph: the ranks hold different sequence sets / orders (fingerprint mismatch); "
-                           "build the store from a deterministic order (not from set())")
+    agreement = _Agreement(store, dist, device)
     tl = lap("fingerprint", tl)
-    if device_path:
-        out = _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap)
+    if device_resident(store, n, device):
+        out = _nn_graph_device_resident(store, is_converged, is_target, depth, dist, lap, agreement)
         return out if return_stats else out[:3]
     hits_all, stats_all = [], []
     best = np.full(max(n, 1), _lib.NN_INF, dtype=np.int32)
@@ -313,6 +339,7 @@ def sharded_nn_graph(store, is_converged=None, is_target=None, depth=2 ** 32, di
         t[nb] = -1 if err is not None else 0
         t[nb + 1 + rank] = -sum(len(h) for h in hits_all)
         td = t.to(device, non_blocking=True) if device.type == "cuda" else t
+        agreement.confirm()                                 # (the fingerprints: reduced while phase 0 ran; raises on every rank alike)
         dist.all_reduce(td, op=dist.ReduceOp.MIN)           # THE exchange of thresholds
         if device.type == "cuda":
             t.copy_(td, non_blocking=False)

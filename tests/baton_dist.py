@@ -60,7 +60,8 @@ class BatonDist(object):
         g.barrier.wait()
         self.take()
 
-    def all_reduce(self, t, op="sum"):
+    def all_reduce(self, t, op="sum", async_op=False):
+        """async_op: the reduction is done at once all the same (the ranks meet here); the handle's wait() has nothing left to do"""
         import torch
 
         def root(slots):
@@ -72,6 +73,7 @@ class BatonDist(object):
                 torch.cuda.synchronize()
             self.g.bytes_moved += red.numel() * red.element_size()
         self._collective(t, root)
+        return types.SimpleNamespace(wait=lambda: None) if async_op else None
 
     def all_gather_into_tensor(self, out, t):
         import torch

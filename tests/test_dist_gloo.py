@@ -73,14 +73,14 @@ def _worker(rank, world, port, seqs, conv, out_dir):
     dist.destroy_process_group()
 
 
-def _worker_mismatch(rank, world, port, out_dir):
+def _worker_mismatch(rank, world, port, out_dir, sizes_differ=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
     sys.path.insert(0, ROOT)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from isocon_amd.dist import sharded_nn_graph
-    st = FakeStore(["ACGT", "ACGTA", "ACGTAC"])
+    st = FakeStore(["ACGT", "ACGTA", "ACGTAC"] + (["ACGTACG", "ACGTACGT"] * rank if sizes_differ else []))
     st.fingerprint = 1234 + rank          # the ranks packed different orders / sets
     try:
         sharded_nn_graph(st, dist=dist, device=torch.device("cpu"))
@@ -93,8 +93,11 @@ def _worker_mismatch(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(120)
-def test_ranks_with_different_stores_are_rejected(tmp_path):
-    mp.spawn(_worker_mismatch, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("sizes_differ", [False, True])
+def test_ranks_with_different_stores_are_rejected(tmp_path, sizes_differ):
+    """The fingerprints are reduced while phase 0 runs and compared before the first collective whose size depends on n: ranks whose sets
+    differ -- also in SIZE, where a reduction of best[] would pair tensors of different lengths -- all raise, none is left in a collective."""
+    mp.spawn(_worker_mismatch, args=(2, _free_port(), str(tmp_path), sizes_differ), nprocs=2, join=True)
     for r in (0, 1):
         assert "fingerprint mismatch" in open(tmp_path / ("mismatch%d.txt" % r)).read()
 
