@@ -41,17 +41,20 @@ static constexpr int QM_NKB = QM_K / QM_KBE;
 static constexpr int QM_TILE = 256;       // rows and columns of the bound matrix per workgroup
 static constexpr int QM_STAGES = 4;       // LDS ring: QM_STAGES x 2 operands x 256 rows x 64 B = 128 KB
 static constexpr int QM_STAGE_BYTES = 2 * QM_TILE * QM_ROWB;
-static constexpr int QM_OUT_STRIDE = QM_TILE + 8;       // bytes per row of the epilogue's byte tile in LDS (66 dwords: 2-way on the dword writes)
-static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 2 * 16 * 2 + 256 * 4 + 256 * (4 + 4 + 8 + 4);
+static constexpr int QM_OUT_STRIDE = QM_TILE + 8;       // bytes per row of the epilogue's byte tile out[q][p] in LDS (66 dwords: the dword writes of a wave hit 64 banks)
+static constexpr int QM_OUTT_STRIDE = QM_TILE + 32;     // bytes per row of the transposed byte tile outT[p][q] (72 dwords = 8 mod 64: the quad-transposed dword writes hit 64 banks; rows 16-byte aligned)
+static constexpr int QM_EPI_BYTES = QM_TILE * (QM_OUT_STRIDE + QM_OUTT_STRIDE);          // both byte tiles: they take the ring's place after the K loop
+static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 3 * 16 * 2 + 256 * (4 + 4 + 8);          // the tile's row and column tables (k_qgram_mm: m_sA .. m_offT)
 #ifndef ISOCON_QM_SEEDS
 #define ISOCON_QM_SEEDS 4
 #endif
 static constexpr int QM_SEEDS = ISOCON_QM_SEEDS;             // seed candidates kept per row and per column of the matrix: the smallest bound of every fourth tile
 static constexpr uint32_t QM_HUB_BOUND = 36;   // a pair with a bound up to this counts towards its ends' hub scores (nn_list.hpp: which end's table a pair uses)
-static constexpr size_t QM_LDS_BYTES = (size_t)QM_STAGES * QM_STAGE_BYTES + QM_META_BYTES;
+static constexpr int QM_META_OFF = QM_STAGES * QM_STAGE_BYTES > QM_EPI_BYTES ? QM_STAGES * QM_STAGE_BYTES : QM_EPI_BYTES;          // (16-byte aligned)
+static constexpr size_t QM_LDS_BYTES = (size_t)QM_META_OFF + QM_META_BYTES;
 static_assert(QG_B0 % 128 == 0 && QG_B1 % 256 == 0 && QG_B0 % QG_B1 == 0, "K-blocks of 128 elements; excess bin = presence bin mod QG_B1");
 static_assert(QM_K % QM_KBE == 0 && QM_NKB >= QM_STAGES && QM_STAGES == 4, "whole K-blocks; the K loop's tail is written for a ring of four");
-static_assert(QM_TILE * QM_OUT_STRIDE <= QM_STAGES * QM_STAGE_BYTES, "the epilogue's byte tile reuses the ring");
+static_assert(QM_META_OFF % 16 == 0 && QM_LDS_BYTES <= 160 * 1024, "the epilogue's byte tiles reuse the ring; the tile's row / column tables sit behind both");
 
 __host__ __device__ __forceinline__ uint32_t qg_bin(uint32_t g)
 {
@@ -160,6 +163,61 @@ __device__ __forceinline__ void qm_glds16(const uint8_t *gsrc, uint32_t lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// ---- pieces of the epilogue (scripts/ubench/epilogue_ops.hip checks each of them on the device) ----
+typedef unsigned short qm_us2 __attribute__((ext_vector_type(2)));
+
+// dword of lane S of the caller's quad (DPP quad_perm:[S,S,S,S])
+template <int S> __device__ __forceinline__ uint32_t qm_quad_bcast(uint32_t w)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, S * 0x55, 0xf, 0xf, true);
+}
+// minimum / sum over the 16 lanes of a DPP row (row_shr:1, 2, 4, 8): the result is in lane 15 of the row
+template <int CTRL> __device__ __forceinline__ uint32_t qm_dpp_min(uint32_t x)
+{
+    const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, 0xf, 0xf, false);
+    return y < x ? y : x;
+}
+template <int CTRL> __device__ __forceinline__ uint32_t qm_dpp_add(uint32_t x)
+{
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t qm_row_min(uint32_t x) { x = qm_dpp_min<0x111>(x); x = qm_dpp_min<0x112>(x); x = qm_dpp_min<0x114>(x); return qm_dpp_min<0x118>(x); }
+__device__ __forceinline__ uint32_t qm_row_add(uint32_t x) { x = qm_dpp_add<0x111>(x); x = qm_dpp_add<0x112>(x); x = qm_dpp_add<0x114>(x); return qm_dpp_add<0x118>(x); }
+
+// A chunk of 16 bound bytes (v, byte k = position k of the chunk) -> key = the smallest (bound << 8 | base + k) over the positions k of
+// the bit mask `eligible`, hub = the number of positions of `inside` whose bound is <= QM_HUB_BOUND.  Whole chunks (the interior of the
+// band: almost every chunk) are done four bytes per instruction: "> 36" per byte by a carry-free add, the keys as packed 16-bit minima.
+__device__ __forceinline__ void qm_chunk_stats(const uint4 v, uint32_t inside, uint32_t eligible, uint32_t base, uint32_t &key, uint32_t &hub)
+{
+    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+    if (inside == 0xffffu && eligible == 0xffffu) {
+        qm_us2 m = {0xffff, 0xffff};
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t w = wv[d];
+            const uint32_t gt = (((w & 0x7f7f7f7fu) + 0x01010101u * (127u - QM_HUB_BOUND)) | w) & 0x80808080u;          // 0x80 per byte > QM_HUB_BOUND
+            cnt += (uint32_t)__builtin_popcount(gt ^ 0x80808080u);
+            const uint32_t b4 = base + 4u * (uint32_t)d;
+            const uint32_t ke = ((w << 8) & 0xff00ff00u) | (b4 | ((b4 + 2u) << 16)), ko = (w & 0xff00ff00u) | ((b4 + 1u) | ((b4 + 3u) << 16));
+            qm_us2 e, o;
+            __builtin_memcpy(&e, &ke, 4);
+            __builtin_memcpy(&o, &ko, 4);
+            m = __builtin_elementwise_min(m, __builtin_elementwise_min(e, o));
+        }
+        key = m.x < m.y ? m.x : m.y;
+        hub = cnt;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t bd = (wv[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        const uint32_t cand = (bd << 8) | (base + (uint32_t)k);
+        if ((eligible >> k) & 1u) key = cand < key ? cand : key;
+        hub += ((inside >> k) & 1u) && bd <= QM_HUB_BOUND ? 1u : 0u;
+    }
+}
+
 // One workgroup = one 256 x 256 tile of the bound matrix: columns = the entries p = 256 J .. + 255 (operand A), rows = the launch
 // slots s = 256 I .. + 255 of the main pass, i.e. the entries q = Q.entry(s) (operand B).  8 waves, wave (wp, wq) owns
 // 128 p x 64 q = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator registers).  The profiles stream through a ring of QM_STAGES K-blocks
@@ -168,10 +226,13 @@ __device__ __forceinline__ void qm_glds16(const uint8_t *gsrc, uint32_t lds_dst)
 // per LDS cycle) conflict-free; the swizzle is applied to the global source address, the LDS image stays lane-linear.
 // Any k-permutation that is the same for A and B leaves the dot products unchanged, so a lane simply takes 16 consecutive bytes.
 //
-// Epilogue: bound = min(255, ceil((max(|A|, |B|) - M) / q)) as bytes into an LDS tile [q][p], then (1) 16-byte stores into the
-// main pass' row layout lb[row_off[s] + (p - q - 1)] -- the host aligns the rows so that the address of p is congruent to p
-// mod 16 -- and the smallest admissible bound of every row (rowmin), (2) the smallest admissible bound of every column (colmin);
-// keys as in k_qgram_seed_pairs.
+// Epilogue (28 % of a tile's time before round 6's second half, when a thread took the bytes one at a time and the transposed matrix was
+// written a column per thread: profiles/r06m_mm_epilogue.txt): bound = min(255, ceil((max(|A|, |B|) - M) / q)) in float -- v_max, v_sub,
+// v_fma, and v_cvt_pk_u8_f32 rounds to nearest, saturates to [0, 255] and packs (exact for every integer |A| - M: ubench/epilogue_ops) --
+// into TWO byte tiles in LDS, out[q][p] and, through a 4 x 4 byte transpose over lane quads, outT[p][q]; then, 16 threads per row and 16
+// bytes per thread, (E2) 256-byte row pieces into the main pass' layout lb[row_off[s] + (p - q - 1)] -- the host aligns the rows so that
+// the address of p is congruent to p mod 16 -- with every row's smallest admissible bound (rowmin) and hub score, (E3) the same from
+// outT for the transposed matrix, the columns' smallest admissible bounds (colmin) and hub scores; keys as in k_qgram_seed_pairs.
 __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__ prof4, const uint32_t *__restrict__ psum, uint32_t n, uint32_t n_pad,
                                                       const uint2 *__restrict__ tiles, const unsigned long long *__restrict__ row_off,
                                                       const uint32_t *__restrict__ row_len, uint8_t *__restrict__ lb, QMap Q, uint32_t nq,
@@ -194,51 +255,22 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     QM_STAMP(0);
     const int r = lane & 31, h = lane >> 5;
 
-    uint8_t *meta = qm_lds + (size_t)QM_STAGES * QM_STAGE_BYTES;
-    uint32_t *m_sA = reinterpret_cast<uint32_t *>(meta);                  // |A| of the 256 columns
-    uint32_t *m_sB = m_sA + 256;                                          // |B| of the 256 rows
-    uint32_t *m_q = m_sB + 256;                                           // entry of the row's slot, 0xffffffff = no such slot
+    uint8_t *meta = qm_lds + (size_t)QM_META_OFF;
+    float *m_sA = reinterpret_cast<float *>(meta);                        // |A| of the 256 columns (as floats: the epilogue's arithmetic)
+    float *m_sB = m_sA + 256;                                             // |B| of the 256 rows
+    uint32_t *m_q = reinterpret_cast<uint32_t *>(m_sB + 256);             // entry of the row's slot, 0xffffffff = no such slot
     uint32_t *m_len = m_q + 256;                                          // row length
     unsigned long long *m_off = reinterpret_cast<unsigned long long *>(m_len + 256);
     uint32_t *m_flB = reinterpret_cast<uint32_t *>(m_off + 256);          // roles of the row entries: bit 0 query, bit 1 target
     uint16_t *m_tA = reinterpret_cast<uint16_t *>(m_flB + 256);           // per 16 columns: target flags, query flags
     uint16_t *m_qA = m_tA + 16;
-    uint32_t *m_cm = reinterpret_cast<uint32_t *>(m_qA + 16);             // column minima of the tile (bound << 8 | row)
-    uint32_t *m_slo = m_cm + 256;                                         // transposed rows: first slot, number of slots, offset of the first slot
+    uint16_t *m_tB = m_qA + 16;                                           // per 16 rows: target flags
+    uint32_t *m_slo = reinterpret_cast<uint32_t *>(m_tB + 16);            // transposed rows: first slot, number of slots, offset of the first slot
     uint32_t *m_lenT = m_slo + 256;
     unsigned long long *m_offT = reinterpret_cast<unsigned long long *>(m_lenT + 256);
-    uint32_t *m_cnt = reinterpret_cast<uint32_t *>(m_offT + 256);         // hub score of the tile's columns
 
-    if (tid < 256) {
-        const uint64_t p = (uint64_t)J * QM_TILE + tid;
-        m_sA[tid] = p < n ? psum[p] : 0u;
-        m_cm[tid] = 0xffffffffu;
-        m_cnt[tid] = 0u;
-        const bool tp = lbT != nullptr && p < n;
-        m_slo[tid] = tp ? sloT[p] : 0u;
-        m_lenT[tid] = tp ? lenT[p] : 0u;
-        m_offT[tid] = tp ? offT[p] : 0ull;
-        const uint32_t s = I * QM_TILE + tid;
-        const uint64_t qq = Q.entry(s);
-        const bool have = s < nq && qq < n;
-        m_q[tid] = have ? (uint32_t)qq : 0xffffffffu;
-        m_sB[tid] = have ? psum[qq] : 0u;
-        m_len[tid] = have ? row_len[s] : 0u;
-        m_off[tid] = have ? row_off[s] : 0ull;
-        m_flB[tid] = (have && rowmin != nullptr) ? ((qflag[qq] != 0 ? 1u : 0u) | (tflag[qq] != 0 ? 2u : 0u)) : 0u;
-    } else if (tid < 256 + 16) {
-        const int c = tid - 256;
-        uint32_t tm = 0, qm = 0;
-        if (rowmin != nullptr) {
-            for (int k = 0; k < 16; ++k) {
-                const uint64_t p = (uint64_t)J * QM_TILE + c * 16 + k;
-                if (p < n) { tm |= (tflag[p] != 0 ? 1u : 0u) << k; qm |= (qflag[p] != 0 ? 1u : 0u) << k; }
-            }
-        }
-        m_tA[c] = (uint16_t)tm; m_qA[c] = (uint16_t)qm;
-    }
-
-    // ---- global -> LDS: 2 operands x 256 rows x 4 slots = 2048 chunks of 16 B per K-block, 4 per thread
+    // ---- global -> LDS: 2 operands x 256 rows x 4 slots = 2048 chunks of 16 B per K-block, 4 per thread.  The first three K-blocks are
+    //      requested before anything else: the tile's row and column tables (dependent loads) arrive while they are under way
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)qm_lds;
     const uint8_t *gsrc[4];
     uint32_t ldst[4];
@@ -263,6 +295,36 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     };
 #pragma unroll
     for (int kb = 0; kb < QM_STAGES - 1; ++kb) issue(kb);
+
+    // the tile's tables: waves 0-3 take the columns (entries p), waves 4-7 the rows (slots s); the flag words per 16 columns / rows are wave votes
+    if (tid < 256) {
+        const uint64_t p = (uint64_t)J * QM_TILE + tid;
+        m_sA[tid] = p < n ? (float)psum[p] : 0.f;
+        const bool tp = lbT != nullptr && p < n;
+        m_slo[tid] = tp ? sloT[p] : 0u;
+        m_lenT[tid] = tp ? lenT[p] : 0u;
+        m_offT[tid] = tp ? offT[p] : 0ull;
+        const bool fl = rowmin != nullptr && p < n;
+        const unsigned long long bt = __ballot(fl && tflag[p] != 0), bq = __ballot(fl && qflag[p] != 0);
+        if (lane < 4) {
+            m_tA[wave * 4 + lane] = (uint16_t)(bt >> (16 * lane));
+            m_qA[wave * 4 + lane] = (uint16_t)(bq >> (16 * lane));
+        }
+    } else {
+        const int t = tid - 256;
+        const uint32_t s = I * QM_TILE + (uint32_t)t;
+        const uint64_t qq = Q.entry(s);
+        const bool have = s < nq && qq < n;
+        m_q[t] = have ? (uint32_t)qq : 0xffffffffu;
+        m_sB[t] = have ? (float)psum[qq] : 0.f;
+        m_len[t] = have ? row_len[s] : 0u;
+        m_off[t] = have ? row_off[s] : 0ull;
+        const bool fl = have && rowmin != nullptr;
+        const bool isq = fl && qflag[qq] != 0, ist = fl && tflag[qq] != 0;
+        m_flB[t] = (isq ? 1u : 0u) | (ist ? 2u : 0u);
+        const unsigned long long bt = __ballot(ist);
+        if (lane < 4) m_tB[(wave - 4) * 4 + lane] = (uint16_t)(bt >> (16 * lane));
+    }
 
     qm_v16f acc[4][2];
 #pragma unroll
@@ -364,36 +426,45 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     __syncthreads();          // every wave is done with the ring: it becomes the byte tile out[q][p]
     QM_STAMP(2);
 
-    // ---- E1: accumulators -> bound bytes.  C layout: column (B side, q) = lane & 31, row (A side, p) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // ---- E1: accumulators -> bound bytes, twice.  C layout: column (B side, q) = lane & 31, row (A side, p) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
+    //      a lane's four registers 4 g .. 4 g + 3 are one dword of out[q][p .. p + 3]; the four lanes of a quad (q .. q + 3) exchange bytes for outT[p + t][q .. q + 3]
     uint32_t *out32 = reinterpret_cast<uint32_t *>(qm_lds);
+    uint32_t *outT32 = reinterpret_cast<uint32_t *>(qm_lds + QM_TILE * QM_OUT_STRIDE);
+    {
+        const uint32_t t4 = (uint32_t)lane & 3u;
+        const uint32_t sel_lo = 0x0c0c0000u | ((4u + t4) << 8) | t4, sel_hi = 0x00000c0cu | ((4u + t4) << 24) | (t4 << 16);
+        float sbf[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ql = wq * 64 + j * 32 + r;
-        const uint32_t sb = m_sB[ql];
+        for (int j = 0; j < 2; ++j) sbf[j] = m_sB[wq * 64 + j * 32 + r];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int pl = wp * 128 + i * 32 + 8 * g + 4 * h;
-                uint32_t w = 0;
+                const float4 sa = *reinterpret_cast<const float4 *>(m_sA + pl);
+                const float sav[4] = {sa.x, sa.y, sa.z, sa.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t sa = m_sA[pl + k];
-                    const int32_t mm = (int32_t)acc[i][j][4 * g + k];
-                    int32_t v = (int32_t)(sa > sb ? sa : sb) - mm;
-                    v = v < 0 ? 0 : v;
-                    uint32_t bd = ((uint32_t)v + (uint32_t)QG_Q - 1u) / (uint32_t)QG_Q;
-                    bd = bd < 255u ? bd : 255u;
-                    w |= bd << (8 * k);
+                for (int j = 0; j < 2; ++j) {
+                    const int ql = wq * 64 + j * 32 + r;
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // floor((t + 8) / 9) for t >= 0, 0 below: (t + 8.5) / 9 - 0.5 is at least 0.055 away from a rounding boundary for every integer t
+                        const float t = __builtin_fmaxf(sav[k], sbf[j]) - acc[i][j][4 * g + k];
+                        const float z = __builtin_fmaf(t, 1.0f / (float)QG_Q, (8.5f / (float)QG_Q) - 0.5f);
+                        w = __builtin_amdgcn_cvt_pk_u8_f32(z, (uint32_t)k, w);
+                    }
+                    out32[ql * (QM_OUT_STRIDE / 4) + (pl >> 2)] = w;
+                    const uint32_t a0 = qm_quad_bcast<0>(w), a1 = qm_quad_bcast<1>(w), a2 = qm_quad_bcast<2>(w), a3 = qm_quad_bcast<3>(w);
+                    outT32[(pl + (int)t4) * (QM_OUTT_STRIDE / 4) + ((ql & ~3) >> 2)] = __builtin_amdgcn_perm(a1, a0, sel_lo) | __builtin_amdgcn_perm(a3, a2, sel_hi);
                 }
-                out32[ql * (QM_OUT_STRIDE / 4) + (pl >> 2)] = w;
             }
         }
     }
     __syncthreads();
     QM_STAMP(3);
 
-    // ---- E2: rows.  16 threads per row (16 columns each), 32 rows per round
+    // ---- E2: rows of the matrix.  16 threads per row (16 columns each), 32 rows per round
     {
         const int chunk = tid & 15;
         const uint64_t p0 = (uint64_t)J * QM_TILE + (uint64_t)chunk * 16;
@@ -419,23 +490,11 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
                 // address of column p: row_off + (p - q - 1), congruent to p mod 16 by the host's row alignment
                 *reinterpret_cast<uint4 *>(lb + (m_off[ql] + (unsigned long long)((int64_t)p0 - (int64_t)qe - 1))) = v;
                 const uint32_t inside = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                const uint32_t vm = (m_flB[ql] & 1u) ? (inside & tmask) : 0u;
-                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t bd = (wv[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                    const uint32_t cand = (bd << 8) | (uint32_t)(chunk * 16 + k);
-                    if ((vm >> k) & 1u) key = cand < key ? cand : key;
-                    hub += ((inside >> k) & 1u) && bd <= QM_HUB_BOUND ? 1u : 0u;
-                }
+                qm_chunk_stats(v, inside, (m_flB[ql] & 1u) ? (inside & tmask) : 0u, (uint32_t)(chunk * 16), key, hub);
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const uint32_t w = (uint32_t)__shfl_xor((int)key, o, 64);
-                key = w < key ? w : key;
-                hub += (uint32_t)__shfl_xor((int)hub, o, 64);
-            }
-            if (chunk == 0) {
+            key = qm_row_min(key);
+            hub = qm_row_add(hub);
+            if (chunk == 15) {
                 if (rowmin != nullptr && key != 0xffffffffu) {
                     const uint64_t e = (uint64_t)J * QM_TILE + (key & 0xffu) - (uint64_t)qe - 1;
                     atomicMin(rowmin + ((size_t)I * QM_TILE + ql) * QM_SEEDS + (J % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)e);
@@ -448,42 +507,35 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     __syncthreads();
     QM_STAMP(4);
 #endif
-    // ---- E3: columns.  Thread = one column x half of the rows: the transposed matrix (row p of lbT = the slots whose window holds p,
-    //      lbT[offT[p] + (slot - sloT[p])], address congruent to the slot mod 16), the columns' hub scores and smallest admissible bounds
+    // ---- E3: rows of the TRANSPOSED matrix (row p of lbT = the slots whose window holds p, lbT[offT[p] + (slot - sloT[p])], address congruent to the
+    //      slot mod 16), from outT in the same shape: 16 threads per row (16 slots each), 32 rows per round; the columns' hub scores and smallest admissible bounds
     if (lbT != nullptr || colmin != nullptr) {
-        const int pl = tid & 255, hh = tid >> 8;
-        const uint32_t slo = m_slo[pl], shi = slo + m_lenT[pl];
-        const unsigned long long ot = m_offT[pl];
-        const bool p_isq = colmin != nullptr && ((m_qA[pl >> 4] >> (pl & 15)) & 1u) != 0;
-        uint32_t best = 0xffffffffu, hub = 0;
-        for (int c = 0; c < 8; ++c) {
-            const int ql0 = hh * 128 + c * 16;
-            const uint32_t s0 = I * QM_TILE + (uint32_t)ql0;
-            if (s0 + 16u <= slo || s0 >= shi) continue;
-            uint32_t wv[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t bd = qm_lds[(ql0 + k) * QM_OUT_STRIDE + pl];
-                wv[k >> 2] |= bd << (8 * (k & 3));
-                const bool ok = s0 + (uint32_t)k >= slo && s0 + (uint32_t)k < shi;
-                hub += ok && bd <= QM_HUB_BOUND ? 1u : 0u;
-                if (p_isq && ok && (m_flB[ql0 + k] & 2u)) { const uint32_t cand = (bd << 8) | (uint32_t)(ql0 + k); best = cand < best ? cand : best; }
+        const int chunk = tid & 15;
+        const uint32_t s0 = I * QM_TILE + (uint32_t)(chunk * 16);
+        const uint32_t tmask = m_tB[chunk];
+        const uint8_t *outT = qm_lds + QM_TILE * QM_OUT_STRIDE;
+        for (int rr = 0; rr < 8; ++rr) {
+            const int pl = rr * 32 + (tid >> 4);
+            const uint32_t slo = m_slo[pl], shi = slo + m_lenT[pl];
+            // valid slots of this chunk: slo <= s < shi
+            const int64_t first = (int64_t)slo - (int64_t)s0, last = (int64_t)shi - (int64_t)s0;
+            const int lo = first < 0 ? 0 : (first > 16 ? 16 : (int)first), hi = last < 0 ? 0 : (last > 16 ? 16 : (int)last);
+            uint32_t key = 0xffffffffu, hub = 0;
+            if (hi > lo) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(outT + pl * QM_OUTT_STRIDE + chunk * 16);
+                if (lbT != nullptr) *reinterpret_cast<uint4 *>(lbT + (m_offT[pl] + (unsigned long long)((int64_t)s0 - (int64_t)slo))) = v;
+                const uint32_t inside = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                const bool p_isq = colmin != nullptr && ((m_qA[pl >> 4] >> (pl & 15)) & 1u) != 0;
+                qm_chunk_stats(v, inside, p_isq ? (inside & tmask) : 0u, (uint32_t)(chunk * 16), key, hub);
             }
-            if (lbT != nullptr) {
-                uint4 v; v.x = wv[0]; v.y = wv[1]; v.z = wv[2]; v.w = wv[3];
-                *reinterpret_cast<uint4 *>(lbT + (ot + (unsigned long long)((int64_t)s0 - (int64_t)slo))) = v;
+            key = qm_row_min(key);
+            hub = qm_row_add(hub);
+            if (chunk == 15) {
+                const uint64_t p = (uint64_t)J * QM_TILE + (uint64_t)pl;
+                if (colmin != nullptr && key != 0xffffffffu)
+                    atomicMin(colmin + p * QM_SEEDS + (I % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
+                if (score != nullptr && hub && p < n) atomicAdd(score + p, hub);
             }
-        }
-        if (best != 0xffffffffu) atomicMin(&m_cm[pl], best);
-        if (hub) atomicAdd(&m_cnt[pl], hub);
-        __syncthreads();
-        if (tid < 256) {
-            const uint64_t p = (uint64_t)J * QM_TILE + tid;
-            if (colmin != nullptr && m_cm[tid] != 0xffffffffu) {
-                const uint32_t key = m_cm[tid];
-                atomicMin(colmin + p * QM_SEEDS + (I % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
-            }
-            if (score != nullptr && m_cnt[tid] != 0 && p < n) atomicAdd(score + p, m_cnt[tid]);
         }
     }
 #ifdef ISOCON_QM_TIMELINE
