@@ -185,19 +185,33 @@ __device__ __forceinline__ uint32_t qm_row_min(uint32_t x) { x = qm_dpp_min<0x11
 __device__ __forceinline__ uint32_t qm_row_add(uint32_t x) { x = qm_dpp_add<0x111>(x); x = qm_dpp_add<0x112>(x); x = qm_dpp_add<0x114>(x); return qm_dpp_add<0x118>(x); }
 
 // A chunk of 16 bound bytes (v, byte k = position k of the chunk) -> key = the smallest (bound << 8 | base + k) over the positions k of
-// the bit mask `eligible`, hub = the number of positions of `inside` whose bound is <= QM_HUB_BOUND.  Whole chunks (the interior of the
-// band: almost every chunk) are done four bytes per instruction: "> 36" per byte by a carry-free add, the keys as packed 16-bit minima.
+// the bit mask `eligible`, hub = the number of positions of `inside` whose bound is <= QM_HUB_BOUND.  Whole masks (the interior of the
+// band: almost every chunk; every entry a query and a target) are done four bytes per instruction: "> 36" per byte by a carry-free add, the
+// keys as packed 16-bit minima; a chunk without eligible positions (reads against few candidates: most chunks) has no key to find.
 __device__ __forceinline__ void qm_chunk_stats(const uint4 v, uint32_t inside, uint32_t eligible, uint32_t base, uint32_t &key, uint32_t &hub)
 {
     const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-    if (inside == 0xffffu && eligible == 0xffffu) {
-        qm_us2 m = {0xffff, 0xffff};
+    if (inside == 0xffffu) {
         uint32_t cnt = 0;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const uint32_t w = wv[d];
             const uint32_t gt = (((w & 0x7f7f7f7fu) + 0x01010101u * (127u - QM_HUB_BOUND)) | w) & 0x80808080u;          // 0x80 per byte > QM_HUB_BOUND
             cnt += (uint32_t)__builtin_popcount(gt ^ 0x80808080u);
+        }
+        hub += cnt;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t bd = (wv[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            hub += ((inside >> k) & 1u) && bd <= QM_HUB_BOUND ? 1u : 0u;
+        }
+    }
+    if (eligible == 0xffffu) {
+        qm_us2 m = {0xffff, 0xffff};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t w = wv[d];
             const uint32_t b4 = base + 4u * (uint32_t)d;
             const uint32_t ke = ((w << 8) & 0xff00ff00u) | (b4 | ((b4 + 2u) << 16)), ko = (w & 0xff00ff00u) | ((b4 + 1u) | ((b4 + 3u) << 16));
             qm_us2 e, o;
@@ -205,16 +219,15 @@ __device__ __forceinline__ void qm_chunk_stats(const uint4 v, uint32_t inside, u
             __builtin_memcpy(&o, &ko, 4);
             m = __builtin_elementwise_min(m, __builtin_elementwise_min(e, o));
         }
-        key = m.x < m.y ? m.x : m.y;
-        hub = cnt;
-        return;
-    }
+        const uint32_t k16 = m.x < m.y ? m.x : m.y;
+        key = k16 < key ? k16 : key;
+    } else if (eligible != 0u) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t bd = (wv[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        const uint32_t cand = (bd << 8) | (base + (uint32_t)k);
-        if ((eligible >> k) & 1u) key = cand < key ? cand : key;
-        hub += ((inside >> k) & 1u) && bd <= QM_HUB_BOUND ? 1u : 0u;
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t bd = (wv[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            const uint32_t cand = (bd << 8) | (base + (uint32_t)k);
+            if ((eligible >> k) & 1u) key = cand < key ? cand : key;
+        }
     }
 }
 
