@@ -31,8 +31,14 @@ static constexpr int QG_B0 = ISOCON_QG_B0;       // presence bins (the 4^q gram 
                                                  // (nn_filter.hpp) behind this bound a survivor costs 0.13 ns instead of 1.1, and the cheaper contraction wins --
                                                  // C3 step 9.04 / 8.55 / 8.46 / 8.33 / 8.43 / 8.67 ms at 20 480 / 16 384 / 14 336 / 12 288 / 10 240 / 8 192 bins
                                                  // (profiles/r06b_b0_sweep.txt)
-static constexpr int QG_B1 = 2048;        // excess bins (presence bin mod QG_B1)
-static constexpr int QG_CAP = 2;          // levels kept of an excess bin
+#ifndef ISOCON_QG_B1
+#define ISOCON_QG_B1 2048
+#endif
+#ifndef ISOCON_QG_CAP
+#define ISOCON_QG_CAP 2
+#endif
+static constexpr int QG_B1 = ISOCON_QG_B1;       // excess bins (presence bin mod QG_B1)
+static constexpr int QG_CAP = ISOCON_QG_CAP;     // levels kept of an excess bin
 static constexpr int QM_K = QG_B0 + QG_B1 * QG_CAP;     // binary elements per profile
 static constexpr int QM_KBE = 128;        // elements per K-block: 64 B per row (4 slots of 16 B = 32 fp4 elements)
 static constexpr int QM_ROWB = QM_KBE / 2;
