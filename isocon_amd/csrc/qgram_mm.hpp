@@ -23,7 +23,10 @@
 
 namespace isocon {
 
-static constexpr int QG_Q = 9;            // gram length
+#ifndef ISOCON_QG_Q
+#define ISOCON_QG_Q 9
+#endif
+static constexpr int QG_Q = ISOCON_QG_Q;         // gram length
 #ifndef ISOCON_QG_B0                      // (experiments: scripts/dev/build_variant.sh NAME -DISOCON_QG_B0=...)
 #define ISOCON_QG_B0 12288
 #endif
@@ -468,9 +471,9 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
                     uint32_t w = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        // floor((t + 8) / 9) for t >= 0, 0 below: (t + 8.5) / 9 - 0.5 is at least 0.055 away from a rounding boundary for every integer t
+                        // floor((t + q - 1) / q) for t >= 0, 0 below: (t + q - 0.5) / q - 0.5 is at least 0.5 / q away from a rounding boundary for every integer t
                         const float t = __builtin_fmaxf(sav[k], sbf[j]) - acc[i][j][4 * g + k];
-                        const float z = __builtin_fmaf(t, 1.0f / (float)QG_Q, (8.5f / (float)QG_Q) - 0.5f);
+                        const float z = __builtin_fmaf(t, 1.0f / (float)QG_Q, (((float)QG_Q - 0.5f) / (float)QG_Q) - 0.5f);
                         w = __builtin_amdgcn_cvt_pk_u8_f32(z, (uint32_t)k, w);
                     }
                     out32[ql * (QM_OUT_STRIDE / 4) + (pl >> 2)] = w;
