@@ -306,6 +306,9 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
             ent = Q.entry(I * QM_TILE + (uint32_t)row);
             if (ent >= n_pad) ent = n_pad - 1;
         }
+#ifdef ISOCON_QM_SAMEPANEL          // timing experiment only (wrong bounds): every tile streams the same two operand panels -- what the K loop costs when nothing misses L2
+        ent = (uint64_t)row;
+#endif
         gsrc[it] = prof4 + ent * QM_ROWB + ls * 16;
         ldst[it] = lds0 + (uint32_t)((it >> 1) * (QM_TILE * QM_ROWB) + ((it & 1) * 512 + wave * 64) * 16);
     }
