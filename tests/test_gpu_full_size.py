@@ -77,6 +77,19 @@ def test_c3_every_row_equals_the_reference_loop_fixture(c3):
     assert bench.graph_digest(best, row_ptr, cols) == bench.EXPECTED_GRAPH_DIGEST_C3
 
 
+def test_c3_pruning_counters(c3):
+    """The work the search does at C3, not only its result: the three counters below are deterministic (the seeds finish before the lists are
+    built, hub scores and seed keys come out of the bound kernel's epilogue) and have been the same through every rewrite of that epilogue
+    (profiles/r06j_bench.json).  A change of the seeds, of the hub scores that decide which end owns a pair, of either bound or of a
+    threshold moves them without touching the graph -- this is where it shows.  A DELIBERATE change of a tuning constant (bins, gram
+    length, probe stride) updates the numbers here."""
+    seqs, st, best, row_ptr, cols, stats = c3
+    assert int(stats["pairs_prefiltered"]) == 293119143          # window pairs rejected by the q-gram bound
+    assert int(stats["pairs_block_rejected"]) == 13913023        # survivors rejected by the block bound (both passes)
+    assert int(stats["pairs_evaluated"]) == 418136               # pairs aligned (seeds not counted)
+    assert int(stats["pairs_lanes"]) == int(stats["pairs_evaluated"])          # no table launch at C3: what is left is aligned one pair per lane
+
+
 def test_c3_alignments_roundtrip(c3):
     """SW on 256 (read, NN) pairs at full length: un-gapped alignment == input (correction_module.py:273-275),
     counts consistent, score identity."""
