@@ -53,7 +53,7 @@ static constexpr int QM_STAGE_BYTES = 2 * QM_TILE * QM_ROWB;
 static constexpr int QM_OUT_STRIDE = QM_TILE + 8;       // bytes per row of the epilogue's byte tile out[q][p] in LDS (66 dwords: the dword writes of a wave hit 64 banks)
 static constexpr int QM_OUTT_STRIDE = QM_TILE + 32;     // bytes per row of the transposed byte tile outT[p][q] (72 dwords = 8 mod 64: the quad-transposed dword writes hit 64 banks; rows 16-byte aligned)
 static constexpr int QM_EPI_BYTES = QM_TILE * (QM_OUT_STRIDE + QM_OUTT_STRIDE);          // both byte tiles: they take the ring's place after the K loop
-static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 3 * 16 * 2 + 256 * (4 + 4 + 8);          // the tile's row and column tables (k_qgram_mm: m_sA .. m_offT)
+static constexpr int QM_META_BYTES = 256 * (4 + 4 + 4 + 4 + 8 + 4) + 3 * 16 * 2 + 256 * (4 + 4 + 8) + 4 * 256 * 4;          // the tile's row and column tables (k_qgram_mm: m_sA .. m_chub)
 #ifndef ISOCON_QM_SEEDS
 #define ISOCON_QM_SEEDS 4
 #endif
@@ -290,6 +290,10 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     uint32_t *m_slo = reinterpret_cast<uint32_t *>(m_tB + 16);            // transposed rows: first slot, number of slots, offset of the first slot
     uint32_t *m_lenT = m_slo + 256;
     unsigned long long *m_offT = reinterpret_cast<unsigned long long *>(m_lenT + 256);
+    uint32_t *m_rkey = reinterpret_cast<uint32_t *>(m_offT + 256);        // per row / per column of the tile: smallest admissible (bound << 8 | index), hub count --
+    uint32_t *m_rhub = m_rkey + 256;                                      // collected by E2 / E3, sent to rowmin / colmin / score in ONE pass behind them
+    uint32_t *m_ckey = m_rhub + 256;
+    uint32_t *m_chub = m_ckey + 256;
 
     // ---- global -> LDS: 2 operands x 256 rows x 4 slots = 2048 chunks of 16 B per K-block, 4 per thread.  The first three K-blocks are
     //      requested before anything else: the tile's row and column tables (dependent loads) arrive while they are under way
@@ -489,23 +493,22 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     __syncthreads();
     QM_STAMP(3);
 
-    // ---- E2: rows of the matrix.  16 threads per row (16 columns each), 32 rows per round
+    // ---- E2: rows of the matrix.  16 threads per row (16 columns each), 32 rows per round.  (Offsets inside the tile fit 32 bits: n < 2^30, build_bounds.)
     {
         const int chunk = tid & 15;
-        const uint64_t p0 = (uint64_t)J * QM_TILE + (uint64_t)chunk * 16;
+        const int32_t p0 = (int32_t)(J * QM_TILE) + chunk * 16;
         const uint32_t tmask = m_tA[chunk];
+        const int32_t nn = (int32_t)n - p0;                                    // columns of the chunk below n
         for (int rr = 0; rr < 8; ++rr) {
             const int ql = rr * 32 + (tid >> 4);
             const uint32_t qe = m_q[ql];
-            const uint32_t rl = m_len[ql];
             // valid columns of this chunk: q < p <= q + rl, p < n
-            int lo = 0, hi = 0;
+            int32_t lo = 0, hi = 0;
             if (qe != 0xffffffffu) {
-                const int64_t first = (int64_t)qe + 1 - (int64_t)p0, last = (int64_t)qe + 1 + (int64_t)rl - (int64_t)p0;        // [first, last)
-                lo = first < 0 ? 0 : (first > 16 ? 16 : (int)first);
-                hi = last < 0 ? 0 : (last > 16 ? 16 : (int)last);
-                const int64_t nn = (int64_t)n - (int64_t)p0;
-                if (nn < hi) hi = nn < 0 ? 0 : (int)nn;
+                const int32_t first = (int32_t)qe + 1 - p0, last = first + (int32_t)m_len[ql];        // [first, last)
+                lo = first < 0 ? 0 : (first > 16 ? 16 : first);
+                hi = last < nn ? last : nn;
+                hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
             }
             uint32_t key = 0xffffffffu, hub = 0;
             if (hi > lo) {
@@ -513,19 +516,13 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
                 const uint2 v1 = *reinterpret_cast<const uint2 *>(qm_lds + ql * QM_OUT_STRIDE + chunk * 16 + 8);
                 uint4 v; v.x = v0.x; v.y = v0.y; v.z = v1.x; v.w = v1.y;
                 // address of column p: row_off + (p - q - 1), congruent to p mod 16 by the host's row alignment
-                *reinterpret_cast<uint4 *>(lb + (m_off[ql] + (unsigned long long)((int64_t)p0 - (int64_t)qe - 1))) = v;
+                *reinterpret_cast<uint4 *>(lb + (m_off[ql] + (unsigned long long)(long long)(p0 - (int32_t)qe - 1))) = v;
                 const uint32_t inside = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
                 qm_chunk_stats(v, inside, (m_flB[ql] & 1u) ? (inside & tmask) : 0u, (uint32_t)(chunk * 16), key, hub);
             }
             key = qm_row_min(key);
             hub = qm_row_add(hub);
-            if (chunk == 15) {
-                if (rowmin != nullptr && key != 0xffffffffu) {
-                    const uint64_t e = (uint64_t)J * QM_TILE + (key & 0xffu) - (uint64_t)qe - 1;
-                    atomicMin(rowmin + ((size_t)I * QM_TILE + ql) * QM_SEEDS + (J % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)e);
-                }
-                if (score != nullptr && hub) atomicAdd(score + qe, hub);
-            }
+            if (chunk == 15) { m_rkey[ql] = key; m_rhub[ql] = hub; }
         }
     }
 #ifdef ISOCON_QM_TIMELINE
@@ -534,34 +531,47 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
 #endif
     // ---- E3: rows of the TRANSPOSED matrix (row p of lbT = the slots whose window holds p, lbT[offT[p] + (slot - sloT[p])], address congruent to the
     //      slot mod 16), from outT in the same shape: 16 threads per row (16 slots each), 32 rows per round; the columns' hub scores and smallest admissible bounds
-    if (lbT != nullptr || colmin != nullptr) {
+    const bool columns = lbT != nullptr || colmin != nullptr;
+    if (columns) {
         const int chunk = tid & 15;
-        const uint32_t s0 = I * QM_TILE + (uint32_t)(chunk * 16);
+        const int32_t s0 = (int32_t)(I * QM_TILE) + chunk * 16;
         const uint32_t tmask = m_tB[chunk];
         const uint8_t *outT = qm_lds + QM_TILE * QM_OUT_STRIDE;
         for (int rr = 0; rr < 8; ++rr) {
             const int pl = rr * 32 + (tid >> 4);
-            const uint32_t slo = m_slo[pl], shi = slo + m_lenT[pl];
-            // valid slots of this chunk: slo <= s < shi
-            const int64_t first = (int64_t)slo - (int64_t)s0, last = (int64_t)shi - (int64_t)s0;
-            const int lo = first < 0 ? 0 : (first > 16 ? 16 : (int)first), hi = last < 0 ? 0 : (last > 16 ? 16 : (int)last);
+            const int32_t slo = (int32_t)m_slo[pl];
+            // valid slots of this chunk: slo <= s < slo + lenT
+            const int32_t first = slo - s0, last = first + (int32_t)m_lenT[pl];
+            const int32_t lo = first < 0 ? 0 : (first > 16 ? 16 : first), hi = last < 0 ? 0 : (last > 16 ? 16 : last);
             uint32_t key = 0xffffffffu, hub = 0;
             if (hi > lo) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(outT + pl * QM_OUTT_STRIDE + chunk * 16);
-                if (lbT != nullptr) *reinterpret_cast<uint4 *>(lbT + (m_offT[pl] + (unsigned long long)((int64_t)s0 - (int64_t)slo))) = v;
+                if (lbT != nullptr) *reinterpret_cast<uint4 *>(lbT + (m_offT[pl] + (unsigned long long)(long long)(s0 - slo))) = v;
                 const uint32_t inside = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
                 const bool p_isq = colmin != nullptr && ((m_qA[pl >> 4] >> (pl & 15)) & 1u) != 0;
                 qm_chunk_stats(v, inside, p_isq ? (inside & tmask) : 0u, (uint32_t)(chunk * 16), key, hub);
             }
             key = qm_row_min(key);
             hub = qm_row_add(hub);
-            if (chunk == 15) {
-                const uint64_t p = (uint64_t)J * QM_TILE + (uint64_t)pl;
-                if (colmin != nullptr && key != 0xffffffffu)
-                    atomicMin(colmin + p * QM_SEEDS + (I % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
-                if (score != nullptr && hub && p < n) atomicAdd(score + p, hub);
-            }
+            if (chunk == 15) { m_ckey[pl] = key; m_chub[pl] = hub; }
         }
+    }
+    // ---- E4: one entry of rowmin / colmin / score per row and per column of the tile (the first half of the workgroup the rows, the second the columns)
+    __syncthreads();
+    if (tid < 256) {
+        const uint32_t key = m_rkey[tid], hub = m_rhub[tid], qe = m_q[tid];
+        if (rowmin != nullptr && key != 0xffffffffu) {
+            const uint64_t e = (uint64_t)J * QM_TILE + (key & 0xffu) - (uint64_t)qe - 1;
+            atomicMin(rowmin + ((size_t)I * QM_TILE + (uint32_t)tid) * QM_SEEDS + (J % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)e);
+        }
+        if (score != nullptr && hub) atomicAdd(score + qe, hub);
+    } else if (columns) {
+        const int pl = tid - 256;
+        const uint32_t key = m_ckey[pl], hub = m_chub[pl];
+        const uint64_t p = (uint64_t)J * QM_TILE + (uint64_t)pl;
+        if (colmin != nullptr && key != 0xffffffffu)
+            atomicMin(colmin + p * QM_SEEDS + (I % QM_SEEDS), ((unsigned long long)(key >> 8) << 32) | (unsigned long long)m_q[key & 0xffu]);
+        if (score != nullptr && hub && p < n) atomicAdd(score + p, hub);
     }
 #ifdef ISOCON_QM_TIMELINE
     __syncthreads();
