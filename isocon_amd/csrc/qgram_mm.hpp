@@ -462,16 +462,18 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
     {
         const uint32_t t4 = (uint32_t)lane & 3u;
         const uint32_t sel_lo = 0x0c0c0000u | ((4u + t4) << 8) | t4, sel_hi = 0x00000c0cu | ((4u + t4) << 24) | (t4 << 16);
-        float sbf[2];
+        // (|A| and |B| are non-negative floats: their maximum is the maximum of their bit patterns -- an integer v_max needs no canonicalised inputs)
+        const uint32_t *m_sAu = reinterpret_cast<const uint32_t *>(m_sA), *m_sBu = reinterpret_cast<const uint32_t *>(m_sB);
+        uint32_t sbf[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) sbf[j] = m_sB[wq * 64 + j * 32 + r];
+        for (int j = 0; j < 2; ++j) sbf[j] = m_sBu[wq * 64 + j * 32 + r];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int pl = wp * 128 + i * 32 + 8 * g + 4 * h;
-                const float4 sa = *reinterpret_cast<const float4 *>(m_sA + pl);
-                const float sav[4] = {sa.x, sa.y, sa.z, sa.w};
+                const uint4 sa = *reinterpret_cast<const uint4 *>(m_sAu + pl);
+                const uint32_t sav[4] = {sa.x, sa.y, sa.z, sa.w};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int ql = wq * 64 + j * 32 + r;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void k_qgram_mm(const uint8_t *__restrict__
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         // floor((t + q - 1) / q) for t >= 0, 0 below: (t + q - 0.5) / q - 0.5 is at least 0.5 / q away from a rounding boundary for every integer t
-                        const float t = __builtin_fmaxf(sav[k], sbf[j]) - acc[i][j][4 * g + k];
+                        const float t = __uint_as_float(sav[k] > sbf[j] ? sav[k] : sbf[j]) - acc[i][j][4 * g + k];
                         const float z = __builtin_fmaf(t, 1.0f / (float)QG_Q, (((float)QG_Q - 0.5f) / (float)QG_Q) - 0.5f);
                         w = __builtin_amdgcn_cvt_pk_u8_f32(z, (uint32_t)k, w);
                     }
